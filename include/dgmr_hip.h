@@ -1,0 +1,235 @@
+/*
+ * dgmr_hip.h — C ABI of libdgmr_hip.so: the MI355X (gfx950) kernels behind the DGMR training step.
+ *
+ * The reference (openclimatefix/skillful_nowcasting) has NO native code and no FFI: every FLOP of
+ * `DGMR.training_step` (dgmr/dgmr.py:137-218) runs inside stock torch ops.  The boundary this library
+ * replaces is therefore "the torch op call sites on the hot path" (SURVEY.md §8a); each entry point
+ * below names the reference call sites it stands in for.  The Python host side
+ * (skillful_nowcasting_amd/_lib.py) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - Activations are fp32, channels-last: NHWC for 2-D, NDHWC for 3-D ("N D H W C"; 2-D == D 1).
+ *   - Conv weights are fp32 [Cout][KD][KH][KW][Cin] (a torch OIHW / OIDHW parameter held in
+ *     channels_last memory format has exactly this physical layout).
+ *   - Cin % 4 == 0 and Cout % 4 == 0 for every conv (true for every conv on the DGMR path; the single
+ *     Linear(768 -> 1) heads use dgmr_linear1_*).
+ *   - Every buffer (incl. workspaces) is allocated by the caller.  Kernels never allocate, free or
+ *     synchronise; every launch goes to the `stream` argument (a hipStream_t passed as void*), so the
+ *     calls are graph-capture safe.
+ *   - Return value: 0 on success, negative on error; dgmr_last_error() returns a thread-local message.
+ */
+#ifndef DGMR_HIP_H
+#define DGMR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGMR_ABI_VERSION 1
+
+int dgmr_abi_version(void);
+const char* dgmr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution (implicit GEMM on v_mfma_f32_32x32x2_f32).
+ * Replaces torch.nn.Conv2d / Conv3d forward+backward at every `conv2d(` / `get_conv_layer` call site:
+ * dgmr/common.py:43-66,113-137,192-215,266-286,350-384,451-455; dgmr/generators.py:52-56,67-73,84-90,
+ * 101-107,115-121; dgmr/layers/ConvGRU.py:29-55; dgmr/layers/Attention.py:38-66 — together with the
+ * ops the reference applies around them, fused into the operand load / epilogue:
+ *   relu on load            F.relu / nn.ReLU before a conv (common.py:77,80,146,151,230,232,296,298)
+ *   affine+relu on load     BatchNorm2d(train) + ReLU before a conv (common.py:76-80,145-151; generators.py:176)
+ *   nearest 2x on load      nn.Upsample(scale_factor=2) before a conv (common.py:142,148)
+ *   1/sigma epilogue scale  spectral_norm's W/sigma (torch/nn/utils/parametrizations.py:506-521)
+ *   residual add            `x2 + sc` (common.py:83,154,237,300)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dgmr_conv_args {
+    const float* x;        /* input [N][D][Hin][Win][Cin]; Hin,Win = H,W  (or H/2,W/2 when upsample) */
+    const float* w;        /* [Cout][KD][KH][KW][Cin] */
+    const float* bias;     /* [Cout] or NULL */
+    const float* scale;    /* per-group multiplier (1/sigma): scale[n / scale_group]; NULL = 1 */
+    const float* pre_a;    /* NULL, or per-(group,channel) a: x' = relu(x*a+b), [N/pre_group][Cin] */
+    const float* pre_b;
+    const float* addend;   /* NULL or [M][Cout]: added to the accumulator BEFORE scale */
+    const float* residual; /* NULL or [M][Cout]: added after scale+bias */
+    const float* mask_src; /* NULL or [M][Cout]: y = (mask_src*mask_a+mask_b > 0) ? y : 0  (relu backward) */
+    const float* mask_a;   /* NULL (plain mask_src > 0) or [N/mask_group][Cout] */
+    const float* mask_b;
+    float* y;              /* output [N][D][H][W][Cout] */
+    int32_t N, D, H, W;    /* output extent (== input extent after the optional upsample) */
+    int32_t Cin, Cout;
+    int32_t KD, KH, KW;    /* each 1 or 3; 'same' zero padding K/2, stride 1 */
+    int32_t upsample;      /* 1: x is [N][D][H/2][W/2][Cin], nearest-upsampled on the fly */
+    int32_t pre_relu;      /* 1: relu on the input (ignored when pre_a != NULL, which implies relu) */
+    int32_t scale_group;   /* samples per scale group (>=1) */
+    int32_t pre_group;     /* samples per pre_a/pre_b group */
+    int32_t mask_group;
+    int32_t act_relu;      /* 1: relu after scale+bias, before the residual add (F.relu(conv(..)), common.py:424) */
+} dgmr_conv_args;
+
+/* y = act(conv(pre(x), w) (+addend) *scale + bias) (+residual), masked.  Forward AND data-gradient (the
+ * latter with dgmr_conv_flip_weights()'ed weights and dy as x). */
+int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream);
+
+/* w_t[Cin][KD][KH][KW][Cout] = w[Cout][KD-1-kd][KH-1-kh][KW-1-kw][Cin]: weights of the transposed
+ * (data-gradient) convolution. */
+int dgmr_conv_flip_weights(const float* w, float* w_t, int Cout, int Cin, int KD, int KH, int KW, void* stream);
+
+typedef struct dgmr_wgrad_args {
+    const float* x;      /* forward input, as in dgmr_conv_args (pre_* / upsample applied on load) */
+    const float* dy;     /* [M][Cout] gradient of the conv output (before scale: caller folds scale later) */
+    const float* pre_a;
+    const float* pre_b;
+    float* partial;      /* workspace [nsplit][Cout][K] (K = KD*KH*KW*Cin), written, not accumulated */
+    int32_t N, D, H, W, Cin, Cout, KD, KH, KW;
+    int32_t upsample, pre_relu, pre_group;
+    int32_t nsplit;      /* >= 1: the M = N*D*H*W reduction is cut into nsplit contiguous slabs */
+    int32_t reserved;
+} dgmr_wgrad_args;
+
+/* Weight-gradient partial sums: partial[s] = dy[slab s]^T * im2col(pre(x))[slab s]. */
+int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream);
+/* Suggested nsplit for a problem (pure host arithmetic). */
+int dgmr_conv_wgrad_nsplit(int M, int Cout, int K);
+
+/* g[Cout*K] = sum_s partial[s]; *dot += <g, w> (dot must be zeroed by the caller / previous finalize). */
+int dgmr_wgrad_reduce(const float* partial, int nsplit, int64_t numel, const float* w, float* g, float* dot, void* stream);
+/* Spectral-norm chain rule (torch/nn/utils/parametrizations.py:515-521):
+ *   gw[i][k] (+)= g[i][k]*inv_sigma - dot*inv_sigma^2 * u[i]*v[perm(k)],  then *dot = 0.
+ * v is stored in torch's logical (ci, kd, kh, kw) order, w/g in physical (kd,kh,kw,ci) order.
+ * accumulate != 0 adds into gw instead of overwriting.  u == v == NULL: plain scaled conv (no rank-1 term). */
+int dgmr_sn_wgrad_finalize(const float* g, float* gw, float* dot, const float* inv_sigma, const float* u, const float* v,
+                           int Cout, int Cin, int taps, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Spectral-norm power iteration — torch/nn/utils/parametrizations.py:454-521, called on every
+ * `spectral_norm(` module forward (list in SURVEY.md §8a row a14).
+ * train != 0: u <- normalize(W v), v <- normalize(W^T u) in place (eps-clamped), inv_sigma = 1/(u^T W v).
+ * train == 0: inv_sigma = 1/(u^T W v) with the stored u, v.
+ * u_save/v_save (may be NULL) receive copies of the u, v used for sigma (needed by the backward).
+ * scratch: 4 floats, zero on entry, left zero on exit.
+ * ---------------------------------------------------------------------------------------------- */
+int dgmr_spectral_sigma(const float* w, float* u, float* v, float* u_save, float* v_save, float* inv_sigma,
+                        float* scratch, float* tmp /* [Cout + K] */, int Cout, int Cin, int taps, float eps, int train,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-channel reductions / BatchNorm — torch.nn.BatchNorm2d (common.py:38-39,108-109; generators.py:113)
+ * and BatchNorm1d (discriminators.py:102,194) in train and eval mode.
+ * x is [G][R][C] (G groups of R rows); everything is per (group, channel).
+ * ---------------------------------------------------------------------------------------------- */
+/* sums[g][0][c] += sum_r x ; sums[g][1][c] += sum_r x^2   (double accumulators, zeroed by the caller). */
+int dgmr_bn_stats(const float* x, double* sums, int G, int64_t R, int C, void* stream);
+/* train: mean/var from sums -> a = gamma*rstd, b = beta - mean*a ; updates running stats once per group in order
+ * (momentum, unbiased var) and num_batches_tracked += G.  eval (sums == NULL): a,b from running stats (G == 1).
+ * save_mean/save_rstd: [G][C] for the backward. */
+int dgmr_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, float* a, float* b, float* save_mean, float* save_rstd, int G,
+                     int64_t R, int C, float eps, float momentum, void* stream);
+/* sums[g][0][c] = sum_r g ; sums[g][1][c] = sum_r g * xhat   with xhat = (x-mean)*rstd  (sums zeroed by caller). */
+int dgmr_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* rstd, double* sums, int G,
+                       int64_t R, int C, void* stream);
+/* dx = a*(gy - sums0/R - xhat*sums1/R) (+ dx_add); dgamma[c] += sum_g sums1, dbeta[c] += sum_g sums0 (if non-NULL). */
+int dgmr_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const double* sums, const float* dx_add, float* dx, float* dgamma, float* dbeta, int G, int64_t R,
+                      int C, int train, void* stream);
+/* out[c] (+)= sum_r x[r][c]  (conv / linear bias gradient).  tmp: 2*C doubles of scratch. */
+int dgmr_colsum(const float* x, float* out, double* tmp, int64_t R, int C, int accumulate, void* stream);
+/* y = x*a[g][c]+b[g][c]  (BatchNorm1d apply; no relu) */
+int dgmr_affine(const float* x, const float* a, const float* b, float* y, int G, int64_t R, int C, int relu, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pooling / resampling / layout — nn.AvgPool2d/3d (common.py:189-191; discriminators.py:68,165),
+ * PixelUnshuffle / PixelShuffle (common.py:326; discriminators.py:69,166; generators.py:123),
+ * nn.Upsample backward (common.py:121), einops rearrange (common.py:423).
+ * ---------------------------------------------------------------------------------------------- */
+/* y[N][D/pd][H/2][W/2][C] = mean over pd x 2 x 2 window (pd in {1,2}) (+ addend).  scale overrides 1/window when != 0
+ * (scale = 1 gives the sum-pool that is the backward of a nearest upsample).  Optional relu-backward mask on the
+ * output: y = (mask_src*mask_a+mask_b > 0) ? y : 0. */
+int dgmr_pool_fwd(const float* x, const float* addend, float* y, int N, int D, int H, int W, int C, int pd, float scale,
+                  const float* mask_src, const float* mask_a, const float* mask_b, int mask_group, void* stream);
+/* dx[N][D][H][W][C] = dy[n][d/pd][h/2][w/2][c] * scale  (scale = 1/window for avg-pool backward). */
+int dgmr_pool_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, int pd, float scale, void* stream);
+/* frames [B][T][C][H][W] (reference layout) -> channels-last space-to-depth tiles.
+ * out[(b*F+f)][H/(2p)][W/(2p)][4C] with channel (c*4 + dy*2 + dx) (PixelUnshuffle(2) order), frame = idx[f],
+ * p = pool ? 2 : 1 (AvgPool2d(2) first).  idx == NULL -> frames 0..F-1.  out_frame_major: 1 -> row (f*B+b). */
+int dgmr_frames_s2d(const float* frames, const int32_t* idx, float* out, int B, int T, int C, int H, int W, int F, int pool,
+                    int frame_major, void* stream);
+int dgmr_frames_s2d_bwd(const float* dout, const int32_t* idx, float* dframes /* accumulated */, int B, int T, int C, int H,
+                        int W, int F, int pool, int frame_major, void* stream);
+/* channels-last [B][h][w][4C] -> frames[b][t][c][2h][2w] (PixelShuffle(2)) and its backward. */
+int dgmr_d2s_frames(const float* x, float* frames, int B, int T, int t, int C, int h, int w, void* stream);
+int dgmr_d2s_frames_bwd(const float* dframes, float* dx, int B, int T, int t, int C, int h, int w, void* stream);
+/* Strided channel copy: dst[r][dst_off + c*dst_cstride] (+)= src[r][src_off + c*src_cstride], c < C.
+ * Implements torch.cat(dim=1) / channel slicing / "b t c h w -> b (c t) h w" on channels-last tensors. */
+int dgmr_copy_channels(const float* src, float* dst, int64_t R, int C, int src_C, int src_off, int src_cstride, int dst_C,
+                       int dst_off, int dst_cstride, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ConvGRU gating — dgmr/layers/ConvGRU.py:69-85.
+ * ---------------------------------------------------------------------------------------------- */
+/* rh = sigmoid(pr) * h */
+int dgmr_gru_gate_fwd(const float* pr, const float* h, float* rh, int64_t n, void* stream);
+/* dpr = d_rh * h * s*(1-s), dh = d_rh * s  (s = sigmoid(pr)) */
+int dgmr_gru_gate_bwd(const float* d_rh, const float* pr, const float* h, float* dpr, float* dh, int64_t n, void* stream);
+/* out = s(pu)*h + (1-s(pu))*relu(pc) */
+int dgmr_gru_blend_fwd(const float* pu, const float* h, const float* pc, float* out, int64_t n, void* stream);
+int dgmr_gru_blend_bwd(const float* dout, const float* pu, const float* h, const float* pc, float* dpu, float* dh, float* dpc,
+                       int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise helpers.
+ * ---------------------------------------------------------------------------------------------- */
+/* y = x * s[0] * host_scale   (s is a device scalar: an upstream gradient) */
+int dgmr_scale_by_dev(const float* x, const float* s, float host_scale, float* y, int64_t n, void* stream);
+/* y = alpha*a + beta*b (b may be NULL) */
+int dgmr_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream);
+/* dx = (x > 0) ? dy : 0 */
+int dgmr_relu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int dgmr_fill(float* p, float value, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Latent attention — dgmr/layers/Attention.py:9-20 (attention_einsum).  q, k, v, out are ONE sample,
+ * channels-last [H][W][Cq].  The reference hands the NCHW view [Cq][H][W] to an einsum written for
+ * "[h w c]": position p = cq*H + y (L = Cq*H of them), feature index = x (length W).  beta: [L][L] saved
+ * softmax.  tmp: [L][L] scratch.
+ * ---------------------------------------------------------------------------------------------- */
+int dgmr_attention_fwd(const float* q, const float* k, const float* v, float* beta, float* out, int Cq, int H, int W,
+                       void* stream);
+int dgmr_attention_bwd(const float* dout, const float* q, const float* k, const float* v, const float* beta, float* dq,
+                       float* dk, float* dv, float* tmp, int Cq, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Discriminator heads — discriminators.py:127-131,217-219: sum_hw(relu(x)), Linear(C -> 1).
+ * ---------------------------------------------------------------------------------------------- */
+int dgmr_relu_sum_hw_fwd(const float* x, float* y, int N, int HW, int C, void* stream);
+int dgmr_relu_sum_hw_bwd(const float* dy, const float* x, float* dx, int N, int HW, int C, void* stream);
+/* y[n] = scale * <x[n], w> + bias */
+int dgmr_linear1_fwd(const float* x, const float* w, const float* bias, const float* scale, float* y, int N, int C, void* stream);
+/* dx[n][c] = dy[n]*scale*w[c]; gw_raw[c] = sum_n dy[n]*x[n][c]; gb = sum_n dy[n] */
+int dgmr_linear1_bwd(const float* dy, const float* x, const float* w, const float* scale, float* dx, float* gw_raw, float* gb,
+                     int N, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses — dgmr/losses.py:172-192,307-319; dgmr/dgmr.py:20-33.
+ * ---------------------------------------------------------------------------------------------- */
+/* loss = mean(relu(1 - real)) + mean(relu(1 + gen)); d_real/d_gen = gradient * gscale */
+int dgmr_hinge_disc(const float* s_real, const float* s_gen, float* loss, float* d_real, float* d_gen, int n_real, int n_gen,
+                    void* stream);
+/* loss = mult * sum_i |mean_k pred_k[i] - y[i]| * max(y[i]+1, cap);  pred_k = preds + k*pred_stride.
+ * acc: one double, zero on entry, left zero.  dweight[i] (optional) = sign(.)*w/K, the per-prediction gradient / mult. */
+int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_stride, const float* target, float cap, double* acc,
+                        float* loss, float mult, float* dweight, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Adam — torch.optim.Adam as constructed at dgmr/dgmr.py:292-300 (eps 1e-8, no weight decay, no amsgrad).
+ * ---------------------------------------------------------------------------------------------- */
+int dgmr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+              int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGMR_HIP_H */

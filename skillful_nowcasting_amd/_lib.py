@@ -1,0 +1,124 @@
+"""ctypes binding of libdgmr_hip.so (C ABI declared in include/dgmr_hip.h).
+
+The product path has no fallback: if the shared library is missing or a kernel call fails, a
+``RuntimeError`` is raised.  Nothing here (or anywhere in this package) imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdgmr_hip.so")
+ABI_VERSION = 1
+
+P = c_void_p  # every device pointer and the stream travel as void*
+
+
+class ConvArgs(Structure):
+    """Mirror of ``dgmr_conv_args`` (include/dgmr_hip.h)."""
+
+    _fields_ = [
+        ("x", P), ("w", P), ("bias", P), ("scale", P), ("pre_a", P), ("pre_b", P), ("addend", P), ("residual", P),
+        ("mask_src", P), ("mask_a", P), ("mask_b", P), ("y", P),
+        ("N", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
+        ("KD", c_int32), ("KH", c_int32), ("KW", c_int32), ("upsample", c_int32), ("pre_relu", c_int32),
+        ("scale_group", c_int32), ("pre_group", c_int32), ("mask_group", c_int32), ("act_relu", c_int32),
+    ]
+
+
+class WgradArgs(Structure):
+    """Mirror of ``dgmr_wgrad_args``."""
+
+    _fields_ = [
+        ("x", P), ("dy", P), ("pre_a", P), ("pre_b", P), ("partial", P),
+        ("N", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
+        ("KD", c_int32), ("KH", c_int32), ("KW", c_int32), ("upsample", c_int32), ("pre_relu", c_int32),
+        ("pre_group", c_int32), ("nsplit", c_int32), ("reserved", c_int32),
+    ]
+
+
+i, f, L = c_int, c_float, c_int64
+# name -> argtypes (every function returns int except the two noted below); must match include/dgmr_hip.h
+SIGNATURES = {
+    "dgmr_conv_fwd": [POINTER(ConvArgs), P],
+    "dgmr_conv_flip_weights": [P, P, i, i, i, i, i, P],
+    "dgmr_conv_wgrad": [POINTER(WgradArgs), P],
+    "dgmr_conv_wgrad_nsplit": [i, i, i],
+    "dgmr_wgrad_reduce": [P, i, L, P, P, P, P],
+    "dgmr_sn_wgrad_finalize": [P, P, P, P, P, P, i, i, i, i, P],
+    "dgmr_spectral_sigma": [P, P, P, P, P, P, P, P, i, i, i, f, i, P],
+    "dgmr_bn_stats": [P, P, i, L, i, P],
+    "dgmr_bn_finalize": [P, P, P, P, P, P, P, P, P, P, i, L, i, f, f, P],
+    "dgmr_bn_bwd_reduce": [P, P, P, P, P, i, L, i, P],
+    "dgmr_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, P, i, L, i, i, P],
+    "dgmr_colsum": [P, P, P, L, i, i, P],
+    "dgmr_affine": [P, P, P, P, i, L, i, i, P],
+    "dgmr_pool_fwd": [P, P, P, i, i, i, i, i, i, f, P, P, P, i, P],
+    "dgmr_pool_bwd": [P, P, i, i, i, i, i, i, f, P],
+    "dgmr_frames_s2d": [P, P, P, i, i, i, i, i, i, i, i, P],
+    "dgmr_frames_s2d_bwd": [P, P, P, i, i, i, i, i, i, i, i, P],
+    "dgmr_d2s_frames": [P, P, i, i, i, i, i, i, P],
+    "dgmr_d2s_frames_bwd": [P, P, i, i, i, i, i, i, P],
+    "dgmr_copy_channels": [P, P, L, i, i, i, i, i, i, i, i, P],
+    "dgmr_gru_gate_fwd": [P, P, P, L, P],
+    "dgmr_gru_gate_bwd": [P, P, P, P, P, L, P],
+    "dgmr_gru_blend_fwd": [P, P, P, P, L, P],
+    "dgmr_gru_blend_bwd": [P, P, P, P, P, P, P, L, P],
+    "dgmr_axpby": [P, P, P, f, f, L, P],
+    "dgmr_scale_by_dev": [P, P, f, P, L, P],
+    "dgmr_relu_bwd": [P, P, P, L, P],
+    "dgmr_fill": [P, f, L, P],
+    "dgmr_attention_fwd": [P, P, P, P, P, i, i, i, P],
+    "dgmr_attention_bwd": [P, P, P, P, P, P, P, P, P, i, i, i, P],
+    "dgmr_relu_sum_hw_fwd": [P, P, i, i, i, P],
+    "dgmr_relu_sum_hw_bwd": [P, P, P, i, i, i, P],
+    "dgmr_linear1_fwd": [P, P, P, P, P, i, i, P],
+    "dgmr_linear1_bwd": [P, P, P, P, P, P, P, i, i, P],
+    "dgmr_hinge_disc": [P, P, P, P, P, i, i, P],
+    "dgmr_grid_cell_loss": [P, i, L, P, f, P, P, f, P, L, P],
+    "dgmr_adam": [P, P, P, P, L, f, f, f, f, i, P],
+}
+del i, f, L
+
+_lib = None
+
+
+def load():
+    """Load libdgmr_hip.so once; raise loudly if it is missing (no CPU / torch fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the DGMR HIP kernels are not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no fallback path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.dgmr_abi_version.restype = c_int
+    lib.dgmr_abi_version.argtypes = []
+    lib.dgmr_last_error.restype = c_char_p
+    lib.dgmr_last_error.argtypes = []
+    got = lib.dgmr_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libdgmr_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int, name: str):
+    if rc != 0:
+        msg = _lib.dgmr_last_error().decode() if _lib is not None else "?"
+        raise RuntimeError(f"{name} failed ({rc}): {msg}")
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        check(rc, name)

@@ -1,0 +1,466 @@
+// Implicit-GEMM convolution kernels for gfx950 (MI355X), fp32 on v_mfma_f32_32x32x2_f32.
+//
+// Forward / data-gradient:   Y[m][co] = sum_k A[m][k] * W[co][k]
+//     m  = output pixel (n,d,h,w) flattened (channels-last activations => A rows are contiguous in ci)
+//     k  = (kd,kh,kw,ci) flattened; Cin % 4 == 0 so a 16-byte load never straddles a tap
+//     A is gathered on the fly (zero padding, optional nearest-2x upsample, optional relu / affine+relu)
+// Weight-gradient:           G[co][k] = sum_m dY[m][co] * A[m][k]     (split over m, partial slabs)
+//
+// Tiling is for 64-wide wavefronts: a workgroup of WM x WN waves owns a BM x BN output tile, each wave
+// a (BM/WM) x (BN/WN) sub-tile made of 32x32 MFMA blocks (16 accumulator VGPRs each).  Operands are
+// staged global -> registers -> LDS (double-buffered, one barrier per K step) so the next tile's HBM
+// latency hides under the current tile's MFMAs; LDS rows are padded to BK+4 floats, which makes the
+// ds_read_b128 fragment reads (lane = row, 4 consecutive k) conflict-free.
+#include "common.h"
+
+namespace {
+
+struct RowCoord {
+    int n, d, h, w;
+};
+
+__device__ __forceinline__ RowCoord decode_row(int m, int D, int H, int W) {
+    RowCoord r;
+    r.w = m % W;
+    int t = m / W;
+    r.h = t % H;
+    t /= H;
+    r.d = t % D;
+    r.n = t / D;
+    return r;
+}
+
+// Gather 4 consecutive input channels of the im2col row (pixel rc, flattened k), with the fused prologue.
+__device__ __forceinline__ f32x4 gather_a(const float* __restrict__ x, const float* __restrict__ pre_a,
+                                          const float* __restrict__ pre_b, const RowCoord& rc, bool row_ok, int k,
+                                          int Ktot, int D, int H, int W, int Cin, int KH, int KW, int KHW, int pd,
+                                          int ph, int pw, int upsample, int pre_relu, int pre_group) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!row_ok || k >= Ktot) return v;
+    const int tap = k / Cin;
+    const int ci = k - tap * Cin;
+    const int kz = tap / KHW;
+    const int r2 = tap - kz * KHW;
+    const int ky = r2 / KW;
+    const int kx = r2 - ky * KW;
+    int id = rc.d + kz - pd, ih = rc.h + ky - ph, iw = rc.w + kx - pw;
+    if ((unsigned)id >= (unsigned)D || (unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) return v;
+    int Hin = H, Win = W;
+    if (upsample) {
+        ih >>= 1;
+        iw >>= 1;
+        Hin >>= 1;
+        Win >>= 1;
+    }
+    const size_t off = ((((size_t)rc.n * D + id) * Hin + ih) * Win + iw) * (size_t)Cin + ci;
+    v = *reinterpret_cast<const f32x4*>(x + off);
+    if (pre_a) {
+        const size_t g = (size_t)(rc.n / pre_group) * Cin + ci;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pre_a + g);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pre_b + g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.f);
+    } else if (pre_relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    return v;
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_conv_args p, const int M, const int Ktot) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int LD = BK + 4;
+    constexpr int KQ = BK / 4;
+    constexpr int RPP = NT / KQ;  // tile rows filled per pass
+    constexpr int AP = BM / RPP, BP = BN / RPP;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(AP >= 1 && BP >= 1 && TM >= 1 && TN >= 1, "bad tile");
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "bad tile");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LD];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kq = tid % KQ, lrow = tid / KQ;
+
+    const int KHW = p.KH * p.KW;
+    const int pd = p.KD >> 1, ph = p.KH >> 1, pw = p.KW >> 1;
+
+    RowCoord rc[AP];
+    bool rok[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + i * RPP + lrow;
+        rok[i] = m < M;
+        rc[i] = decode_row(rok[i] ? m : 0, p.D, p.H, p.W);
+    }
+
+    f32x4 ra[AP], rb[BP];
+    auto load_tiles = [&](int kt) {
+        const int k = kt * BK + kq * 4;
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+            ra[i] = gather_a(p.x, p.pre_a, p.pre_b, rc[i], rok[i], k, Ktot, p.D, p.H, p.W, p.Cin, p.KH, p.KW, KHW, pd, ph,
+                             pw, p.upsample, p.pre_relu, p.pre_group);
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const int co = n0 + i * RPP + lrow;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (co < p.Cout && k < Ktot) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)co * Ktot + k);
+            rb[i] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf * BM * LD + (i * RPP + lrow) * LD + kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * BN * LD + (i * RPP + lrow) * LD + kq * 4]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (Ktot + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        const float* Ab = As + cur * BM * LD + (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+        const float* Bb = Bs + cur * BN * LD + (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a4[TM], b4[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LD + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // Epilogue: (acc + addend) * scale + bias + residual, masked.  Lane = output channel, 16 rows per MFMA block.
+    const int DHW = p.D * p.H * p.W;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= M) continue;
+            const int n = row / DHW;
+            const float sc = p.scale ? p.scale[n / p.scale_group] : 1.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+                if (col >= p.Cout) continue;
+                const size_t idx = (size_t)row * p.Cout + col;
+                float v = acc[i][j][r];
+                if (p.addend) v += p.addend[idx];
+                v *= sc;
+                if (p.bias) v += p.bias[col];
+                if (p.act_relu) v = fmaxf(v, 0.f);
+                if (p.residual) v += p.residual[idx];
+                if (p.mask_src) {
+                    float ms = p.mask_src[idx];
+                    if (p.mask_a) {
+                        const size_t g = (size_t)(n / p.mask_group) * p.Cout + col;
+                        ms = fmaf(ms, p.mask_a[g], p.mask_b[g]);
+                    }
+                    v = ms > 0.f ? v : 0.f;
+                }
+                p.y[idx] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+int launch_conv(const dgmr_conv_args& a, int M, int Ktot, hipStream_t s) {
+    dim3 grid((M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(64 * WM * WN), 0, s, a, M, Ktot);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+template <int BI, int BJ, int WI, int WJ>
+__global__ __launch_bounds__(64 * WI * WJ) void conv_wgrad_kernel(const dgmr_wgrad_args p, const int M, const int Ktot,
+                                                                   const int rows_per_split) {
+    constexpr int NT = 64 * WI * WJ;
+    constexpr int BR = 32;               // pixels per reduction step
+    constexpr int TPR = NT / BR;         // threads per tile row (8 for NT = 256)
+    constexpr int YP = BI / 4 / TPR;     // float4 per thread per row, dY tile
+    constexpr int XP = BJ / 4 / TPR;     // float4 per thread per row, X tile
+    constexpr int LDY = BI + 4, LDX = BJ + 4;
+    constexpr int TM = BI / WI / 32, TN = BJ / WJ / 32;
+    static_assert(YP >= 1 && XP >= 1 && TM >= 1 && TN >= 1, "bad tile");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * BR * (LDY + LDX)];
+    float* Ys = smem;
+    float* Xs = smem + 2 * BR * LDY;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wi = wid / WJ, wj = wid % WJ;
+    const int k0 = blockIdx.x * BJ, co0 = blockIdx.y * BI;
+    const int r_begin = blockIdx.z * rows_per_split;
+    const int r_end = min(M, r_begin + rows_per_split);
+    const int lr = tid / TPR, lq = tid % TPR;
+
+    const int KHW = p.KH * p.KW;
+    const int pd = p.KD >> 1, ph = p.KH >> 1, pw = p.KW >> 1;
+
+    f32x4 ry[YP], rx[XP];
+    auto load_tiles = [&](int r0) {
+        const int m = r0 + lr;
+        const bool ok = m < r_end;
+        const RowCoord rc = decode_row(ok ? m : 0, p.D, p.H, p.W);
+#pragma unroll
+        for (int i = 0; i < YP; ++i) {
+            const int co = co0 + (lq + i * TPR) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok && co < p.Cout) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co);
+            ry[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int k = k0 + (lq + i * TPR) * 4;
+            rx[i] = gather_a(p.x, p.pre_a, p.pre_b, rc, ok, k, Ktot, p.D, p.H, p.W, p.Cin, p.KH, p.KW, KHW, pd, ph, pw,
+                             p.upsample, p.pre_relu, p.pre_group);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < YP; ++i) *reinterpret_cast<f32x4*>(&Ys[buf * BR * LDY + lr * LDY + (lq + i * TPR) * 4]) = ry[i];
+#pragma unroll
+        for (int i = 0; i < XP; ++i) *reinterpret_cast<f32x4*>(&Xs[buf * BR * LDX + lr * LDX + (lq + i * TPR) * 4]) = rx[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nr = (r_end - r_begin + BR - 1) / BR;
+    if (nr > 0) {
+        load_tiles(r_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nr; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nr) load_tiles(r_begin + (it + 1) * BR);
+        const float* Yb = Ys + cur * BR * LDY + (lane >> 5) * LDY + wi * TM * 32 + (lane & 31);
+        const float* Xb = Xs + cur * BR * LDX + (lane >> 5) * LDX + wj * TN * 32 + (lane & 31);
+#pragma unroll
+        for (int rr = 0; rr < BR; rr += 2) {
+            float a1[TM], b1[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a1[i] = Yb[rr * LDY + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b1[j] = Xb[rr * LDX + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < nr) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* out = p.partial + (size_t)blockIdx.z * p.Cout * Ktot;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wi * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co >= p.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int k = k0 + wj * TN * 32 + j * 32 + (lane & 31);
+                if (k < Ktot) out[(size_t)co * Ktot + k] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int taps) {
+    // wt[ci][taps-1-t][co] = w[co][t][ci]; one thread per (ci, t, co) destination element, co fastest.
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = i % Cout;
+        const size_t r = i / Cout;
+        const int t = r % taps;
+        const int ci = r / taps;
+        wt[i] = w[((size_t)co * taps + (taps - 1 - t)) * Cin + ci];
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, size_t numel, const float* __restrict__ w,
+                                    float* __restrict__ g, float* __restrict__ dot) {
+    __shared__ float red[32];
+    float d = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * numel + i];
+        g[i] = s;
+        if (w) d = fmaf(s, w[i], d);
+    }
+    if (dot) {
+        d = block_sum(d, red);
+        if (threadIdx.x == 0) atomicAdd(dot, d);
+    }
+}
+
+__global__ void sn_wgrad_finalize_kernel(const float* __restrict__ g, float* __restrict__ gw, const float* __restrict__ dot,
+                                         const float* __restrict__ inv_sigma, const float* __restrict__ u,
+                                         const float* __restrict__ v, int Cout, int Cin, int taps, int accumulate) {
+    const size_t K = (size_t)Cin * taps;
+    const size_t total = (size_t)Cout * K;
+    const float is = inv_sigma[0];
+    const float c = dot[0] * is * is;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = i / K;
+        const int k = i - (size_t)co * K;
+        const int t = k / Cin, ci = k - t * Cin;
+        const float val = u ? g[i] * is - c * u[co] * v[(size_t)ci * taps + t] : g[i] * is;
+        gw[i] = accumulate ? gw[i] + val : val;
+    }
+}
+
+__global__ void zero1_kernel(float* p) { p[0] = 0.f; }
+
+}  // namespace
+
+extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
+    DGMR_CHECK_ARG(a && a->x && a->w && a->y, "dgmr_conv_fwd: null pointer");
+    DGMR_CHECK_ARG(a->Cin % 4 == 0 && a->Cin > 0, "dgmr_conv_fwd: Cin=%d must be a positive multiple of 4", a->Cin);
+    DGMR_CHECK_ARG(a->Cout > 0, "dgmr_conv_fwd: Cout=%d", a->Cout);
+    DGMR_CHECK_ARG((a->KD == 1 || a->KD == 3) && (a->KH == 1 || a->KH == 3) && (a->KW == 1 || a->KW == 3),
+                   "dgmr_conv_fwd: kernel %dx%dx%d unsupported", a->KD, a->KH, a->KW);
+    DGMR_CHECK_ARG(!a->upsample || (a->H % 2 == 0 && a->W % 2 == 0), "dgmr_conv_fwd: upsample needs even H,W");
+    DGMR_CHECK_ARG((a->pre_a == nullptr) == (a->pre_b == nullptr), "dgmr_conv_fwd: pre_a/pre_b must come together");
+    const int64_t M64 = (int64_t)a->N * a->D * a->H * a->W;
+    DGMR_CHECK_ARG(M64 > 0 && M64 < (1ll << 31), "dgmr_conv_fwd: M=%lld out of range", (long long)M64);
+    dgmr_conv_args p = *a;
+    if (p.scale_group < 1) p.scale_group = 1;
+    if (p.pre_group < 1) p.pre_group = 1;
+    if (p.mask_group < 1) p.mask_group = 1;
+    const int M = (int)M64, Ktot = a->KD * a->KH * a->KW * a->Cin;
+    hipStream_t s = (hipStream_t)stream;
+    const int C = a->Cout;
+    // Tile choice: N tile from Cout (32x32 MFMA granularity), M tile shrinks when the grid would not fill 256 CUs.
+    int bn;
+    if (C <= 32) bn = 32;
+    else if (C <= 64) bn = 64;
+    else if (C % 128 == 0) bn = 128;
+    else if (C % 96 == 0) bn = 96;
+    else bn = 128;
+    const int64_t wgs128 = ((M64 + 127) / 128) * ((C + bn - 1) / bn);
+    if (bn == 128) {
+        if (wgs128 >= 256) launch_conv<128, 128, 32, 2, 2>(p, M, Ktot, s);
+        else launch_conv<64, 64, 32, 2, 2>(p, M, Ktot, s);
+    } else if (bn == 96) {
+        launch_conv<128, 96, 32, 4, 1>(p, M, Ktot, s);
+    } else if (bn == 64) {
+        if (wgs128 >= 256) launch_conv<128, 64, 32, 4, 1>(p, M, Ktot, s);
+        else launch_conv<64, 64, 32, 2, 2>(p, M, Ktot, s);
+    } else {
+        launch_conv<128, 32, 32, 4, 1>(p, M, Ktot, s);
+    }
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_conv_flip_weights(const float* w, float* w_t, int Cout, int Cin, int KD, int KH, int KW, void* stream) {
+    DGMR_CHECK_ARG(w && w_t, "dgmr_conv_flip_weights: null pointer");
+    const int taps = KD * KH * KW;
+    const size_t total = (size_t)Cout * Cin * taps;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(flip_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, w_t, Cout, Cin, taps);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_conv_wgrad_nsplit(int M, int Cout, int K) {
+    const int bi = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+    const int64_t tiles = (int64_t)((K + 127) / 128) * ((Cout + bi - 1) / bi);
+    int64_t ns = 1024 / tiles;
+    const int64_t cap = M / 256;  // at least 256 pixels per slab
+    if (ns > cap) ns = cap;
+    if (ns < 1) ns = 1;
+    if (ns > 1024) ns = 1024;
+    return (int)ns;
+}
+
+extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
+    DGMR_CHECK_ARG(a && a->x && a->dy && a->partial, "dgmr_conv_wgrad: null pointer");
+    DGMR_CHECK_ARG(a->Cin % 4 == 0 && a->Cout % 4 == 0, "dgmr_conv_wgrad: Cin=%d Cout=%d must be multiples of 4", a->Cin,
+                   a->Cout);
+    DGMR_CHECK_ARG(a->nsplit >= 1, "dgmr_conv_wgrad: nsplit=%d", a->nsplit);
+    const int64_t M64 = (int64_t)a->N * a->D * a->H * a->W;
+    DGMR_CHECK_ARG(M64 > 0 && M64 < (1ll << 31), "dgmr_conv_wgrad: M out of range");
+    dgmr_wgrad_args p = *a;
+    if (p.pre_group < 1) p.pre_group = 1;
+    const int M = (int)M64, Ktot = a->KD * a->KH * a->KW * a->Cin;
+    int rows = (M + a->nsplit - 1) / a->nsplit;
+    rows = (rows + 31) / 32 * 32;
+    hipStream_t s = (hipStream_t)stream;
+    const int kt = (Ktot + 127) / 128;
+    if (a->Cout <= 32) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), dim3(kt, (a->Cout + 31) / 32, a->nsplit), dim3(256), 0, s, p, M,
+                           Ktot, rows);
+    } else if (a->Cout <= 64) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2>), dim3(kt, (a->Cout + 63) / 64, a->nsplit), dim3(256), 0, s, p, M,
+                           Ktot, rows);
+    } else {
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), dim3(kt, (a->Cout + 127) / 128, a->nsplit), dim3(256), 0, s, p,
+                           M, Ktot, rows);
+    }
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_wgrad_reduce(const float* partial, int nsplit, int64_t numel, const float* w, float* g, float* dot,
+                                 void* stream) {
+    DGMR_CHECK_ARG(partial && g && numel > 0 && nsplit >= 1, "dgmr_wgrad_reduce: bad args");
+    const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, (size_t)numel, w, g,
+                       dot);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_sn_wgrad_finalize(const float* g, float* gw, float* dot, const float* inv_sigma, const float* u,
+                                      const float* v, int Cout, int Cin, int taps, int accumulate, void* stream) {
+    DGMR_CHECK_ARG(g && gw && dot && inv_sigma && ((u == nullptr) == (v == nullptr)), "dgmr_sn_wgrad_finalize: null pointer");
+    const size_t total = (size_t)Cout * Cin * taps;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sn_wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, s, g, gw, dot, inv_sigma, u, v, Cout, Cin, taps,
+                       accumulate);
+    hipLaunchKernelGGL(zero1_kernel, dim3(1), dim3(1), 0, s, dot);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,1006 @@
+// HBM-bound kernels of the DGMR step for gfx950: spectral-norm power iteration, BatchNorm statistics and
+// backward, pooling / space-to-depth layout moves, ConvGRU gating, latent attention, discriminator heads,
+// losses and Adam.  All of them are bandwidth- or latency-bound (no MFMA): coalesced, 16-byte vectorised
+// where the layout allows, per-channel reductions accumulate in double so that E[x^2]-E[x]^2 stays accurate.
+#include <stdarg.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void dgmr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* dgmr_last_error(void) { return g_err; }
+extern "C" int dgmr_abi_version(void) { return DGMR_ABI_VERSION; }
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+inline int ew_blocks(int64_t n_items) { return (int)std::min<int64_t>((n_items + EW_THREADS - 1) / EW_THREADS, 256 * 16); }
+
+#define GRID_STRIDE(i, n) \
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// spectral norm
+// ------------------------------------------------------------------------------------------------
+// t[i] = sum_k w[i][k] * v[perm(k)]; scratch[0] += (u_for_dot ? u[i]*t[i] : t[i]^2)
+__global__ void sn_rows_kernel(const float* __restrict__ w, const float* __restrict__ v, const float* __restrict__ u_for_dot,
+                               float* __restrict__ t, float* __restrict__ scratch, int K, int Cin, int taps) {
+    __shared__ float red[32];
+    const int i = blockIdx.x;
+    const float* wr = w + (size_t)i * K;
+    float s = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += blockDim.x * 4) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+        const int tp = k / Cin, ci = k - tp * Cin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = fmaf(wv[j], v[(size_t)(ci + j) * taps + tp], s);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        t[i] = s;
+        atomicAdd(scratch, u_for_dot ? u_for_dot[i] * s : s * s);
+    }
+}
+
+// s[k] = sum_i w[i][k] * t[i] / max(||t||, eps); block 0 also writes u = t / max(||t||, eps); scratch[1] += s^2
+__global__ void sn_cols_kernel(const float* __restrict__ w, const float* __restrict__ t, float* __restrict__ s_out,
+                               float* __restrict__ u, float* __restrict__ u_save, float* __restrict__ scratch, int Cout, int K,
+                               float eps) {
+    __shared__ float part[4][64];
+    __shared__ float red[32];
+    const float inv = 1.f / fmaxf(sqrtf(scratch[0]), eps);
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (k < K)
+        for (int i = rg; i < Cout; i += 4) s = fmaf(w[(size_t)i * K + k], t[i] * inv, s);
+    part[rg][c] = s;
+    __syncthreads();
+    float sq = 0.f;
+    if (rg == 0 && k < K) {
+        s = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+        s_out[k] = s;
+        sq = s * s;
+    }
+    sq = block_sum(sq, red);
+    if (threadIdx.x == 0) atomicAdd(scratch + 1, sq);
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < Cout; i += blockDim.x) {
+            const float ui = t[i] * inv;
+            u[i] = ui;
+            if (u_save) u_save[i] = ui;
+        }
+}
+
+// v[perm(k)] = s[k]/max(||s||,eps); inv_sigma = max(||s||,eps)/||s||^2   (sigma = u^T W v = ||s||^2 / max(||s||, eps))
+__global__ void sn_finish_train_kernel(const float* __restrict__ s, float* __restrict__ v, float* __restrict__ v_save,
+                                       float* __restrict__ inv_sigma, const float* __restrict__ scratch, int K, int Cin, int taps,
+                                       float eps) {
+    const float n2 = scratch[1];
+    const float d = fmaxf(sqrtf(n2), eps);
+    const float inv = 1.f / d;
+    GRID_STRIDE(k, K) {
+        const int tp = k / Cin, ci = k - tp * Cin;
+        const float vk = s[k] * inv;
+        const size_t j = (size_t)ci * taps + tp;
+        v[j] = vk;
+        if (v_save) v_save[j] = vk;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv_sigma[0] = d / n2;
+}
+
+__global__ void sn_finish_eval_kernel(const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ u_save,
+                                      float* __restrict__ v_save, float* __restrict__ inv_sigma,
+                                      const float* __restrict__ scratch, int Cout, int K) {
+    GRID_STRIDE(i, (int64_t)Cout + K) {
+        if (i < Cout) {
+            if (u_save) u_save[i] = u[i];
+        } else if (v_save)
+            v_save[i - Cout] = v[i - Cout];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv_sigma[0] = 1.f / scratch[0];
+}
+
+__global__ void zero_kernel(float* p, int n) {
+    if (threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-channel reductions over [G][R][C]
+// ------------------------------------------------------------------------------------------------
+// F: void(int64_t elem_index, int g, int c, float& s0, float& s1)
+template <class F>
+__device__ __forceinline__ void chan_reduce2(F f, int64_t R, int C, double* __restrict__ out /* [G][2][C] */) {
+    __shared__ float l0[256], l1[256];
+    const int g = blockIdx.y;
+    const int64_t rows_per_block = (R + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    for (int cb = 0; cb < C; cb += 256) {
+        const int Wd = min(256, C - cb);
+        const int RL = 256 / Wd;
+        const int c = cb + threadIdx.x % Wd, rl = threadIdx.x / Wd;
+        float s0 = 0.f, s1 = 0.f;
+        if (rl < RL)
+            for (int64_t r = r0 + rl; r < r1; r += RL) f(((int64_t)g * R + r) * C + c, g, c, s0, s1);
+        l0[threadIdx.x] = s0;
+        l1[threadIdx.x] = s1;
+        __syncthreads();
+        if (threadIdx.x < Wd) {
+            double a0 = 0.0, a1 = 0.0;
+            for (int k = 0; k < RL; ++k) {
+                a0 += l0[threadIdx.x + k * Wd];
+                a1 += l1[threadIdx.x + k * Wd];
+            }
+            atomicAdd(out + ((size_t)g * 2 + 0) * C + c, a0);
+            atomicAdd(out + ((size_t)g * 2 + 1) * C + c, a1);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int64_t R, int C) {
+    chan_reduce2(
+        [&](int64_t i, int, int, float& s0, float& s1) {
+            const float v = x[i];
+            s0 += v;
+            s1 = fmaf(v, v, s1);
+        },
+        R, C, sums);
+}
+
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, double* __restrict__ sums, int64_t R, int C) {
+    chan_reduce2(
+        [&](int64_t i, int g, int c, float& s0, float& s1) {
+            const float gv = gy[i];
+            const float xh = (x[i] - mean[(size_t)g * C + c]) * rstd[(size_t)g * C + c];
+            s0 += gv;
+            s1 = fmaf(gv, xh, s1);
+        },
+        R, C, sums);
+}
+
+__global__ void colsum_kernel(const float* __restrict__ x, double* __restrict__ sums, int64_t R, int C) {
+    chan_reduce2([&](int64_t i, int, int, float& s0, float&) { s0 += x[i]; }, R, C, sums);
+}
+
+__global__ void colsum_finish_kernel(const double* __restrict__ sums, float* __restrict__ out, int C, int accumulate) {
+    GRID_STRIDE(c, C) out[c] = (accumulate ? out[c] : 0.f) + (float)sums[c];
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
+                                   float* __restrict__ a, float* __restrict__ b, float* __restrict__ save_mean,
+                                   float* __restrict__ save_rstd, int G, int64_t R, int C, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt && sums) nbt[0] += G;
+    if (c >= C) return;
+    const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    if (!sums) {  // eval: running statistics
+        const float mean = rm[c], rstd = 1.f / sqrtf(rv[c] + eps);
+        a[c] = gm * rstd;
+        b[c] = bt - mean * gm * rstd;
+        if (save_mean) {
+            save_mean[c] = mean;
+            save_rstd[c] = rstd;
+        }
+        return;
+    }
+    float rmc = rm[c], rvc = rv[c];
+    for (int g = 0; g < G; ++g) {
+        const double mean = sums[((size_t)g * 2 + 0) * C + c] / (double)R;
+        double var = sums[((size_t)g * 2 + 1) * C + c] / (double)R - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float av = gm * rstd;
+        a[(size_t)g * C + c] = av;
+        b[(size_t)g * C + c] = bt - (float)mean * av;
+        if (save_mean) {
+            save_mean[(size_t)g * C + c] = (float)mean;
+            save_rstd[(size_t)g * C + c] = rstd;
+        }
+        const double unbiased = R > 1 ? var * ((double)R / (double)(R - 1)) : var;
+        rmc = (1.f - momentum) * rmc + momentum * (float)mean;
+        rvc = (1.f - momentum) * rvc + momentum * (float)unbiased;
+    }
+    rm[c] = rmc;
+    rv[c] = rvc;
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const double* __restrict__ sums, const float* __restrict__ dx_add, float* __restrict__ dx,
+                                    int64_t R, int C, int train) {
+    const int g = blockIdx.y;
+    const int64_t n = R * C;
+    const float invR = 1.f / (float)R;
+    GRID_STRIDE(i, n) {
+        const int c = i % C;
+        const size_t gc = (size_t)g * C + c;
+        const size_t idx = (size_t)g * n + i;
+        const float gm = gamma ? gamma[c] : 1.f;
+        const float rs = rstd[gc];
+        float v = gy[idx];
+        if (train) {
+            const float xh = (x[idx] - mean[gc]) * rs;
+            v = v - (float)sums[((size_t)g * 2 + 0) * C + c] * invR - xh * (float)sums[((size_t)g * 2 + 1) * C + c] * invR;
+        }
+        v *= gm * rs;
+        if (dx_add) v += dx_add[idx];
+        dx[idx] = v;
+    }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int G,
+                                     int C) {
+    GRID_STRIDE(c, C) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int g = 0; g < G; ++g) {
+            s0 += sums[((size_t)g * 2 + 0) * C + c];
+            s1 += sums[((size_t)g * 2 + 1) * C + c];
+        }
+        if (dbeta) dbeta[c] += (float)s0;
+        if (dgamma) dgamma[c] += (float)s1;
+    }
+}
+
+__global__ void affine_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
+                              float* __restrict__ y, int64_t R, int C, int relu) {
+    const int g = blockIdx.y;
+    const int64_t n = R * C;
+    GRID_STRIDE(i, n) {
+        const int c = i % C;
+        float v = fmaf(x[(size_t)g * n + i], a[(size_t)g * C + c], b[(size_t)g * C + c]);
+        if (relu) v = fmaxf(v, 0.f);
+        y[(size_t)g * n + i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling and layout
+// ------------------------------------------------------------------------------------------------
+__global__ void pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ addend, float* __restrict__ y, int N, int D,
+                                int H, int W, int C, int pd, float scale, const float* __restrict__ mask_src,
+                                const float* __restrict__ mask_a, const float* __restrict__ mask_b, int mask_group) {
+    const int Do = D / pd, Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const int64_t total = (int64_t)N * Do * Ho * Wo * C4;
+    GRID_STRIDE(i, total) {
+        const int c4 = i % C4;
+        int64_t t = i / C4;
+        const int wo = t % Wo;
+        t /= Wo;
+        const int ho = t % Ho;
+        t /= Ho;
+        const int d_o = t % Do;
+        const int n = t / Do;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int dz = 0; dz < pd; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const size_t off = ((((size_t)n * D + d_o * pd + dz) * H + ho * 2 + dy) * W + wo * 2 + dx) * C + c4 * 4;
+                    s += *reinterpret_cast<const f32x4*>(x + off);
+                }
+        s *= scale;
+        const size_t o = (size_t)i * 4;
+        if (addend) s += *reinterpret_cast<const f32x4*>(addend + o);
+        if (mask_src) {
+            f32x4 m = *reinterpret_cast<const f32x4*>(mask_src + o);
+            if (mask_a) {
+                const size_t gc = (size_t)(n / mask_group) * C + c4 * 4;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(mask_a + gc);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(mask_b + gc);
+                m = m * a + b;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] = m[j] > 0.f ? s[j] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(y + o) = s;
+    }
+}
+
+__global__ void pool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int D, int H, int W, int C, int pd,
+                                float scale) {
+    const int Do = D / pd, Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const int64_t total = (int64_t)N * D * H * W * C4;
+    GRID_STRIDE(i, total) {
+        const int c4 = i % C4;
+        int64_t t = i / C4;
+        const int w = t % W;
+        t /= W;
+        const int h = t % H;
+        t /= H;
+        const int d = t % D;
+        const int n = t / D;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int d_o = d / pd, ho = h >> 1, wo = w >> 1;
+        if (d_o < Do && ho < Ho && wo < Wo) {
+            const size_t off = ((((size_t)n * Do + d_o) * Ho + ho) * Wo + wo) * C + c4 * 4;
+            v = *reinterpret_cast<const f32x4*>(dy + off) * scale;
+        }
+        *reinterpret_cast<f32x4*>(dx + (size_t)i * 4) = v;
+    }
+}
+
+__global__ void frames_s2d_kernel(const float* __restrict__ fr, const int32_t* __restrict__ idx, float* __restrict__ out, int B,
+                                  int T, int C, int H, int W, int F, int p, int frame_major) {
+    const int Ho = H / (2 * p), Wo = W / (2 * p), Co = 4 * C;
+    const int64_t total = (int64_t)B * F * Ho * Wo * Co;
+    const float inv = 1.f / (float)(p * p);
+    GRID_STRIDE(i, total) {
+        const int co = i % Co;
+        int64_t t = i / Co;
+        const int wo = t % Wo;
+        t /= Wo;
+        const int ho = t % Ho;
+        t /= Ho;
+        int b, f;
+        if (frame_major) {
+            b = t % B;
+            f = t / B;
+        } else {
+            f = t % F;
+            b = t / F;
+        }
+        const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
+        const int tf = idx ? idx[f] : f;
+        const float* src = fr + (((size_t)b * T + tf) * C + c) * H * W;
+        float s = 0.f;
+        for (int py = 0; py < p; ++py)
+            for (int px = 0; px < p; ++px) s += src[(size_t)((2 * ho + dy) * p + py) * W + (2 * wo + dx) * p + px];
+        out[i] = s * inv;
+    }
+}
+
+__global__ void frames_s2d_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx, float* __restrict__ dfr,
+                                      int B, int T, int C, int H, int W, int F, int p, int frame_major) {
+    const int Ho = H / (2 * p), Wo = W / (2 * p), Co = 4 * C;
+    const int64_t total = (int64_t)B * F * Ho * Wo * Co;
+    const float inv = 1.f / (float)(p * p);
+    GRID_STRIDE(i, total) {
+        const int co = i % Co;
+        int64_t t = i / Co;
+        const int wo = t % Wo;
+        t /= Wo;
+        const int ho = t % Ho;
+        t /= Ho;
+        int b, f;
+        if (frame_major) {
+            b = t % B;
+            f = t / B;
+        } else {
+            f = t % F;
+            b = t / F;
+        }
+        const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
+        const int tf = idx ? idx[f] : f;
+        float* dst = dfr + (((size_t)b * T + tf) * C + c) * H * W;
+        const float g = dout[i] * inv;
+        for (int py = 0; py < p; ++py)
+            for (int px = 0; px < p; ++px) atomicAdd(dst + (size_t)((2 * ho + dy) * p + py) * W + (2 * wo + dx) * p + px, g);
+    }
+}
+
+template <bool BWD>
+__global__ void d2s_frames_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int T, int t, int C, int h, int w) {
+    // forward: frames[b][t][c][2y+dy][2x+dx] = x[b][y][x][c*4+dy*2+dx]; one thread per frame pixel (coalesced frame side)
+    const int H = 2 * h, W = 2 * w;
+    const int64_t total = (int64_t)B * C * H * W;
+    GRID_STRIDE(i, total) {
+        const int X = i % W;
+        int64_t r = i / W;
+        const int Y = r % H;
+        r /= H;
+        const int c = r % C;
+        const int b = r / C;
+        const size_t fi = ((((size_t)b * T + t) * C + c) * H + Y) * W + X;
+        const size_t xi = (((size_t)b * h + (Y >> 1)) * w + (X >> 1)) * (4 * C) + c * 4 + (Y & 1) * 2 + (X & 1);
+        if (BWD) dst[xi] = src[fi];
+        else dst[fi] = src[xi];
+    }
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t R, int C, int src_C, int src_off,
+                                     int src_cs, int dst_C, int dst_off, int dst_cs, int accumulate) {
+    const int64_t total = R * C;
+    GRID_STRIDE(i, total) {
+        const int c = i % C;
+        const int64_t r = i / C;
+        const float v = src[(size_t)r * src_C + src_off + (size_t)c * src_cs];
+        float* d = dst + (size_t)r * dst_C + dst_off + (size_t)c * dst_cs;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvGRU gating, elementwise
+// ------------------------------------------------------------------------------------------------
+__global__ void gru_gate_fwd_kernel(const f32x4* __restrict__ pr, const f32x4* __restrict__ h, f32x4* __restrict__ rh, int64_t n4) {
+    GRID_STRIDE(i, n4) {
+        const f32x4 p = pr[i], hv = h[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = sigmoidf_(p[j]) * hv[j];
+        rh[i] = o;
+    }
+}
+
+__global__ void gru_gate_bwd_kernel(const f32x4* __restrict__ d_rh, const f32x4* __restrict__ pr, const f32x4* __restrict__ h,
+                                    f32x4* __restrict__ dpr, f32x4* __restrict__ dh, int64_t n4) {
+    GRID_STRIDE(i, n4) {
+        const f32x4 g = d_rh[i], p = pr[i], hv = h[i];
+        f32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = sigmoidf_(p[j]);
+            a[j] = g[j] * hv[j] * s * (1.f - s);
+            b[j] = g[j] * s;
+        }
+        dpr[i] = a;
+        dh[i] = b;
+    }
+}
+
+__global__ void gru_blend_fwd_kernel(const f32x4* __restrict__ pu, const f32x4* __restrict__ h, const f32x4* __restrict__ pc,
+                                     f32x4* __restrict__ out, int64_t n4) {
+    GRID_STRIDE(i, n4) {
+        const f32x4 u = pu[i], hv = h[i], c = pc[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = sigmoidf_(u[j]);
+            o[j] = s * hv[j] + (1.f - s) * fmaxf(c[j], 0.f);
+        }
+        out[i] = o;
+    }
+}
+
+__global__ void gru_blend_bwd_kernel(const f32x4* __restrict__ dout, const f32x4* __restrict__ pu, const f32x4* __restrict__ h,
+                                     const f32x4* __restrict__ pc, f32x4* __restrict__ dpu, f32x4* __restrict__ dh,
+                                     f32x4* __restrict__ dpc, int64_t n4) {
+    GRID_STRIDE(i, n4) {
+        const f32x4 g = dout[i], u = pu[i], hv = h[i], c = pc[i];
+        f32x4 a, b, d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = sigmoidf_(u[j]);
+            const float rc = fmaxf(c[j], 0.f);
+            a[j] = g[j] * (hv[j] - rc) * s * (1.f - s);
+            b[j] = g[j] * s;
+            d[j] = c[j] > 0.f ? g[j] * (1.f - s) : 0.f;
+        }
+        dpu[i] = a;
+        dh[i] = b;
+        dpc[i] = d;
+    }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, float alpha,
+                             float beta, int64_t n) {
+    GRID_STRIDE(i, n) y[i] = b ? alpha * a[i] + beta * b[i] : alpha * a[i];
+}
+
+__global__ void scale_by_dev_kernel(const float* __restrict__ x, const float* __restrict__ s, float host_scale,
+                                    float* __restrict__ y, int64_t n) {
+    const float f = s[0] * host_scale;
+    GRID_STRIDE(i, n) y[i] = x[i] * f;
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int64_t n) {
+    GRID_STRIDE(i, n) dx[i] = x[i] > 0.f ? dy[i] : 0.f;
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) { GRID_STRIDE(i, n) p[i] = v; }
+
+// ------------------------------------------------------------------------------------------------
+// latent attention (dgmr/layers/Attention.py:9-20).  Tensors are one sample, channels-last [H][W][Cq]; the
+// reference's einsum treats the NCHW view [Cq][H][W] as "[h w c]": position p = cq*H + y, feature = x.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t att_addr(int p, int f, int Cq, int H, int W) {
+    const int cq = p / H, y = p - cq * H;
+    return ((size_t)y * W + f) * Cq + cq;
+}
+
+__global__ void attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                     float* __restrict__ beta, float* __restrict__ out, int Cq, int H, int W) {
+    extern __shared__ float sh[];  // logits [L] + red[32]
+    const int L = Cq * H, p = blockIdx.x;
+    float* logit = sh;
+    float* red = sh + L;
+    float mx = -INFINITY;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        float s = 0.f;
+        for (int f = 0; f < W; ++f) s = fmaf(q[att_addr(p, f, Cq, H, W)], k[att_addr(l, f, Cq, H, W)], s);
+        logit[l] = s;
+        mx = fmaxf(mx, s);
+    }
+    // block max
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int i = 1; i < (int)((blockDim.x + 63) >> 6); ++i) mx = fmaxf(mx, red[i]);
+    float sum = 0.f;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        const float e = __expf(logit[l] - mx);
+        logit[l] = e;
+        sum += e;
+    }
+    sum = block_sum(sum, red);
+    const float inv = 1.f / sum;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        const float bv = logit[l] * inv;
+        logit[l] = bv;
+        beta[(size_t)p * L + l] = bv;
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < W; f += blockDim.x) {
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s = fmaf(logit[l], v[att_addr(l, f, Cq, H, W)], s);
+        out[att_addr(p, f, Cq, H, W)] = s;
+    }
+}
+
+// per query position p: dlogit[p][l] = beta*(dbeta - sum_l beta*dbeta) -> tmp ; dq[p][f] = sum_l dlogit*k[l][f]
+__global__ void attention_bwd_q_kernel(const float* __restrict__ dout, const float* __restrict__ k, const float* __restrict__ v,
+                                       const float* __restrict__ beta, float* __restrict__ dq, float* __restrict__ tmp, int Cq,
+                                       int H, int W) {
+    extern __shared__ float sh[];
+    const int L = Cq * H, p = blockIdx.x;
+    float* dl = sh;
+    float* red = sh + L;
+    float dot = 0.f;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        float s = 0.f;
+        for (int f = 0; f < W; ++f) s = fmaf(dout[att_addr(p, f, Cq, H, W)], v[att_addr(l, f, Cq, H, W)], s);
+        dl[l] = s;
+        dot = fmaf(beta[(size_t)p * L + l], s, dot);
+    }
+    dot = block_sum(dot, red);
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        const float g = beta[(size_t)p * L + l] * (dl[l] - dot);
+        dl[l] = g;
+        tmp[(size_t)p * L + l] = g;
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < W; f += blockDim.x) {
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s = fmaf(dl[l], k[att_addr(l, f, Cq, H, W)], s);
+        dq[att_addr(p, f, Cq, H, W)] = s;
+    }
+}
+
+// per key position l: dk[l][f] = sum_p dlogit[p][l]*q[p][f]; dv[l][f] = sum_p beta[p][l]*dout[p][f]
+__global__ void attention_bwd_kv_kernel(const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ beta,
+                                        const float* __restrict__ tmp, float* __restrict__ dk, float* __restrict__ dv, int Cq, int H,
+                                        int W) {
+    const int L = Cq * H, l = blockIdx.x;
+    for (int f = threadIdx.x; f < W; f += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int p = 0; p < L; ++p) {
+            a = fmaf(tmp[(size_t)p * L + l], q[att_addr(p, f, Cq, H, W)], a);
+            b = fmaf(beta[(size_t)p * L + l], dout[att_addr(p, f, Cq, H, W)], b);
+        }
+        dk[att_addr(l, f, Cq, H, W)] = a;
+        dv[att_addr(l, f, Cq, H, W)] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// discriminator heads
+// ------------------------------------------------------------------------------------------------
+__global__ void relu_sum_hw_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int HW, int C) {
+    GRID_STRIDE(i, (int64_t)N * C) {
+        const int c = i % C;
+        const int n = i / C;
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += fmaxf(x[((size_t)n * HW + p) * C + c], 0.f);
+        y[i] = s;
+    }
+}
+
+__global__ void relu_sum_hw_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int N,
+                                       int HW, int C) {
+    GRID_STRIDE(i, (int64_t)N * HW * C) {
+        const int c = i % C;
+        const int n = i / ((int64_t)HW * C);
+        dx[i] = x[i] > 0.f ? dy[(size_t)n * C + c] : 0.f;
+    }
+}
+
+__global__ void linear1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                   const float* __restrict__ scale, float* __restrict__ y, int C) {
+    __shared__ float red[32];
+    const int n = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) s = fmaf(x[(size_t)n * C + c], w[c], s);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) y[n] = s * (scale ? scale[0] : 1.f) + (bias ? bias[0] : 0.f);
+}
+
+__global__ void linear1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
+                                   const float* __restrict__ scale, float* __restrict__ dx, float* __restrict__ gw_raw,
+                                   float* __restrict__ gb, int N, int C) {
+    const float sc = scale ? scale[0] : 1.f;
+    GRID_STRIDE(c, C) {
+        float g = 0.f;
+        const float wc = w[c] * sc;
+        for (int n = 0; n < N; ++n) {
+            const float d = dy[n];
+            dx[(size_t)n * C + c] = d * wc;
+            g = fmaf(d, x[(size_t)n * C + c], g);
+        }
+        gw_raw[c] = g;
+        if (c == 0 && gb) {
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s += dy[n];
+            gb[0] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// losses, Adam
+// ------------------------------------------------------------------------------------------------
+__global__ void hinge_disc_kernel(const float* __restrict__ s_real, const float* __restrict__ s_gen, float* __restrict__ loss,
+                                  float* __restrict__ d_real, float* __restrict__ d_gen, int n_real, int n_gen) {
+    __shared__ float red[32];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n_real; i += blockDim.x) {
+        const float v = 1.f - s_real[i];
+        a += fmaxf(v, 0.f);
+        if (d_real) d_real[i] = v > 0.f ? -1.f / n_real : 0.f;
+    }
+    for (int i = threadIdx.x; i < n_gen; i += blockDim.x) {
+        const float v = 1.f + s_gen[i];
+        b += fmaxf(v, 0.f);
+        if (d_gen) d_gen[i] = v > 0.f ? 1.f / n_gen : 0.f;
+    }
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    if (threadIdx.x == 0) loss[0] = a / n_real + b / n_gen;
+}
+
+__global__ void grid_cell_kernel(const float* __restrict__ preds, int K, int64_t stride, const float* __restrict__ target, float cap,
+                                 double* __restrict__ acc, float* __restrict__ dweight, int64_t n) {
+    __shared__ float red[32];
+    float s = 0.f;
+    const float invK = 1.f / (float)K;
+    GRID_STRIDE(i, n) {
+        float m = 0.f;
+        for (int k = 0; k < K; ++k) m += preds[(size_t)k * stride + i];
+        m *= invK;
+        const float y = target[i];
+        const float w = fmaxf(y + 1.f, cap);
+        const float d = (m - y) * w;
+        s += fabsf(d);
+        if (dweight) dweight[i] = (d > 0.f ? w : (d < 0.f ? -w : 0.f)) * invK;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, (double)s);
+}
+
+__global__ void grid_cell_finish_kernel(double* __restrict__ acc, float* __restrict__ loss, float mult) {
+    loss[0] = (float)(acc[0] * (double)mult);
+    acc[0] = 0.0;
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                            float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt) {
+    GRID_STRIDE(i, n) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_bc2_sqrt + eps);
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int dgmr_spectral_sigma(const float* w, float* u, float* v, float* u_save, float* v_save, float* inv_sigma,
+                                   float* scratch, float* tmp, int Cout, int Cin, int taps, float eps, int train, void* stream) {
+    DGMR_CHECK_ARG(w && u && v && inv_sigma && scratch && tmp, "dgmr_spectral_sigma: null pointer");
+    DGMR_CHECK_ARG(Cin % 4 == 0, "dgmr_spectral_sigma: Cin=%d must be a multiple of 4", Cin);
+    const int K = Cin * taps;
+    float* t = tmp;
+    float* s = tmp + Cout;
+    if (train) {
+        hipLaunchKernelGGL(sn_rows_kernel, dim3(Cout), dim3(256), 0, ST, w, v, (const float*)nullptr, t, scratch, K, Cin, taps);
+        hipLaunchKernelGGL(sn_cols_kernel, dim3((K + 63) / 64), dim3(256), 0, ST, w, t, s, u, u_save, scratch, Cout, K, eps);
+        hipLaunchKernelGGL(sn_finish_train_kernel, dim3(std::min((K + 255) / 256, 64)), dim3(256), 0, ST, s, v, v_save, inv_sigma,
+                           scratch, K, Cin, taps, eps);
+    } else {
+        hipLaunchKernelGGL(sn_rows_kernel, dim3(Cout), dim3(256), 0, ST, w, v, (const float*)u, t, scratch, K, Cin, taps);
+        hipLaunchKernelGGL(sn_finish_eval_kernel, dim3(std::min((Cout + K + 255) / 256, 64)), dim3(256), 0, ST, u, v, u_save, v_save,
+                           inv_sigma, scratch, Cout, K);
+    }
+    hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ST, scratch, 4);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+static inline dim3 reduce_grid(int G, int64_t R) {
+    int64_t bx = (R + 63) / 64;
+    if (bx > 512) bx = 512;
+    if (bx < 1) bx = 1;
+    return dim3((unsigned)bx, (unsigned)G);
+}
+
+extern "C" int dgmr_bn_stats(const float* x, double* sums, int G, int64_t R, int C, void* stream) {
+    DGMR_CHECK_ARG(x && sums && G > 0 && R > 0 && C > 0, "dgmr_bn_stats: bad args");
+    hipLaunchKernelGGL(bn_stats_kernel, reduce_grid(G, R), dim3(256), 0, ST, x, sums, R, C);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                int64_t* num_batches_tracked, float* a, float* b, float* save_mean, float* save_rstd, int G,
+                                int64_t R, int C, float eps, float momentum, void* stream) {
+    DGMR_CHECK_ARG(running_mean && running_var && a && b, "dgmr_bn_finalize: null pointer");
+    DGMR_CHECK_ARG(sums || G == 1, "dgmr_bn_finalize: eval mode needs G == 1");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, sums, gamma, beta, running_mean, running_var,
+                       num_batches_tracked, a, b, save_mean, save_rstd, G, R, C, eps, momentum);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* rstd, double* sums, int G,
+                                  int64_t R, int C, void* stream) {
+    DGMR_CHECK_ARG(gy && x && mean && rstd && sums, "dgmr_bn_bwd_reduce: null pointer");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, reduce_grid(G, R), dim3(256), 0, ST, gy, x, mean, rstd, sums, R, C);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 const double* sums, const float* dx_add, float* dx, float* dgamma, float* dbeta, int G,
+                                 int64_t R, int C, int train, void* stream) {
+    DGMR_CHECK_ARG(gy && x && mean && rstd && sums && dx, "dgmr_bn_bwd_apply: null pointer");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(R * C), G), dim3(EW_THREADS), 0, ST, gy, x, mean, rstd, gamma, sums,
+                       dx_add, dx, R, C, train);
+    if (dgamma || dbeta)
+        hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, sums, dgamma, dbeta, G, C);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_colsum(const float* x, float* out, double* tmp, int64_t R, int C, int accumulate, void* stream) {
+    DGMR_CHECK_ARG(x && out && tmp, "dgmr_colsum: null pointer");
+    (void)hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C, ST);
+    hipLaunchKernelGGL(colsum_kernel, reduce_grid(1, R), dim3(256), 0, ST, x, tmp, R, C);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, tmp, out, C, accumulate);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_affine(const float* x, const float* a, const float* b, float* y, int G, int64_t R, int C, int relu,
+                           void* stream) {
+    DGMR_CHECK_ARG(x && a && b && y, "dgmr_affine: null pointer");
+    hipLaunchKernelGGL(affine_kernel, dim3(ew_blocks(R * C), G), dim3(EW_THREADS), 0, ST, x, a, b, y, R, C, relu);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_pool_fwd(const float* x, const float* addend, float* y, int N, int D, int H, int W, int C, int pd, float scale,
+                             const float* mask_src, const float* mask_a, const float* mask_b, int mask_group, void* stream) {
+    DGMR_CHECK_ARG(x && y, "dgmr_pool_fwd: null pointer");
+    DGMR_CHECK_ARG(C % 4 == 0 && (pd == 1 || pd == 2), "dgmr_pool_fwd: C=%d pd=%d unsupported", C, pd);
+    if (scale == 0.f) scale = 1.f / (4.f * pd);
+    if (mask_group < 1) mask_group = 1;
+    const int64_t total = (int64_t)N * (D / pd) * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, x, addend, y, N, D, H, W, C, pd, scale,
+                       mask_src, mask_a, mask_b, mask_group);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_pool_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, int pd, float scale, void* stream) {
+    DGMR_CHECK_ARG(dy && dx, "dgmr_pool_bwd: null pointer");
+    DGMR_CHECK_ARG(C % 4 == 0 && (pd == 1 || pd == 2), "dgmr_pool_bwd: C=%d pd=%d unsupported", C, pd);
+    if (scale == 0.f) scale = 1.f / (4.f * pd);
+    const int64_t total = (int64_t)N * D * H * W * (C / 4);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dy, dx, N, D, H, W, C, pd, scale);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_frames_s2d(const float* frames, const int32_t* idx, float* out, int B, int T, int C, int H, int W, int F,
+                               int pool, int frame_major, void* stream) {
+    DGMR_CHECK_ARG(frames && out, "dgmr_frames_s2d: null pointer");
+    const int p = pool ? 2 : 1;
+    DGMR_CHECK_ARG(H % (2 * p) == 0 && W % (2 * p) == 0, "dgmr_frames_s2d: H=%d W=%d not divisible by %d", H, W, 2 * p);
+    const int64_t total = (int64_t)B * F * (H / (2 * p)) * (W / (2 * p)) * 4 * C;
+    hipLaunchKernelGGL(frames_s2d_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, frames, idx, out, B, T, C, H, W, F, p,
+                       frame_major);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_frames_s2d_bwd(const float* dout, const int32_t* idx, float* dframes, int B, int T, int C, int H, int W, int F,
+                                   int pool, int frame_major, void* stream) {
+    DGMR_CHECK_ARG(dout && dframes, "dgmr_frames_s2d_bwd: null pointer");
+    const int p = pool ? 2 : 1;
+    const int64_t total = (int64_t)B * F * (H / (2 * p)) * (W / (2 * p)) * 4 * C;
+    hipLaunchKernelGGL(frames_s2d_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dout, idx, dframes, B, T, C, H, W, F,
+                       p, frame_major);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_d2s_frames(const float* x, float* frames, int B, int T, int t, int C, int h, int w, void* stream) {
+    DGMR_CHECK_ARG(x && frames && t >= 0 && t < T, "dgmr_d2s_frames: bad args");
+    const int64_t total = (int64_t)B * C * 4 * h * w;
+    hipLaunchKernelGGL(d2s_frames_kernel<false>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, x, frames, B, T, t, C, h, w);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_d2s_frames_bwd(const float* dframes, float* dx, int B, int T, int t, int C, int h, int w, void* stream) {
+    DGMR_CHECK_ARG(dframes && dx && t >= 0 && t < T, "dgmr_d2s_frames_bwd: bad args");
+    const int64_t total = (int64_t)B * C * 4 * h * w;
+    hipLaunchKernelGGL(d2s_frames_kernel<true>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dframes, dx, B, T, t, C, h, w);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_copy_channels(const float* src, float* dst, int64_t R, int C, int src_C, int src_off, int src_cstride,
+                                  int dst_C, int dst_off, int dst_cstride, int accumulate, void* stream) {
+    DGMR_CHECK_ARG(src && dst && R > 0 && C > 0, "dgmr_copy_channels: bad args");
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(ew_blocks(R * C)), dim3(EW_THREADS), 0, ST, src, dst, R, C, src_C, src_off,
+                       src_cstride, dst_C, dst_off, dst_cstride, accumulate);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+#define CHECK_N4(n) DGMR_CHECK_ARG((n) > 0 && (n) % 4 == 0, "%s: n=%lld must be a positive multiple of 4", __func__, (long long)(n))
+
+extern "C" int dgmr_gru_gate_fwd(const float* pr, const float* h, float* rh, int64_t n, void* stream) {
+    CHECK_N4(n);
+    hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(ew_blocks(n / 4)), dim3(EW_THREADS), 0, ST, (const f32x4*)pr, (const f32x4*)h,
+                       (f32x4*)rh, n / 4);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dgmr_gru_gate_bwd(const float* d_rh, const float* pr, const float* h, float* dpr, float* dh, int64_t n, void* stream) {
+    CHECK_N4(n);
+    hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(EW_THREADS), 0, ST, (const f32x4*)d_rh, (const f32x4*)pr,
+                       (const f32x4*)h, (f32x4*)dpr, (f32x4*)dh, n / 4);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dgmr_gru_blend_fwd(const float* pu, const float* h, const float* pc, float* out, int64_t n, void* stream) {
+    CHECK_N4(n);
+    hipLaunchKernelGGL(gru_blend_fwd_kernel, dim3(ew_blocks(n / 4)), dim3(EW_THREADS), 0, ST, (const f32x4*)pu, (const f32x4*)h,
+                       (const f32x4*)pc, (f32x4*)out, n / 4);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dgmr_gru_blend_bwd(const float* dout, const float* pu, const float* h, const float* pc, float* dpu, float* dh,
+                                  float* dpc, int64_t n, void* stream) {
+    CHECK_N4(n);
+    hipLaunchKernelGGL(gru_blend_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(EW_THREADS), 0, ST, (const f32x4*)dout, (const f32x4*)pu,
+                       (const f32x4*)h, (const f32x4*)pc, (f32x4*)dpu, (f32x4*)dh, (f32x4*)dpc, n / 4);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream) {
+    DGMR_CHECK_ARG(a && y && n > 0, "dgmr_axpby: bad args");
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, a, b, y, alpha, beta, n);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dgmr_scale_by_dev(const float* x, const float* s, float host_scale, float* y, int64_t n, void* stream) {
+    DGMR_CHECK_ARG(x && s && y && n > 0, "dgmr_scale_by_dev: bad args");
+    hipLaunchKernelGGL(scale_by_dev_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, x, s, host_scale, y, n);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dgmr_relu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+    DGMR_CHECK_ARG(dy && x && dx && n > 0, "dgmr_relu_bwd: bad args");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, dy, x, dx, n);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dgmr_fill(float* p, float value, int64_t n, void* stream) {
+    DGMR_CHECK_ARG(p && n > 0, "dgmr_fill: bad args");
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, p, value, n);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_attention_fwd(const float* q, const float* k, const float* v, float* beta, float* out, int Cq, int H, int W,
+                                  void* stream) {
+    DGMR_CHECK_ARG(q && k && v && beta && out, "dgmr_attention_fwd: null pointer");
+    const int L = Cq * H;
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(L), dim3(256), (L + 32) * sizeof(float), ST, q, k, v, beta, out, Cq, H, W);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_attention_bwd(const float* dout, const float* q, const float* k, const float* v, const float* beta, float* dq,
+                                  float* dk, float* dv, float* tmp, int Cq, int H, int W, void* stream) {
+    DGMR_CHECK_ARG(dout && q && k && v && beta && dq && dk && dv && tmp, "dgmr_attention_bwd: null pointer");
+    const int L = Cq * H;
+    hipLaunchKernelGGL(attention_bwd_q_kernel, dim3(L), dim3(256), (L + 32) * sizeof(float), ST, dout, k, v, beta, dq, tmp, Cq, H, W);
+    hipLaunchKernelGGL(attention_bwd_kv_kernel, dim3(L), dim3(64), 0, ST, dout, q, beta, tmp, dk, dv, Cq, H, W);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_relu_sum_hw_fwd(const float* x, float* y, int N, int HW, int C, void* stream) {
+    DGMR_CHECK_ARG(x && y, "dgmr_relu_sum_hw_fwd: null pointer");
+    hipLaunchKernelGGL(relu_sum_hw_fwd_kernel, dim3(ew_blocks((int64_t)N * C)), dim3(EW_THREADS), 0, ST, x, y, N, HW, C);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dgmr_relu_sum_hw_bwd(const float* dy, const float* x, float* dx, int N, int HW, int C, void* stream) {
+    DGMR_CHECK_ARG(dy && x && dx, "dgmr_relu_sum_hw_bwd: null pointer");
+    hipLaunchKernelGGL(relu_sum_hw_bwd_kernel, dim3(ew_blocks((int64_t)N * HW * C)), dim3(EW_THREADS), 0, ST, dy, x, dx, N, HW, C);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dgmr_linear1_fwd(const float* x, const float* w, const float* bias, const float* scale, float* y, int N, int C,
+                                void* stream) {
+    DGMR_CHECK_ARG(x && w && y, "dgmr_linear1_fwd: null pointer");
+    hipLaunchKernelGGL(linear1_fwd_kernel, dim3(N), dim3(256), 0, ST, x, w, bias, scale, y, C);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dgmr_linear1_bwd(const float* dy, const float* x, const float* w, const float* scale, float* dx, float* gw_raw,
+                                float* gb, int N, int C, void* stream) {
+    DGMR_CHECK_ARG(dy && x && w && dx && gw_raw, "dgmr_linear1_bwd: null pointer");
+    hipLaunchKernelGGL(linear1_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, dy, x, w, scale, dx, gw_raw, gb, N, C);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_hinge_disc(const float* s_real, const float* s_gen, float* loss, float* d_real, float* d_gen, int n_real,
+                               int n_gen, void* stream) {
+    DGMR_CHECK_ARG(s_real && s_gen && loss && n_real > 0 && n_gen > 0, "dgmr_hinge_disc: bad args");
+    hipLaunchKernelGGL(hinge_disc_kernel, dim3(1), dim3(256), 0, ST, s_real, s_gen, loss, d_real, d_gen, n_real, n_gen);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_stride, const float* target, float cap, double* acc,
+                                   float* loss, float mult, float* dweight, int64_t n, void* stream) {
+    DGMR_CHECK_ARG(preds && target && acc && loss && K > 0 && n > 0, "dgmr_grid_cell_loss: bad args");
+    hipLaunchKernelGGL(grid_cell_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, preds, K, pred_stride, target, cap, acc,
+                       dweight, n);
+    hipLaunchKernelGGL(grid_cell_finish_kernel, dim3(1), dim3(1), 0, ST, acc, loss, mult);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                         int step, void* stream) {
+    DGMR_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "dgmr_adam: bad args");
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / std::sqrt(bc2));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, p, g, m, v, n, beta1, beta2, eps, step_size,
+                       inv_bc2_sqrt);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,109 @@
+"""Spatial / temporal discriminators (mirror of dgmr/discriminators.py) on the HIP operators."""
+import torch
+from huggingface_hub import PyTorchModelHubMixin
+
+from . import ops
+from .common import DBlock
+from .nn import BatchNorm1d, SNLinear1
+
+
+class Discriminator(torch.nn.Module, PyTorchModelHubMixin):
+    """dgmr/discriminators.py:12-44."""
+
+    def __init__(self, input_channels: int = 12, num_spatial_frames: int = 8, conv_type: str = "standard"):
+        super().__init__()
+        self.spatial_discriminator = SpatialDiscriminator(input_channels=input_channels, num_timesteps=num_spatial_frames,
+                                                          conv_type=conv_type)
+        self.temporal_discriminator = TemporalDiscriminator(input_channels=input_channels, conv_type=conv_type)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        spatial_loss = self.spatial_discriminator(x)
+        temporal_loss = self.temporal_discriminator(x)
+        return torch.cat([spatial_loss, temporal_loss], dim=1)
+
+
+def _sum_heads(reps):
+    acc = reps[0]
+    for r in reps[1:]:
+        acc = ops.axpby(acc, r)
+    return acc.unsqueeze(1)  # [N, 1, 1]
+
+
+class TemporalDiscriminator(torch.nn.Module, PyTorchModelHubMixin):
+    """dgmr/discriminators.py:47-138."""
+
+    def __init__(self, input_channels: int = 12, num_layers: int = 3, conv_type: str = "standard"):
+        super().__init__()
+        self.downsample = torch.nn.AvgPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2))
+        self.space2depth = torch.nn.PixelUnshuffle(downscale_factor=2)
+        internal_chn = 48
+        self.d1 = DBlock(4 * input_channels, internal_chn * input_channels, conv_type="3d", first_relu=False)
+        self.d2 = DBlock(internal_chn * input_channels, 2 * internal_chn * input_channels, conv_type="3d")
+        self.intermediate_dblocks = torch.nn.ModuleList()
+        for _ in range(num_layers):
+            internal_chn *= 2
+            self.intermediate_dblocks.append(
+                DBlock(internal_chn * input_channels, 2 * internal_chn * input_channels, conv_type=conv_type))
+        self.d_last = DBlock(2 * internal_chn * input_channels, 2 * internal_chn * input_channels, keep_same_output=True,
+                             conv_type=conv_type)
+        self.fc = SNLinear1(2 * internal_chn * input_channels)
+        self.relu = torch.nn.ReLU()
+        self.bn = BatchNorm1d(2 * internal_chn * input_channels)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        ops.require_hip(x, "discriminator frames")
+        # AvgPool3d((1,2,2)) + PixelUnshuffle(2) + permute to N C T H W, written once as N T H W C
+        x = ops.frames_s2d(x, None, pool=True, frame_major=False, as_3d=True)
+        x = self.d1(x)
+        x = self.d2(x)
+        representations = []
+        for idx in range(x.size(2)):
+            rep = x[:, :, idx]
+            for d in self.intermediate_dblocks:
+                rep = d(rep)
+            rep = self.d_last(rep)
+            rep = ops.relu_sum_hw(rep)
+            rep = self.bn(rep)
+            rep = self.fc(rep)
+            representations.append(rep)
+        return _sum_heads(representations)
+
+
+class SpatialDiscriminator(torch.nn.Module, PyTorchModelHubMixin):
+    """dgmr/discriminators.py:141-232."""
+
+    def __init__(self, input_channels: int = 12, num_timesteps: int = 8, num_layers: int = 4, conv_type: str = "standard"):
+        super().__init__()
+        self.num_timesteps = num_timesteps
+        self.mean_pool = torch.nn.AvgPool2d(2)
+        self.space2depth = torch.nn.PixelUnshuffle(downscale_factor=2)
+        internal_chn = 24
+        self.d1 = DBlock(4 * input_channels, 2 * internal_chn * input_channels, first_relu=False, conv_type=conv_type)
+        self.intermediate_dblocks = torch.nn.ModuleList()
+        for _ in range(num_layers):
+            internal_chn *= 2
+            self.intermediate_dblocks.append(
+                DBlock(internal_chn * input_channels, 2 * internal_chn * input_channels, conv_type=conv_type))
+        self.d6 = DBlock(2 * internal_chn * input_channels, 2 * internal_chn * input_channels, keep_same_output=True,
+                         conv_type=conv_type)
+        self.fc = SNLinear1(2 * internal_chn * input_channels)
+        self.relu = torch.nn.ReLU()
+        self.bn = BatchNorm1d(2 * internal_chn * input_channels)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        ops.require_hip(x, "discriminator frames")
+        # frame indices come from the CPU generator exactly as in the reference (discriminators.py:199)
+        idxs = torch.randint(low=0, high=x.size()[1], size=(self.num_timesteps,))
+        idxs_dev = idxs.to(device=x.device, dtype=torch.int32)
+        representations = []
+        for i in range(self.num_timesteps):
+            rep = ops.frames_s2d(x, idxs_dev[i:i + 1], pool=True)  # AvgPool2d(2) + PixelUnshuffle(2) of frame idx
+            rep = self.d1(rep)
+            for d in self.intermediate_dblocks:
+                rep = d(rep)
+            rep = self.d6(rep)
+            rep = ops.relu_sum_hw(rep)
+            rep = self.bn(rep)
+            rep = self.fc(rep)
+            representations.append(rep)
+        return _sum_heads(representations)

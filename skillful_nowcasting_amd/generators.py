@@ -1,0 +1,72 @@
+"""Sampler and Generator (mirror of dgmr/generators.py) on the HIP operators."""
+from typing import List
+
+import torch
+from huggingface_hub import PyTorchModelHubMixin
+
+from . import ops
+from .common import GBlock, UpsampleGBlock
+from .layers import ConvGRU
+from .nn import BatchNorm, SNConv
+
+
+class Sampler(torch.nn.Module, PyTorchModelHubMixin):
+    """dgmr/generators.py:20-182: 4 x (ConvGRU -> SN-1x1 -> GBlock -> UpsampleGBlock), BN+ReLU, SN-1x1, depth-to-space."""
+
+    def __init__(self, forecast_steps: int = 18, latent_channels: int = 768, context_channels: int = 384,
+                 output_channels: int = 1):
+        super().__init__()
+        self.forecast_steps = forecast_steps
+        lc, cc = latent_channels, context_channels
+        self.convGRU1 = ConvGRU(lc + cc, cc, 3)
+        self.gru_conv_1x1 = SNConv(cc, lc, 1)
+        self.g1 = GBlock(lc, lc)
+        self.up_g1 = UpsampleGBlock(lc, lc // 2)
+        self.convGRU2 = ConvGRU(lc // 2 + cc // 2, cc // 2, 3)
+        self.gru_conv_1x1_2 = SNConv(cc // 2, lc // 2, 1)
+        self.g2 = GBlock(lc // 2, lc // 2)
+        self.up_g2 = UpsampleGBlock(lc // 2, lc // 4)
+        self.convGRU3 = ConvGRU(lc // 4 + cc // 4, cc // 4, 3)
+        self.gru_conv_1x1_3 = SNConv(cc // 4, lc // 4, 1)
+        self.g3 = GBlock(lc // 4, lc // 4)
+        self.up_g3 = UpsampleGBlock(lc // 4, lc // 8)
+        self.convGRU4 = ConvGRU(lc // 8 + cc // 8, cc // 8, 3)
+        self.gru_conv_1x1_4 = SNConv(cc // 8, lc // 8, 1)
+        self.g4 = GBlock(lc // 8, lc // 8)
+        self.up_g4 = UpsampleGBlock(lc // 8, lc // 16)
+        self.bn = BatchNorm(lc // 16)
+        self.relu = torch.nn.ReLU()
+        self.conv_1x1 = SNConv(lc // 16, 4 * output_channels, 1)
+        self.depth2space = torch.nn.PixelShuffle(upscale_factor=2)
+
+    def forward(self, conditioning_states: List[torch.Tensor], latent_dim: torch.Tensor) -> torch.Tensor:
+        init_states = conditioning_states
+        latent_dim = ops.repeat_batch(latent_dim, init_states[0].shape[0])
+        hidden_states = [latent_dim] * self.forecast_steps
+        levels = ((self.convGRU1, self.gru_conv_1x1, self.g1, self.up_g1),
+                  (self.convGRU2, self.gru_conv_1x1_2, self.g2, self.up_g2),
+                  (self.convGRU3, self.gru_conv_1x1_3, self.g3, self.up_g3),
+                  (self.convGRU4, self.gru_conv_1x1_4, self.g4, self.up_g4))
+        for lvl, (gru, c11, g, upg) in enumerate(levels):
+            hidden_states = gru.forward_list(hidden_states, init_states[3 - lvl])
+            hidden_states = [c11(h) for h in hidden_states]
+            hidden_states = [g(h) for h in hidden_states]
+            hidden_states = [upg(h) for h in hidden_states]
+        # relu(bn(h)) folded into the 1x1 conv's operand load; PixelShuffle + stack in one layout kernel per step
+        hidden_states = [self.conv_1x1(h, bn=self.bn.prepare(h)) for h in hidden_states]
+        return ops.d2s_frames(hidden_states)
+
+
+class Generator(torch.nn.Module, PyTorchModelHubMixin):
+    """dgmr/generators.py:185-212."""
+
+    def __init__(self, conditioning_stack: torch.nn.Module, latent_stack: torch.nn.Module, sampler: torch.nn.Module):
+        super().__init__()
+        self.conditioning_stack = conditioning_stack
+        self.latent_stack = latent_stack
+        self.sampler = sampler
+
+    def forward(self, x: torch.Tensor):
+        conditioning_states = self.conditioning_stack(x)
+        latent_dim = self.latent_stack(x)
+        return self.sampler(conditioning_states, latent_dim)

@@ -1,0 +1,792 @@
+"""Host-side operators of the DGMR step: thin ``torch.autograd.Function`` wrappers over libdgmr_hip.so.
+
+PyTorch is plumbing here (device memory, streams, the autograd tape); every arithmetic op on the hot
+path is a HIP kernel reached through the C ABI in ``include/dgmr_hip.h``.  There is no CPU or eager-torch
+fallback: tensors that are not on a HIP device raise ``RuntimeError``.
+
+Layout: activations are logical NCHW / NCDHW tensors held in ``channels_last`` / ``channels_last_3d``
+memory format, i.e. physically N[D]HWC; conv weights are OIHW parameters held channels_last, i.e.
+physically O[D]HWI — exactly what the kernels index.
+
+Parameter gradients are accumulated by the kernels directly into ``param.grad`` (allocated zeroed on
+first touch); the Functions return ``None`` for parameter inputs.  That is what lets the weight-gradient
+epilogue fuse the spectral-norm chain rule and skips autograd's separate accumulate kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from ._lib import ConvArgs, WgradArgs, call
+
+_WEIGHTS_EPOCH = 0  # bumped by the optimiser after every in-place parameter update (flip cache key)
+
+
+def bump_weights_epoch():
+    global _WEIGHTS_EPOCH
+    _WEIGHTS_EPOCH += 1
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def require_hip(t: torch.Tensor, what: str = "input"):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"skillful_nowcasting_amd: {what} is on '{t.device}'. The DGMR kernels are HIP-only (gfx950); "
+            "there is no CPU fallback — move the module and its inputs to a HIP device."
+        )
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"skillful_nowcasting_amd: {what} must be float32, got {t.dtype}")
+
+
+def to_cl(x: torch.Tensor) -> torch.Tensor:
+    """Channels-last contiguous view/copy of a 4-D or 5-D activation (no-op on the hot path)."""
+    if x.dim() == 4:
+        return x.contiguous(memory_format=torch.channels_last)
+    if x.dim() == 5:
+        return x.contiguous(memory_format=torch.channels_last_3d)
+    return x.contiguous()
+
+
+def empty_cl(shape: Sequence[int], like: torch.Tensor) -> torch.Tensor:
+    mf = torch.channels_last if len(shape) == 4 else torch.channels_last_3d
+    return torch.empty(tuple(shape), device=like.device, dtype=torch.float32, memory_format=mf)
+
+
+def _dims(x: torch.Tensor):
+    """(N, C, D, H, W) of a 4-D / 5-D logical NC[D]HW tensor."""
+    if x.dim() == 4:
+        n, c, h, w = x.shape
+        return n, c, 1, h, w
+    n, c, d, h, w = x.shape
+    return n, c, d, h, w
+
+
+def grad_buffer(p: torch.Tensor) -> torch.Tensor:
+    """``p.grad`` with p's physical layout, zero-initialised on first touch."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)  # preserve_format: same strides as the parameter
+    return p.grad
+
+
+# ---------------------------------------------------------------------------------------------------
+# spectral norm (torch/nn/utils/parametrizations.py:454-521)
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class SNCall:
+    inv_sigma: torch.Tensor  # [1]
+    u: torch.Tensor  # copies of the u, v that sigma was computed with (the module buffers move on)
+    v: torch.Tensor
+
+
+def spectral_sigma(w: torch.Tensor, u: torch.Tensor, v: torch.Tensor, scratch: torch.Tensor, eps: float, train: bool) -> SNCall:
+    """One power iteration (train) + 1/sigma; u, v updated in place like the reference does."""
+    require_hip(w, "spectral-norm weight")
+    cout = w.shape[0]
+    cin = w.shape[1]
+    taps = w.numel() // (cout * cin)
+    k = cin * taps
+    inv_sigma = torch.empty(1, device=w.device, dtype=torch.float32)
+    u_save = torch.empty_like(u)
+    v_save = torch.empty_like(v)
+    tmp = torch.empty(cout + k, device=w.device, dtype=torch.float32)
+    call("dgmr_spectral_sigma", _p(w), _p(u), _p(v), _p(u_save), _p(v_save), _p(inv_sigma), _p(scratch), _p(tmp), cout, cin,
+         taps, float(eps), int(bool(train)), _stream())
+    return SNCall(inv_sigma, u_save, v_save)
+
+
+# ---------------------------------------------------------------------------------------------------
+# batch norm statistics -> per-channel affine consumed by the next conv's operand load
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class BNState:
+    a: torch.Tensor  # [G, C]   y = relu(a*x + b)
+    b: torch.Tensor
+    mean: torch.Tensor
+    rstd: torch.Tensor
+    gamma: Optional[torch.Tensor]
+    beta: Optional[torch.Tensor]
+    train: bool
+    groups: int
+    group_size: int  # samples per group
+
+
+def bn_prepare(x: torch.Tensor, gamma, beta, running_mean, running_var, num_batches_tracked, eps: float, momentum: float,
+               train: bool, groups: int = 1) -> BNState:
+    """BatchNorm statistics of x (train) or running statistics (eval) folded to y = a*x + b.
+
+    torch.nn.BatchNorm2d semantics (dgmr/common.py:38-39,108-109; generators.py:113): biased batch variance
+    for normalisation, unbiased for the running estimate, momentum 0.1, one running update per group in order.
+    """
+    require_hip(x)
+    x = to_cl(x)
+    n, c, d, h, w = _dims(x)
+    if not train:
+        groups = 1
+    assert n % groups == 0
+    r = (n // groups) * d * h * w
+    dev = x.device
+    a = torch.empty(groups, c, device=dev)
+    b = torch.empty(groups, c, device=dev)
+    mean = torch.empty(groups, c, device=dev)
+    rstd = torch.empty(groups, c, device=dev)
+    if train:
+        sums = torch.zeros(groups * 2 * c, device=dev, dtype=torch.float64)
+        call("dgmr_bn_stats", _p(x), _p(sums), groups, r, c, _stream())
+        call("dgmr_bn_finalize", _p(sums), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(num_batches_tracked),
+             _p(a), _p(b), _p(mean), _p(rstd), groups, r, c, float(eps), float(momentum), _stream())
+    else:
+        call("dgmr_bn_finalize", None, _p(gamma), _p(beta), _p(running_mean), _p(running_var), None, _p(a), _p(b), _p(mean),
+             _p(rstd), 1, r, c, float(eps), float(momentum), _stream())
+    return BNState(a, b, mean, rstd, gamma, beta, train, groups, n // groups)
+
+
+# ---------------------------------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class ConvSpec:
+    """Everything about one conv call that is not a differentiable tensor."""
+
+    upsample: bool = False  # nearest 2x on the input (common.py:142,148)
+    pre_relu: bool = False  # relu on the input
+    bn: Optional[BNState] = None  # BatchNorm+ReLU on the input
+    sn: Optional[SNCall] = None  # spectral-norm call record (scale = 1/sigma)
+    gamma_scale: bool = False  # scale tensor is a learnable scalar parameter (Attention.gamma)
+    act_relu: bool = False  # relu on the output (F.relu(conv(..)), common.py:424)
+
+
+_flip_cache = {}
+
+
+def _flipped_weight(w: torch.Tensor) -> torch.Tensor:
+    """Weights of the transposed conv, cached until the parameter changes."""
+    key = id(w)
+    tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr())
+    hit = _flip_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    cout, cin = w.shape[0], w.shape[1]
+    ks = list(w.shape[2:])
+    kd, kh, kw = ([1] + ks) if len(ks) == 2 else ks
+    wt = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+    call("dgmr_conv_flip_weights", _p(w), _p(wt), cout, cin, kd, kh, kw, _stream())
+    _flip_cache[key] = (tag, wt)
+    return wt
+
+
+def _kdims(w: torch.Tensor):
+    ks = list(w.shape[2:])
+    return tuple([1] + ks) if len(ks) == 2 else tuple(ks)
+
+
+def _launch_conv(x, w_ptr, bias, scale, y, n, d, h, w_, cin, cout, kd, kh, kw, *, upsample=False, pre_relu=False, pre_a=None,
+                 pre_b=None, pre_group=1, residual=None, addend=None, mask_src=None, mask_a=None, mask_b=None, mask_group=1,
+                 scale_group=None, act_relu=False):
+    a = ConvArgs()
+    a.x, a.w, a.bias, a.scale = _p(x), w_ptr, _p(bias), _p(scale)
+    a.pre_a, a.pre_b, a.addend, a.residual = _p(pre_a), _p(pre_b), _p(addend), _p(residual)
+    a.mask_src, a.mask_a, a.mask_b, a.y = _p(mask_src), _p(mask_a), _p(mask_b), _p(y)
+    a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, d, h, w_, cin, cout
+    a.KD, a.KH, a.KW = kd, kh, kw
+    a.upsample, a.pre_relu = int(upsample), int(pre_relu)
+    a.scale_group = scale_group if scale_group else n
+    a.pre_group, a.mask_group = pre_group, mask_group
+    a.act_relu = int(act_relu)
+    call("dgmr_conv_fwd", ctypes.byref(a), _stream())
+
+
+class ConvFn(Function):
+    """y = conv(pre(x), W) * scale + bias (+ residual), pre in {id, relu, BN+relu, nearest-2x∘those}."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, scale, residual, bn_gamma, bn_beta, spec: ConvSpec):
+        require_hip(x)
+        x = to_cl(x)
+        n, cin, d, h, wd = _dims(x)
+        if spec.upsample:
+            h, wd = 2 * h, 2 * wd
+        cout = w.shape[0]
+        kd, kh, kw = _kdims(w)
+        if w.shape[1] != cin:
+            raise RuntimeError(f"conv: input has {cin} channels, weight expects {w.shape[1]}")
+        oshape = (n, cout, h, wd) if x.dim() == 4 else (n, cout, d, h, wd)
+        y = empty_cl(oshape, x)
+        if residual is not None:
+            residual = to_cl(residual)
+        bn = spec.bn
+        _launch_conv(x, _p(w), bias, scale, y, n, d, h, wd, cin, cout, kd, kh, kw, upsample=spec.upsample,
+                     pre_relu=spec.pre_relu, pre_a=bn.a if bn else None, pre_b=bn.b if bn else None,
+                     pre_group=bn.group_size if bn else 1, residual=residual, act_relu=spec.act_relu)
+        ctx.spec = spec
+        ctx.has_residual = residual is not None
+        ctx.params = (w, bias)
+        ctx.save_for_backward(x, scale, y if spec.act_relu else None)
+        ctx.geom = (n, cin, cout, d, h, wd, kd, kh, kw)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        spec: ConvSpec = ctx.spec
+        x, scale, y_act = ctx.saved_tensors
+        w, bias = ctx.params
+        n, cin, cout, d, h, wd, kd, kh, kw = ctx.geom
+        dy = to_cl(dy)
+        dev = dy.device
+        if y_act is not None:  # relu epilogue (never combined with a residual on this path)
+            assert not ctx.has_residual
+            dz = torch.empty_like(dy)
+            call("dgmr_relu_bwd", _p(dy), _p(y_act), _p(dz), dy.numel(), _stream())
+            dy = dz
+        m = n * d * h * wd
+        k = kd * kh * kw * cin
+        bn = spec.bn
+        st = _stream()
+        # ---- bias ----
+        if bias is not None and bias.requires_grad:
+            tmp = torch.empty(2 * cout, device=dev, dtype=torch.float64)
+            call("dgmr_colsum", _p(dy), _p(grad_buffer(bias)), _p(tmp), m, cout, 1, st)
+        # ---- weight (and scale) ----
+        if w.requires_grad:
+            ns = call_nsplit(m, cout, k)
+            partial = torch.empty(ns * cout * k, device=dev, dtype=torch.float32)
+            wa = WgradArgs()
+            wa.x, wa.dy, wa.partial = _p(x), _p(dy), _p(partial)
+            wa.pre_a, wa.pre_b = (_p(bn.a), _p(bn.b)) if bn else (None, None)
+            wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, d, h, wd, cin, cout
+            wa.KD, wa.KH, wa.KW = kd, kh, kw
+            wa.upsample, wa.pre_relu, wa.pre_group, wa.nsplit = int(spec.upsample), int(spec.pre_relu), (bn.group_size if bn else 1), ns
+            call("dgmr_conv_wgrad", ctypes.byref(wa), st)
+            gw = grad_buffer(w)
+            if scale is None:
+                g = torch.empty(cout * k, device=dev, dtype=torch.float32)
+                call("dgmr_wgrad_reduce", _p(partial), ns, cout * k, None, _p(g), None, st)
+                call("dgmr_axpby", _p(gw), _p(g), _p(gw), 1.0, 1.0, cout * k, st)
+            else:
+                g = torch.empty(cout * k, device=dev, dtype=torch.float32)
+                dot = torch.zeros(1, device=dev, dtype=torch.float32)
+                call("dgmr_wgrad_reduce", _p(partial), ns, cout * k, _p(w), _p(g), _p(dot), st)
+                if spec.sn is not None:
+                    call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), _p(spec.sn.u), _p(spec.sn.v), cout, cin,
+                         kd * kh * kw, 1, st)
+                else:  # learnable scalar gain: d scale = <G, W>, dW = scale * G
+                    if spec.gamma_scale and scale.requires_grad:
+                        gs = grad_buffer(scale)
+                        call("dgmr_axpby", _p(gs), _p(dot), _p(gs), 1.0, 1.0, 1, st)
+                    call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), None, None, cout, cin, kd * kh * kw, 1, st)
+        # ---- input ----
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = _flipped_weight(w)
+            if spec.upsample:
+                hi = empty_cl((n, cin, h, wd) if x.dim() == 4 else (n, cin, d, h, wd), dy)
+                _launch_conv(dy, _p(wt), None, scale, hi, n, d, h, wd, cout, cin, kd, kh, kw)
+                g = empty_cl(x.shape, dy)
+                call("dgmr_pool_fwd", _p(hi), None, _p(g), n, d, h, wd, cin, 1, 1.0, _p(x) if (bn or spec.pre_relu) else None,
+                     _p(bn.a) if bn else None, _p(bn.b) if bn else None, bn.group_size if bn else 1, st)
+            else:
+                g = empty_cl(x.shape, dy)
+                _launch_conv(dy, _p(wt), None, scale, g, n, d, h, wd, cout, cin, kd, kh, kw,
+                             mask_src=x if (bn or spec.pre_relu) else None, mask_a=bn.a if bn else None,
+                             mask_b=bn.b if bn else None, mask_group=bn.group_size if bn else 1)
+            if bn is None:
+                dx = g
+            else:
+                c = cin
+                r = x.numel() // (c * bn.groups)
+                sums = torch.zeros(bn.groups * 2 * c, device=dev, dtype=torch.float64)
+                call("dgmr_bn_bwd_reduce", _p(g), _p(x), _p(bn.mean), _p(bn.rstd), _p(sums), bn.groups, r, c, st)
+                dx = empty_cl(x.shape, dy)
+                dgam = grad_buffer(bn.gamma) if (bn.gamma is not None and bn.gamma.requires_grad) else None
+                dbet = grad_buffer(bn.beta) if (bn.beta is not None and bn.beta.requires_grad) else None
+                call("dgmr_bn_bwd_apply", _p(g), _p(x), _p(bn.mean), _p(bn.rstd), _p(bn.gamma), _p(sums), None, _p(dx), _p(dgam),
+                     _p(dbet), bn.groups, r, c, int(bn.train), st)
+        d_res = dy if ctx.has_residual else None
+        return dx, None, None, None, d_res, None, None, None
+
+
+def call_nsplit(m: int, cout: int, k: int) -> int:
+    from ._lib import load
+
+    return int(load().dgmr_conv_wgrad_nsplit(m, cout, k))
+
+
+def conv(x, w, bias=None, scale=None, residual=None, spec: Optional[ConvSpec] = None):
+    spec = spec or ConvSpec()
+    bn = spec.bn
+    return ConvFn.apply(x, w, bias, scale, residual, bn.gamma if bn else None, bn.beta if bn else None, spec)
+
+
+# ---------------------------------------------------------------------------------------------------
+# pooling / layout
+# ---------------------------------------------------------------------------------------------------
+class PoolAddFn(Function):
+    """AvgPool2d(2) / AvgPool3d(2) (+ addend): dgmr/common.py:189-191,225,236-237."""
+
+    @staticmethod
+    def forward(ctx, x, addend, pd: int):
+        require_hip(x)
+        x = to_cl(x)
+        n, c, d, h, w = _dims(x)
+        oshape = (n, c, h // 2, w // 2) if x.dim() == 4 else (n, c, d // pd, h // 2, w // 2)
+        y = empty_cl(oshape, x)
+        if addend is not None:
+            addend = to_cl(addend)
+        call("dgmr_pool_fwd", _p(x), _p(addend), _p(y), n, d, h, w, c, pd, 0.0, None, None, None, 1, _stream())
+        ctx.geom = (n, c, d, h, w, pd, x.dim())
+        ctx.has_addend = addend is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, d, h, w, pd, nd = ctx.geom
+        dy = to_cl(dy)
+        dx = empty_cl((n, c, h, w) if nd == 4 else (n, c, d, h, w), dy)
+        call("dgmr_pool_bwd", _p(dy), _p(dx), n, d, h, w, c, pd, 0.0, _stream())
+        return dx, (dy if ctx.has_addend else None), None
+
+
+def avg_pool_add(x, addend=None, pd: int = 1):
+    return PoolAddFn.apply(x, addend, pd)
+
+
+class FramesS2DFn(Function):
+    """[B,T,C,H,W] frames -> (optional AvgPool2d(2)) -> PixelUnshuffle(2) -> channels-last batch of frames.
+
+    discriminators.py:106-108,202-203 ; common.py:393,400.
+    """
+
+    @staticmethod
+    def forward(ctx, frames, idx, pool: bool, frame_major: bool, as_3d: bool):
+        require_hip(frames)
+        frames = frames.contiguous()
+        b, t, c, h, w = frames.shape
+        f = t if idx is None else idx.numel()
+        p = 2 if pool else 1
+        ho, wo = h // (2 * p), w // (2 * p)
+        if as_3d:
+            out = empty_cl((b, 4 * c, f, ho, wo), frames)
+        else:
+            out = empty_cl((b * f, 4 * c, ho, wo), frames)
+        call("dgmr_frames_s2d", _p(frames), _p(idx), _p(out), b, t, c, h, w, f, int(pool), int(frame_major), _stream())
+        ctx.geom = (b, t, c, h, w, f, int(pool), int(frame_major))
+        ctx.idx = idx
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, t, c, h, w, f, pool, fm = ctx.geom
+        dout = to_cl(dout)
+        dfr = torch.zeros(b, t, c, h, w, device=dout.device, dtype=torch.float32)
+        call("dgmr_frames_s2d_bwd", _p(dout), _p(ctx.idx), _p(dfr), b, t, c, h, w, f, pool, fm, _stream())
+        return dfr, None, None, None, None
+
+
+def frames_s2d(frames, idx=None, pool=False, frame_major=False, as_3d=False):
+    return FramesS2DFn.apply(frames, idx, pool, frame_major, as_3d)
+
+
+class D2SFramesFn(Function):
+    """T channels-last maps [B,4C,h,w] -> PixelShuffle(2) -> stacked frames [B,T,C,2h,2w] (generators.py:178-181)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [to_cl(x) for x in xs]
+        require_hip(xs[0])
+        b, c4, h, w = xs[0].shape
+        c, t = c4 // 4, len(xs)
+        frames = torch.empty(b, t, c, 2 * h, 2 * w, device=xs[0].device, dtype=torch.float32)
+        for i, x in enumerate(xs):
+            call("dgmr_d2s_frames", _p(x), _p(frames), b, t, i, c, h, w, _stream())
+        ctx.geom = (b, t, c, h, w)
+        return frames
+
+    @staticmethod
+    def backward(ctx, dfr):
+        b, t, c, h, w = ctx.geom
+        dfr = dfr.contiguous()
+        outs = []
+        for i in range(t):
+            dx = empty_cl((b, 4 * c, h, w), dfr)
+            call("dgmr_d2s_frames_bwd", _p(dfr), _p(dx), b, t, i, c, h, w, _stream())
+            outs.append(dx)
+        return tuple(outs)
+
+
+def d2s_frames(xs: Sequence[torch.Tensor]):
+    return D2SFramesFn.apply(*xs)
+
+
+class CatChannelsFn(Function):
+    """torch.cat(dim=1) on channels-last tensors; `interleave`: 'b t c h w -> b (c t) h w' (common.py:423)."""
+
+    @staticmethod
+    def forward(ctx, interleave: bool, *xs):
+        xs = [to_cl(x) for x in xs]
+        require_hip(xs[0])
+        cs = [x.shape[1] for x in xs]
+        ctot = sum(cs)
+        shape = list(xs[0].shape)
+        shape[1] = ctot
+        out = empty_cl(shape, xs[0])
+        r = xs[0].numel() // cs[0]
+        off = 0
+        for i, x in enumerate(xs):
+            if interleave:
+                call("dgmr_copy_channels", _p(x), _p(out), r, cs[i], cs[i], 0, 1, ctot, i, len(xs), 0, _stream())
+            else:
+                call("dgmr_copy_channels", _p(x), _p(out), r, cs[i], cs[i], 0, 1, ctot, off, 1, 0, _stream())
+            off += cs[i]
+        ctx.cs, ctx.interleave, ctx.r = cs, interleave, r
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = to_cl(dout)
+        cs, ctot = ctx.cs, sum(ctx.cs)
+        outs = []
+        off = 0
+        for i, c in enumerate(cs):
+            shape = list(dout.shape)
+            shape[1] = c
+            dx = empty_cl(shape, dout)
+            if ctx.interleave:
+                call("dgmr_copy_channels", _p(dout), _p(dx), ctx.r, c, ctot, i, len(cs), c, 0, 1, 0, _stream())
+            else:
+                call("dgmr_copy_channels", _p(dout), _p(dx), ctx.r, c, ctot, off, 1, c, 0, 1, 0, _stream())
+            outs.append(dx)
+            off += c
+        return (None, *outs)
+
+
+def cat_channels(xs: Sequence[torch.Tensor], interleave: bool = False):
+    return CatChannelsFn.apply(interleave, *xs)
+
+
+class RepeatBatchFn(Function):
+    """einops 'b c h w -> (repeat b) c h w' for b == 1 (generators.py:146-148)."""
+
+    @staticmethod
+    def forward(ctx, x, repeat: int):
+        require_hip(x)
+        x = to_cl(x)
+        assert x.shape[0] == 1
+        out = empty_cl((repeat,) + tuple(x.shape[1:]), x)
+        n = x.numel()
+        for i in range(repeat):
+            call("dgmr_axpby", _p(x), None, out.data_ptr() + 4 * n * i, 1.0, 0.0, n, _stream())
+        ctx.repeat = repeat
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = to_cl(dout)
+        n = dout.numel() // ctx.repeat
+        dx = empty_cl((1,) + tuple(dout.shape[1:]), dout)
+        tmp = torch.empty(2 * n, device=dout.device, dtype=torch.float64)
+        call("dgmr_colsum", _p(dout), _p(dx), _p(tmp), ctx.repeat, n, 0, _stream())
+        return dx, None
+
+
+def repeat_batch(x, repeat: int):
+    return RepeatBatchFn.apply(x, repeat)
+
+
+# ---------------------------------------------------------------------------------------------------
+# ConvGRU gating (dgmr/layers/ConvGRU.py:69-85)
+# ---------------------------------------------------------------------------------------------------
+class GruGateFn(Function):
+    @staticmethod
+    def forward(ctx, pr, h):
+        pr, h = to_cl(pr), to_cl(h)
+        require_hip(pr)
+        out = torch.empty_like(pr)
+        call("dgmr_gru_gate_fwd", _p(pr), _p(h), _p(out), pr.numel(), _stream())
+        ctx.save_for_backward(pr, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        pr, h = ctx.saved_tensors
+        d = to_cl(d)
+        dpr, dh = torch.empty_like(pr), torch.empty_like(pr)
+        call("dgmr_gru_gate_bwd", _p(d), _p(pr), _p(h), _p(dpr), _p(dh), pr.numel(), _stream())
+        return dpr, dh
+
+
+class GruBlendFn(Function):
+    @staticmethod
+    def forward(ctx, pu, h, pc):
+        pu, h, pc = to_cl(pu), to_cl(h), to_cl(pc)
+        require_hip(pu)
+        out = torch.empty_like(pu)
+        call("dgmr_gru_blend_fwd", _p(pu), _p(h), _p(pc), _p(out), pu.numel(), _stream())
+        ctx.save_for_backward(pu, h, pc)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        pu, h, pc = ctx.saved_tensors
+        d = to_cl(d)
+        dpu, dh, dpc = torch.empty_like(pu), torch.empty_like(pu), torch.empty_like(pu)
+        call("dgmr_gru_blend_bwd", _p(d), _p(pu), _p(h), _p(pc), _p(dpu), _p(dh), _p(dpc), pu.numel(), _stream())
+        return dpu, dh, dpc
+
+
+gru_gate = GruGateFn.apply
+gru_blend = GruBlendFn.apply
+
+
+# ---------------------------------------------------------------------------------------------------
+# latent attention (dgmr/layers/Attention.py:9-20,78-82)
+# ---------------------------------------------------------------------------------------------------
+class AttentionFn(Function):
+    @staticmethod
+    def forward(ctx, q, k, v):
+        q, k, v = to_cl(q), to_cl(k), to_cl(v)
+        require_hip(q)
+        b, cq, h, w = q.shape
+        if v.shape[1] != cq:
+            raise RuntimeError("attention: ratio_kq must equal ratio_v (the reference's einsum requires it)")
+        L = cq * h
+        out = torch.empty_like(v)
+        beta = torch.empty(b, L, L, device=q.device, dtype=torch.float32)
+        n = cq * h * w
+        for i in range(b):
+            o = 4 * n * i
+            call("dgmr_attention_fwd", q.data_ptr() + o, k.data_ptr() + o, v.data_ptr() + o, beta.data_ptr() + 4 * L * L * i,
+                 out.data_ptr() + o, cq, h, w, _stream())
+        ctx.save_for_backward(q, k, v, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, beta = ctx.saved_tensors
+        dout = to_cl(dout)
+        b, cq, h, w = q.shape
+        L = cq * h
+        n = cq * h * w
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        tmp = torch.empty(L * L, device=q.device, dtype=torch.float32)
+        for i in range(b):
+            o = 4 * n * i
+            call("dgmr_attention_bwd", dout.data_ptr() + o, q.data_ptr() + o, k.data_ptr() + o, v.data_ptr() + o,
+                 beta.data_ptr() + 4 * L * L * i, dq.data_ptr() + o, dk.data_ptr() + o, dv.data_ptr() + o, _p(tmp), cq, h, w,
+                 _stream())
+        return dq, dk, dv
+
+
+attention = AttentionFn.apply
+
+
+# ---------------------------------------------------------------------------------------------------
+# discriminator heads (discriminators.py:127-131,217-219)
+# ---------------------------------------------------------------------------------------------------
+class ReluSumHWFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_hip(x)
+        x = to_cl(x)
+        n, c, h, w = x.shape
+        y = torch.empty(n, c, device=x.device, dtype=torch.float32)
+        call("dgmr_relu_sum_hw_fwd", _p(x), _p(y), n, h * w, c, _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        call("dgmr_relu_sum_hw_bwd", _p(dy.contiguous()), _p(x), _p(dx), n, h * w, c, _stream())
+        return dx
+
+
+relu_sum_hw = ReluSumHWFn.apply
+
+
+class BatchNorm1dFn(Function):
+    """torch.nn.BatchNorm1d on [N, C] (discriminators.py:102,129,194,218), batch statistics in train mode."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, eps, momentum, train):
+        require_hip(x)
+        x = x.contiguous()
+        n, c = x.shape
+        st = bn_prepare(x.view(n, c, 1, 1), gamma, beta, running_mean, running_var, nbt, eps, momentum, train)
+        y = torch.empty_like(x)
+        call("dgmr_affine", _p(x), _p(st.a), _p(st.b), _p(y), 1, n, c, 0, _stream())
+        ctx.st = st
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        st: BNState = ctx.st
+        n, c = x.shape
+        dy = dy.contiguous()
+        sums = torch.zeros(2 * c, device=x.device, dtype=torch.float64)
+        call("dgmr_bn_bwd_reduce", _p(dy), _p(x), _p(st.mean), _p(st.rstd), _p(sums), 1, n, c, _stream())
+        dx = torch.empty_like(x)
+        dgam = grad_buffer(st.gamma) if st.gamma.requires_grad else None
+        dbet = grad_buffer(st.beta) if st.beta.requires_grad else None
+        call("dgmr_bn_bwd_apply", _p(dy), _p(x), _p(st.mean), _p(st.rstd), _p(st.gamma), _p(sums), None, _p(dx), _p(dgam), _p(dbet),
+             1, n, c, int(st.train), _stream())
+        return dx, None, None, None, None, None, None, None, None
+
+
+class SNLinear1Fn(Function):
+    """spectral_norm(Linear(C, 1)) (discriminators.py:100,192)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, sn: SNCall):
+        require_hip(x)
+        x = x.contiguous()
+        n, c = x.shape
+        y = torch.empty(n, 1, device=x.device, dtype=torch.float32)
+        call("dgmr_linear1_fwd", _p(x), _p(w), _p(bias), _p(sn.inv_sigma), _p(y), n, c, _stream())
+        ctx.sn = sn
+        ctx.params = (w, bias)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w, bias = ctx.params
+        sn: SNCall = ctx.sn
+        n, c = x.shape
+        dy = dy.contiguous()
+        dev = x.device
+        dx = torch.empty_like(x)
+        g = torch.empty(c, device=dev, dtype=torch.float32)
+        gb = torch.empty(1, device=dev, dtype=torch.float32)
+        st = _stream()
+        call("dgmr_linear1_bwd", _p(dy), _p(x), _p(w), _p(sn.inv_sigma), _p(dx), _p(g), _p(gb), n, c, st)
+        if bias is not None and bias.requires_grad:
+            b = grad_buffer(bias)
+            call("dgmr_axpby", _p(b), _p(gb), _p(b), 1.0, 1.0, 1, st)
+        if w.requires_grad:
+            dot = torch.zeros(1, device=dev, dtype=torch.float32)
+            g2 = torch.empty_like(g)
+            call("dgmr_wgrad_reduce", _p(g), 1, c, _p(w), _p(g2), _p(dot), st)
+            call("dgmr_sn_wgrad_finalize", _p(g2), _p(grad_buffer(w)), _p(dot), _p(sn.inv_sigma), _p(sn.u), _p(sn.v), 1, c, 1, 1, st)
+        return dx, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# losses (dgmr/losses.py:172-192,307-319 ; dgmr/dgmr.py:20-33)
+# ---------------------------------------------------------------------------------------------------
+class HingeDiscFn(Function):
+    @staticmethod
+    def forward(ctx, score_generated, score_real):
+        require_hip(score_real)
+        sg, sr = score_generated.contiguous(), score_real.contiguous()
+        loss = torch.empty((), device=sr.device, dtype=torch.float32)
+        dg, dr = torch.empty_like(sg), torch.empty_like(sr)
+        call("dgmr_hinge_disc", _p(sr), _p(sg), _p(loss), _p(dr), _p(dg), sr.numel(), sg.numel(), _stream())
+        ctx.save_for_backward(dg, dr)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        dg, dr = ctx.saved_tensors
+        gl = gl.contiguous()
+        og, orr = torch.empty_like(dg), torch.empty_like(dr)
+        call("dgmr_scale_by_dev", _p(dg), _p(gl), 1.0, _p(og), dg.numel(), _stream())
+        call("dgmr_scale_by_dev", _p(dr), _p(gl), 1.0, _p(orr), dr.numel(), _stream())
+        return og, orr
+
+
+class MeanFn(Function):
+    """sign * mean(x) (loss_hinge_gen = -mean)."""
+
+    @staticmethod
+    def forward(ctx, x, sign: float):
+        require_hip(x)
+        x = x.contiguous()
+        n = x.numel()
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        tmp = torch.empty(2, device=x.device, dtype=torch.float64)
+        call("dgmr_colsum", _p(x), _p(out), _p(tmp), n, 1, 0, _stream())
+        call("dgmr_axpby", _p(out), None, _p(out), sign / n, 0.0, 1, _stream())
+        ctx.n, ctx.sign, ctx.shape = n, sign, x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, gl):
+        g = torch.empty(ctx.shape, device=gl.device, dtype=torch.float32)
+        ones = torch.ones(ctx.shape, device=gl.device, dtype=torch.float32)
+        call("dgmr_scale_by_dev", _p(ones), _p(gl.contiguous()), ctx.sign / ctx.n, _p(g), ctx.n, _stream())
+        return g, None
+
+
+class GridCellFn(Function):
+    """GridCellLoss on the mean of K stacked predictions: || (mean_k g_k - y) * max(y+1, cap) ||_1 / T * H * W."""
+
+    @staticmethod
+    def forward(ctx, preds, targets, cap: float):
+        require_hip(preds)
+        preds, targets = preds.contiguous(), targets.contiguous()
+        k = preds.shape[0]
+        n = targets.numel()
+        mult = float(targets.size(3) * targets.size(4)) / float(targets.size(1))
+        loss = torch.empty((), device=preds.device, dtype=torch.float32)
+        acc = torch.zeros(1, device=preds.device, dtype=torch.float64)
+        dweight = torch.empty_like(targets)
+        call("dgmr_grid_cell_loss", _p(preds), k, n, _p(targets), float(cap), _p(acc), _p(loss), mult, _p(dweight), n, _stream())
+        ctx.save_for_backward(dweight)
+        ctx.k, ctx.mult = k, mult
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        (dweight,) = ctx.saved_tensors
+        n = dweight.numel()
+        g1 = torch.empty_like(dweight)
+        call("dgmr_scale_by_dev", _p(dweight), _p(gl.contiguous()), ctx.mult, _p(g1), n, _stream())
+        return g1.unsqueeze(0).expand(ctx.k, *dweight.shape), None, None
+
+
+class AxpbyFn(Function):
+    """alpha*a + beta*b on device (loss bookkeeping without torch arithmetic kernels)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha: float, beta: float):
+        require_hip(a)
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        call("dgmr_axpby", _p(a), _p(b), _p(out), alpha, beta, a.numel(), _stream())
+        ctx.ab = (alpha, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, beta = ctx.ab
+        g = g.contiguous()
+        ga, gb = torch.empty_like(g), torch.empty_like(g)
+        call("dgmr_axpby", _p(g), None, _p(ga), alpha, 0.0, g.numel(), _stream())
+        call("dgmr_axpby", _p(g), None, _p(gb), beta, 0.0, g.numel(), _stream())
+        return ga, gb, None, None
+
+
+def axpby(a, b, alpha=1.0, beta=1.0):
+    return AxpbyFn.apply(a, b, float(alpha), float(beta))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Adam (dgmr/dgmr.py:292-300)
+# ---------------------------------------------------------------------------------------------------
+def adam_update(p, g, m, v, step, lr, beta1, beta2, eps=1e-8):
+    call("dgmr_adam", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step), _stream())
