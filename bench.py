@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py — radar frames/s of the DGMR training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one `DGMR.training_step` (2 discriminator passes + 1 generator pass over `generation_steps`
+draws + both Adam updates) on one synthetic batch that is resident in HBM before the timed region.
+Workload = BASELINE.json configs[2] ("paper config: 4 in -> 18 out, 256x256, latent=768"), the configuration the
+metric "radar frames/sec (G+D step) 4->18 @256^2" is quoted on; per-GPU batch fixed (weak scaling).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DGMR_BENCH_BATCH", "4")), help="per-GPU batch")
+    ap.add_argument("--workload", default="paper", choices=["paper", "cfg2", "smoke"])
+    ap.add_argument("--fast", action="store_true", help="strict_reference_semantics=False (skip discarded work)")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "off"])
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    # name: (DGMR kwargs, H=W, T)
+    "paper": (dict(forecast_steps=18, output_shape=256, latent_channels=768, context_channels=384, generation_steps=6), 256, 18),
+    "cfg2": (dict(forecast_steps=4, output_shape=256, latent_channels=384, context_channels=192, generation_steps=6), 256, 4),
+    "smoke": (dict(forecast_steps=2, output_shape=128, latent_channels=384, context_channels=192, generation_steps=2), 128, 2),
+}
+
+
+def cpu_baseline(kw, hw, T):
+    """Oracle (CPU restatement of the reference, `kind: port`) timed on this host on a bounded sample.
+
+    Sample: at the bench's model configuration, batch 1 — one generator forward+backward and one discriminator
+    forward+backward on a (real, generated) pair.  The reference's step executes, per sample, 17 G forwards,
+    8 G backwards, 16 D sequence-forwards and 16 D sequence-backwards, i.e.
+    t_step ~= 9*t_Gf + 8*t_Gfb + 8*t_Dfb(2 seq); frames/s = (4+T)/t_step.
+    """
+    import torch
+
+    import skillful_nowcasting_amd as S
+    from oracle import dgmr_oracle as O
+
+    torch.manual_seed(0)
+    model = S.DGMR(**kw)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items() if k.startswith(("generator.", "discriminator."))}
+    del model
+    for k in O.param_keys(sd, "generator.") + O.param_keys(sd, "discriminator."):
+        sd[k].requires_grad_(True)
+    x = torch.rand(1, 4, 1, hw, hw)
+    y = torch.rand(1, T, 1, hw, hw)
+    z = O.draw_latent((8, hw // 32, hw // 32))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.generator(sd, "generator.", x, z, T, True)
+    t_gf = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pred = O.generator(sd, "generator.", x, z, T, True)
+    pred.square().mean().backward()
+    t_gfb = time.perf_counter() - t0
+    seq = torch.cat([torch.cat([x, y], 1), torch.cat([x, pred.detach()], 1)], 0)
+    t0 = time.perf_counter()
+    out = O.discriminator(sd, "discriminator.", seq, torch.randint(0, 4 + T, (8,)).tolist(), True)
+    out.sum().backward()
+    t_dfb = time.perf_counter() - t0
+    t_step = 9 * t_gf + 8 * t_gfb + 8 * t_dfb
+    return {
+        "value": (4 + T) / t_step, "unit": "radar frames/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"oracle (torch-CPU fp32 restatement of the reference), batch 1: G fwd {t_gf:.2f}s, G fwd+bwd {t_gfb:.2f}s, "
+                  f"D fwd+bwd(2 seq) {t_dfb:.2f}s; step = 9*Gf + 8*Gfb + 8*Dfb = {t_step:.1f}s (reference op counts, SURVEY §3.1)",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+
+    ge.build()
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    kw, hw, T = WORKLOADS[args.workload]
+    B = args.batch
+    torch.manual_seed(0)
+    model = S.DGMR(strict_reference_semantics=not args.fast, **kw).to(dev)
+    if world > 1:
+        model.attach_data_parallel()
+    torch.manual_seed(1000 + rank)
+    images = torch.rand(B, 4, 1, hw, hw).to(dev)
+    future = torch.rand(B, T, 1, hw, hw).to(dev)
+    batch = (images, future)
+    torch.manual_seed(2000 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        model.training_step(batch, i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.training_step(batch, args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    frames = world * B * (4 + T)
+    value = frames * args.steps / dt
+
+    roofline = None
+    if not args.no_roofline:
+        # one extra step with HIP events around every conv launch (recorded on the launch stream inside the library)
+        lib = _lib.load()
+        lib.dgmr_profile_enable(1)
+        model.training_step(batch, args.warmup + args.steps)
+        torch.cuda.synchronize()
+        lib.dgmr_profile_enable(0)
+        nv = lib.dgmr_profile_variants()
+        ms = (ctypes.c_double * nv)()
+        fl = (ctypes.c_double * nv)()
+        cnt = (ctypes.c_int64 * nv)()
+        lib.dgmr_profile_collect(ms, fl, cnt, nv)
+        rows = [dict(kernel=lib.dgmr_profile_variant_name(i).decode(), launches=int(cnt[i]), total_ms=ms[i],
+                     avg_us=(1e3 * ms[i] / cnt[i]) if cnt[i] else 0.0, tflops=(fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] > 0 else 0.0,
+                     flops_per_launch=(fl[i] / cnt[i]) if cnt[i] else 0.0) for i in range(nv)]
+        dom = max(rows, key=lambda r: r["total_ms"])
+        tot_ms = sum(r["total_ms"] for r in rows)
+        tot_fl = sum(fl[i] for i in range(nv))
+        roofline = {
+            "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": dom["kernel"],
+            "launches_per_step": dom["launches"], "avg_launch_us": dom["avg_us"], "flops_per_launch": dom["flops_per_launch"],
+            "all_conv_kernels": {"tflops": tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0, "ms_per_step": tot_ms,
+                                 "frac_of_step": tot_ms / ms_per_step},
+            "per_kernel": rows,
+        }
+
+    if rank == 0:
+        out = {
+            "metric": "radar frames/sec (G+D step) 4->18 @256^2" if args.workload == "paper" else f"radar frames/sec (G+D step) [{args.workload}]",
+            "value": value, "unit": "radar frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic torch.rand frames, random-init weights",
+            "config": {"workload": f"DGMR.training_step {args.workload}: {kw}, H=W={hw}", "per_gpu_batch": B, "global_batch": world * B,
+                       "frames_per_sample": 4 + T, "parallelism": f"dp{world}",
+                       "semantics": "fast (discarded work skipped)" if args.fast else "strict reference semantics (checkpoint recompute, "
+                                    "un-detached D pass, extra logging forward)"},
+        }
+        if roofline:
+            out["roofline"] = roofline
+        if args.cpu_baseline != "off":
+            out["cpu_baseline"] = cpu_baseline(kw, hw, T)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -229,6 +229,16 @@ int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_stride, const fl
 int dgmr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
               int step, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py's roofline leg; not part of the reference's surface).  When enabled, every conv /
+ * wgrad launch is bracketed by HIP events on its launch stream; collect() returns, per tile variant, the summed
+ * kernel time, the summed algorithmic FLOPs (2*M*K*Cout) and the launch count, then clears the records.
+ * ---------------------------------------------------------------------------------------------- */
+int dgmr_profile_enable(int on);
+int dgmr_profile_variants(void);
+const char* dgmr_profile_variant_name(int variant);
+int dgmr_profile_collect(double* total_ms, double* total_flops, int64_t* launches, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -342,3 +342,78 @@ def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
         bc2 = 1 - beta2 ** step
         denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
         p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+# --------------------------------------------------------------------------------------
+# the whole step — dgmr/dgmr.py:137-218
+# --------------------------------------------------------------------------------------
+_BUFFER_SUFFIXES = ("._u", "._v", "running_mean", "running_var", "num_batches_tracked")
+
+
+def param_keys(sd: SD, prefix: str) -> List[str]:
+    return [k for k in sd if k.startswith(prefix) and not k.endswith(_BUFFER_SUFFIXES)]
+
+
+def training_step(sd: SD, images: torch.Tensor, future: torch.Tensor, hp: dict, opt: dict):
+    """One `DGMR.training_step` on the state dict `sd` (keys under ``generator.`` and ``discriminator.``).
+
+    Restates dgmr/dgmr.py:137-218 literally, including activation checkpointing of the generator
+    (:150,176), the un-detached predictions in the D pass (Q6), the extra forward at :213 (Q8) and the
+    CPU-RNG draws (latent z: common.py:481-483; frame indices: discriminators.py:199).
+    `hp`: forecast_steps, generation_steps, grid_lambda, gen_lr, disc_lr, beta1, beta2, precip_weight_cap,
+    latent_shape, num_spatial_frames.  `opt`: {"step": {key: int}, "m": {key: t}, "v": {key: t}} (Adam state).
+    Returns (d_loss, g_loss, grid_loss) as floats; `sd` and `opt` are updated in place.
+    """
+    from torch.utils.checkpoint import checkpoint
+
+    gp, dp = param_keys(sd, "generator."), param_keys(sd, "discriminator.")
+    for k in gp + dp:
+        sd[k].requires_grad_(True)
+    T = hp["forecast_steps"]
+
+    def gen(x):
+        z = draw_latent(hp["latent_shape"])
+        return generator(sd, "generator.", x, z, T, True)
+
+    def disc(x):
+        idxs = torch.randint(low=0, high=x.size(1), size=(hp.get("num_spatial_frames", 8),))
+        return discriminator(sd, "discriminator.", x, idxs.tolist(), True)
+
+    def adam(keys, lr):
+        for k in keys:
+            p = sd[k]
+            if p.grad is None:
+                continue
+            if k not in opt["m"]:
+                opt["m"][k] = torch.zeros_like(p)
+                opt["v"][k] = torch.zeros_like(p)
+                opt["step"][k] = 0
+            opt["step"][k] += 1
+            adam_step(p, p.grad, opt["m"][k], opt["v"][k], opt["step"][k], lr, hp["beta1"], hp["beta2"])
+
+    real_sequence = torch.cat([images, future], dim=1)
+    b = images.shape[0]
+    for _ in range(2):
+        for k in dp:
+            sd[k].grad = None
+        predictions = checkpoint(gen, images, use_reentrant=False)
+        generated_sequence = torch.cat([images, predictions], dim=1)
+        out = disc(torch.cat([real_sequence, generated_sequence], dim=0))
+        s_real, s_gen = out[:b], out[b:]
+        d_loss = loss_hinge_disc(s_gen[:, 0:1], s_real[:, 0:1]) + loss_hinge_disc(s_gen[:, 1:2], s_real[:, 1:2])
+        d_loss.backward()
+        adam(dp, hp["disc_lr"])
+    predictions = [checkpoint(gen, images, use_reentrant=False) for _ in range(hp["generation_steps"])]
+    gen_mean = torch.stack(predictions, dim=0).mean(dim=0)
+    grid = grid_cell_loss(gen_mean, future, hp["precip_weight_cap"])
+    scores = []
+    for p_ in predictions:
+        out = disc(torch.cat([real_sequence, torch.cat([images, p_], dim=1)], dim=0))
+        scores.append(out[b:])
+    g_loss = loss_hinge_gen(torch.cat(scores, dim=0)) + hp["grid_lambda"] * grid
+    for k in gp:
+        sd[k].grad = None
+    g_loss.backward()
+    adam(gp, hp["gen_lr"])
+    gen(images)  # the logging forward (dgmr.py:213): advances u/v, BN statistics and the CPU RNG
+    return float(d_loss.detach()), float(g_loss.detach()), float(grid.detach())

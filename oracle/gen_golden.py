@@ -111,10 +111,10 @@ def main():
     torch.manual_seed(11)
     record("lblock_8_12", LBlock(8, 12), [torch.randn(1, 8, 4, 4)], lambda m, x: m(x))
     torch.manual_seed(12)
-    att = AttentionLayer(16, 16)
+    att = AttentionLayer(32, 32)
     with torch.no_grad():
         att.gamma.fill_(0.7)
-    record("attention_16", att, [torch.randn(2, 16, 4, 6)], lambda m, x: m(x))
+    record("attention_32", att, [torch.randn(2, 32, 4, 6)], lambda m, x: m(x))
     # ---- ConvGRU (dgmr/layers/ConvGRU.py) ----
     torch.manual_seed(13)
     record("convgru_8_4_T3", ConvGRU(8 + 4, 4, 3),
@@ -124,7 +124,7 @@ def main():
     record("context_128", ContextConditioningStack(1, 128), [torch.rand(2, 4, 1, 32, 32)], lambda m, x: m(x),
            grad_params=False)
     torch.manual_seed(15)
-    lat = LatentConditioningStack((8, 2, 2), 288)
+    lat = LatentConditioningStack((8, 2, 2), 256)
     with torch.no_grad():
         lat.att_block.gamma.fill_(0.5)
     torch.manual_seed(150)
@@ -135,7 +135,7 @@ def main():
         torch.manual_seed(150)  # the reference draws z itself (common.py:481-483); same seed -> same z
         return m(torch.zeros(1))
 
-    record("latent_288", lat, [z], lat_call, grad_params=False)
+    record("latent_256", lat, [z], lat_call, grad_params=False)
     # ---- Sampler (dgmr/generators.py:20-182) ----
     torch.manual_seed(16)
     smp = Sampler(forecast_steps=2, latent_channels=64, context_channels=32)
@@ -157,6 +157,95 @@ def main():
     torch.manual_seed(18)
     td = TemporalDiscriminator(input_channels=1, num_layers=1)
     record("temporal_disc_L1", td, [torch.rand(2, 8, 1, 32, 32)], lambda m, x: m(x), grad_params=False)
+    training_step_golden()
+
+
+TS_KW = dict(forecast_steps=2, input_channels=1, output_shape=128, latent_channels=384, context_channels=192, generation_steps=2)
+
+
+GRAD_KEYS = ["generator.sampler.conv_1x1.bias", "generator.sampler.bn.weight",
+             "generator.sampler.conv_1x1.parametrizations.weight.original",
+             "generator.sampler.up_g4.first_conv_3x3.parametrizations.weight.original",
+             "generator.sampler.convGRU4.cell.output_conv.parametrizations.weight.original",
+             "generator.sampler.gru_conv_1x1_3.parametrizations.weight.original",
+             "generator.latent_stack.conv_3x3.parametrizations.weight.original",
+             "generator.latent_stack.l_block1.first_conv_3x3.weight",
+             "generator.latent_stack.att_block.gamma",
+             "generator.conditioning_stack.d1.first_conv_3x3.parametrizations.weight.original",
+             "generator.conditioning_stack.conv1.parametrizations.weight.original",
+             "discriminator.spatial_discriminator.fc.parametrizations.weight.original",
+             "discriminator.spatial_discriminator.bn.weight",
+             "discriminator.spatial_discriminator.d1.first_conv_3x3.parametrizations.weight.original",
+             "discriminator.spatial_discriminator.intermediate_dblocks.0.conv_1x1.parametrizations.weight.original",
+             "discriminator.temporal_discriminator.d1.first_conv_3x3.parametrizations.weight.original",
+             "discriminator.temporal_discriminator.d2.last_conv_3x3.bias",
+             "discriminator.temporal_discriminator.fc.bias"]
+
+
+def checksums(sd):
+    """Per-tensor (sum, abs-sum, first, last) in float64: compact fingerprint of a ~100 M-parameter state."""
+    keys = sorted(sd.keys())
+    vals = torch.zeros(len(keys), 4, dtype=torch.float64)
+    for i, k in enumerate(keys):
+        t = sd[k].detach().double().flatten()
+        vals[i, 0], vals[i, 1], vals[i, 2], vals[i, 3] = t.sum(), t.abs().sum(), t[0], t[-1]
+    return keys, vals
+
+
+def training_step_golden():
+    """One full `DGMR.training_step` of the unmodified reference on a seeded model (dgmr/dgmr.py:137-218)."""
+    from dgmr import DGMR
+
+    torch.manual_seed(42)
+    model = DGMR(**TS_KW)
+    keys0, cs0 = checksums(model.state_dict())
+    torch.manual_seed(43)
+    images, future = torch.rand(2, 4, 1, 128, 128), torch.rand(2, 2, 1, 128, 128)
+    logged = {}
+    model.log_dict = lambda d, **k: logged.update({kk: float(v) for kk, v in d.items()})
+    bw = []
+    model.manual_backward = lambda loss: (bw.append(float(loss.detach())), loss.backward())
+    # snapshot the gradients the optimisers see: D at its first step (the second D pass has zero hinge loss), G at its step
+    grads = {}
+    g_opt, d_opt = model.optimizers()
+    named = dict(model.named_parameters())
+
+    def wrap(opt, prefix, once):
+        orig = opt.step
+
+        def step(*a, **k):
+            if not (once and any(kk.startswith("grad." + prefix) for kk in grads)):
+                for kk in GRAD_KEYS:
+                    if kk.startswith(prefix):
+                        p = named[kk[len("generator."):]] if kk.startswith("generator.") else named[kk]
+                        grads["grad." + kk] = p.grad.detach().clone().contiguous()
+            return orig(*a, **k)
+
+        opt.step = step
+
+    wrap(g_opt, "generator.", False)
+    wrap(d_opt, "discriminator.", True)
+    torch.manual_seed(44)
+    model.training_step((images, future), 0)
+    sd1 = model.state_dict()
+    keys1, cs1 = checksums(sd1)
+    assert keys0 == keys1
+    rec = {"images": images, "future": future, "cs0": cs0, "cs1": cs1,
+           "losses": torch.tensor([logged["train/d_loss"], logged["train/g_loss"], logged["train/grid_loss"]], dtype=torch.float64),
+           "backward_losses": torch.tensor(bw, dtype=torch.float64)}  # d pass 1, d pass 2, g
+    # a few whole tensors after the step (small ones + slices of big ones) for element-wise checks
+    rec.update(grads)
+    for k in ["generator.sampler.conv_1x1.bias", "generator.sampler.bn.running_mean", "generator.sampler.bn.weight",
+              "generator.latent_stack.conv_3x3.parametrizations.weight.original",
+              "generator.conditioning_stack.d1.first_conv_3x3.parametrizations.weight.original",
+              "generator.sampler.convGRU4.cell.read_gate_conv.parametrizations.weight.0._u",
+              "discriminator.spatial_discriminator.fc.parametrizations.weight.original",
+              "discriminator.temporal_discriminator.d1.first_conv_3x3.parametrizations.weight.original",
+              "discriminator.spatial_discriminator.bn.running_var"]:
+        rec["post." + k] = sd1[k].detach().clone().contiguous()
+    save_file(rec, os.path.join(OUT, "training_step.safetensors"),
+              metadata={"keys": json.dumps(keys0), "kw": json.dumps(TS_KW), "seeds": "[42, 43, 44]"})
+    print("training_step golden: losses", rec["losses"].tolist(), bw)
 
 
 if __name__ == "__main__":

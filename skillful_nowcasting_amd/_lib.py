@@ -79,6 +79,9 @@ SIGNATURES = {
     "dgmr_hinge_disc": [P, P, P, P, P, i, i, P],
     "dgmr_grid_cell_loss": [P, i, L, P, f, P, P, f, P, L, P],
     "dgmr_adam": [P, P, P, P, L, f, f, f, f, i, P],
+    "dgmr_profile_enable": [i],
+    "dgmr_profile_variants": [],
+    "dgmr_profile_collect": [P, P, P, i],
 }
 del i, f, L
 
@@ -107,6 +110,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
+    lib.dgmr_profile_variant_name.restype = c_char_p
+    lib.dgmr_profile_variant_name.argtypes = [c_int]
     _lib = lib
     return lib
 

@@ -11,6 +11,9 @@
 // staged global -> registers -> LDS (double-buffered, one barrier per K step) so the next tile's HBM
 // latency hides under the current tile's MFMAs; LDS rows are padded to BK+4 floats, which makes the
 // ds_read_b128 fragment reads (lane = row, 4 consecutive k) conflict-free.
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -191,6 +194,58 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_con
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Optional per-launch timing (bench.py's roofline leg): HIP events recorded on the launch stream around every
+// conv / wgrad kernel, grouped by tile variant.  Off by default; never used inside the timed region.
+// ------------------------------------------------------------------------------------------------
+struct ProfRec {
+    int variant;
+    double flops;
+    hipEvent_t e0, e1;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_event_pool;
+std::mutex g_prof_mu;
+
+hipEvent_t prof_event() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    bool on;
+    ProfRec r;
+    hipStream_t s;
+    ProfScope(int variant, double flops, hipStream_t st) : on(g_prof_on), s(st) {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        r.variant = variant;
+        r.flops = flops;
+        r.e0 = prof_event();
+        r.e1 = prof_event();
+        (void)hipEventRecord(r.e0, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(r);
+    }
+};
+
+enum { V_F128x128 = 0, V_F64x64, V_F128x96, V_F128x64, V_F128x32, V_W128, V_W64, V_W32, V_COUNT };
+const char* const kVariantNames[V_COUNT] = {
+    "conv_igemm_kernel<128,128,32,2,2>", "conv_igemm_kernel<64,64,32,2,2>", "conv_igemm_kernel<128,96,32,4,1>",
+    "conv_igemm_kernel<128,64,32,4,1>",  "conv_igemm_kernel<128,32,32,4,1>", "conv_wgrad_kernel<128,128,2,2>",
+    "conv_wgrad_kernel<64,128,2,2>",     "conv_wgrad_kernel<32,128,1,4>"};
 
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_conv(const dgmr_conv_args& a, int M, int Ktot, hipStream_t s) {
@@ -378,16 +433,21 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     else if (C % 96 == 0) bn = 96;
     else bn = 128;
     const int64_t wgs128 = ((M64 + 127) / 128) * ((C + bn - 1) / bn);
-    if (bn == 128) {
-        if (wgs128 >= 256) launch_conv<128, 128, 32, 2, 2>(p, M, Ktot, s);
-        else launch_conv<64, 64, 32, 2, 2>(p, M, Ktot, s);
-    } else if (bn == 96) {
-        launch_conv<128, 96, 32, 4, 1>(p, M, Ktot, s);
-    } else if (bn == 64) {
-        if (wgs128 >= 256) launch_conv<128, 64, 32, 4, 1>(p, M, Ktot, s);
-        else launch_conv<64, 64, 32, 2, 2>(p, M, Ktot, s);
-    } else {
-        launch_conv<128, 32, 32, 4, 1>(p, M, Ktot, s);
+    const double flops = 2.0 * (double)M64 * (double)Ktot * (double)C;  // algorithmic: 2*MACs of the dense conv
+    int variant;
+    if (bn == 128) variant = wgs128 >= 256 ? V_F128x128 : V_F64x64;
+    else if (bn == 96) variant = V_F128x96;
+    else if (bn == 64) variant = wgs128 >= 256 ? V_F128x64 : V_F64x64;
+    else variant = V_F128x32;
+    {
+        ProfScope ps(variant, flops, s);
+        switch (variant) {
+            case V_F128x128: launch_conv<128, 128, 32, 2, 2>(p, M, Ktot, s); break;
+            case V_F64x64: launch_conv<64, 64, 32, 2, 2>(p, M, Ktot, s); break;
+            case V_F128x96: launch_conv<128, 96, 32, 4, 1>(p, M, Ktot, s); break;
+            case V_F128x64: launch_conv<128, 64, 32, 4, 1>(p, M, Ktot, s); break;
+            default: launch_conv<128, 32, 32, 4, 1>(p, M, Ktot, s); break;
+        }
     }
     DGMR_CHECK_LAUNCH();
     return 0;
@@ -428,6 +488,7 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
     rows = (rows + 31) / 32 * 32;
     hipStream_t s = (hipStream_t)stream;
     const int kt = (Ktot + 127) / 128;
+    ProfScope ps(a->Cout <= 32 ? V_W32 : (a->Cout <= 64 ? V_W64 : V_W128), 2.0 * (double)M64 * (double)Ktot * (double)a->Cout, s);
     if (a->Cout <= 32) {
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), dim3(kt, (a->Cout + 31) / 32, a->nsplit), dim3(256), 0, s, p, M,
                            Ktot, rows);
@@ -462,5 +523,37 @@ extern "C" int dgmr_sn_wgrad_finalize(const float* g, float* gw, float* dot, con
                        accumulate);
     hipLaunchKernelGGL(zero1_kernel, dim3(1), dim3(1), 0, s, dot);
     DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return 0;
+}
+
+extern "C" int dgmr_profile_variants(void) { return V_COUNT; }
+extern "C" const char* dgmr_profile_variant_name(int v) { return (v >= 0 && v < V_COUNT) ? kVariantNames[v] : ""; }
+
+// Synchronises the events recorded so far and returns per-variant totals; clears the records.
+extern "C" int dgmr_profile_collect(double* total_ms, double* total_flops, int64_t* launches, int n) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < n; ++i) {
+        total_ms[i] = 0.0;
+        total_flops[i] = 0.0;
+        launches[i] = 0;
+    }
+    for (auto& r : g_prof) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && r.variant < n) {
+            total_ms[r.variant] += ms;
+            total_flops[r.variant] += r.flops;
+            launches[r.variant] += 1;
+        }
+        g_event_pool.push_back(r.e0);
+        g_event_pool.push_back(r.e1);
+    }
+    g_prof.clear();
     return 0;
 }

@@ -90,6 +90,7 @@ class DGMR(
         self.discriminator = Discriminator(input_channels)
         self.save_hyperparameters()
         self.global_iteration = 0
+        self.grad_sync = None  # ddp.GradSync when running data-parallel (attach_data_parallel)
         # Important: This property activates manual optimization.
         self.automatic_optimization = False
         # NB the reference also flips torch.autograd.set_detect_anomaly(True) globally here (dgmr.py:130); that is a
@@ -137,6 +138,8 @@ class DGMR(
         self.global_iteration += 1
         g_opt, d_opt = self.optimizers()
         strict = self.strict_reference_semantics
+        if self.grad_sync is not None:
+            self.grad_sync.broadcast_buffers()
         ##########################
         # Optimize Discriminator #
         ##########################
@@ -149,6 +152,8 @@ class DGMR(
                     predictions = self.forward(images)
             discriminator_loss = self._disc_losses(images, future_images, predictions)
             self.manual_backward(discriminator_loss)
+            if self.grad_sync is not None:
+                self.grad_sync.sync("d")
             d_opt.step()
         ######################
         # Optimize Generator #
@@ -160,6 +165,8 @@ class DGMR(
         generator_loss, grid_cell_reg = self._gen_losses(images, future_images, predictions)
         g_opt.zero_grad()
         self.manual_backward(generator_loss)
+        if self.grad_sync is not None:
+            self.grad_sync.sync("g")
         g_opt.step()
         if not strict:
             for p in self.discriminator.parameters():
@@ -186,6 +193,18 @@ class DGMR(
         generated_images = self(images)
         if self.visualize:
             self.visualize_step(images, future_images, generated_images, self.global_iteration, step="val")
+
+    def attach_data_parallel(self, process_group=None, chunk_mb: int = 64):
+        """One-process-per-GPU data parallelism: flat gradient buffers + RCCL all-reduce after each backward."""
+        from .ddp import GradSync
+
+        self.grad_sync = GradSync(self, process_group, chunk_mb)
+        g_opt, d_opt = self.optimizers()
+        g_opt.flat_grads = self.grad_sync.gen
+        d_opt.flat_grads = self.grad_sync.disc
+        self.grad_sync.broadcast_parameters()
+        self.grad_sync.broadcast_buffers()
+        return self.grad_sync
 
     def configure_optimizers(self):
         """Two Adam optimisers, lr 5e-5 / 2e-4, betas (0.0, 0.999) by default (dgmr/dgmr.py:292-300)."""

@@ -14,6 +14,14 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
+    flat_grads = None  # set by ddp.GradSync users: gradients then live in one flat buffer that is zeroed, not dropped
+
+    def zero_grad(self, set_to_none: bool = True):
+        if self.flat_grads is not None:
+            self.flat_grads.zero_()
+            return
+        super().zero_grad(set_to_none=set_to_none)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

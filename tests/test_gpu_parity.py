@@ -89,7 +89,7 @@ def test_lblock():
 def test_attention():
     from skillful_nowcasting_amd.layers import AttentionLayer
 
-    _run_golden("attention_16", lambda: AttentionLayer(16, 16), lambda m, x: m(x))
+    _run_golden("attention_32", lambda: AttentionLayer(32, 32), lambda m, x: m(x))
 
 
 def test_convgru():
@@ -107,7 +107,7 @@ def test_context_stack():
 def test_latent_stack():
     from skillful_nowcasting_amd import LatentConditioningStack
 
-    _run_golden("latent_288", lambda: LatentConditioningStack((8, 2, 2), 288), lambda m, z: m.forward_latent(z), tol=1e-4)
+    _run_golden("latent_256", lambda: LatentConditioningStack((8, 2, 2), 256), lambda m, z: m.forward_latent(z), tol=1e-4)
 
 
 def test_sampler():

@@ -71,7 +71,7 @@ def test_lblock():
 
 
 def test_attention():
-    _run("attention_16", lambda sd, x, tr: O.attention(sd, "", x[0]))
+    _run("attention_32", lambda sd, x, tr: O.attention(sd, "", x[0]))
 
 
 def test_convgru():
@@ -83,7 +83,7 @@ def test_context_stack():
 
 
 def test_latent_stack():
-    _run("latent_288", lambda sd, x, tr: O.latent_stack(sd, "", x[0], tr))
+    _run("latent_256", lambda sd, x, tr: O.latent_stack(sd, "", x[0], tr))
 
 
 def test_sampler():
