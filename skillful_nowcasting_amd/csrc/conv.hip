@@ -33,36 +33,58 @@ __device__ __forceinline__ RowCoord decode_row(int m, int D, int H, int W) {
     return r;
 }
 
-// Gather 4 consecutive input channels of the im2col row (pixel rc, flattened k), with the fused prologue.
-__device__ __forceinline__ f32x4 gather_a(const float* __restrict__ x, const float* __restrict__ pre_a,
-                                          const float* __restrict__ pre_b, const RowCoord& rc, bool row_ok, int k,
-                                          int Ktot, int D, int H, int W, int Cin, int KH, int KW, int KHW, int pd,
-                                          int ph, int pw, int upsample, int pre_relu, int pre_group) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (!row_ok || k >= Ktot) return v;
+// Decoded position of a thread's 4-channel group inside the flattened K axis.
+struct KPos {
+    int ci, dz, dy, dx;  // channel, tap offsets relative to the output pixel (already minus padding)
+    bool ok;
+};
+
+__device__ __forceinline__ KPos decode_k(int k, int Ktot, int Cin, int KW, int KHW, int pd, int ph, int pw) {
+    KPos p;
+    p.ok = k < Ktot;
     const int tap = k / Cin;
-    const int ci = k - tap * Cin;
+    p.ci = k - tap * Cin;
     const int kz = tap / KHW;
     const int r2 = tap - kz * KHW;
     const int ky = r2 / KW;
-    const int kx = r2 - ky * KW;
-    int id = rc.d + kz - pd, ih = rc.h + ky - ph, iw = rc.w + kx - pw;
-    if ((unsigned)id >= (unsigned)D || (unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) return v;
-    int Hin = H, Win = W;
-    if (upsample) {
-        ih >>= 1;
-        iw >>= 1;
-        Hin >>= 1;
-        Win >>= 1;
+    p.dz = kz - pd;
+    p.dy = ky - ph;
+    p.dx = r2 - ky * KW - pw;
+    return p;
+}
+
+// Issue the 16-byte load of 4 consecutive input channels of im2col element (pixel rc, position kp).  The value is
+// returned RAW (no relu / affine): the fused prologue is applied later, at LDS-store time (finish_a), so that the
+// load stays in flight under the MFMAs of the current tile instead of being waited for right here.
+__device__ __forceinline__ f32x4 issue_a(const float* __restrict__ x, const RowCoord& rc, bool row_ok, const KPos& kp, int D,
+                                         int H, int W, int Cin, int upsample, bool& valid) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    int id = rc.d + kp.dz, ih = rc.h + kp.dy, iw = rc.w + kp.dx;
+    valid = row_ok && kp.ok && (unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    if (valid) {
+        int Hin = H, Win = W;
+        if (upsample) {
+            ih >>= 1;
+            iw >>= 1;
+            Hin >>= 1;
+            Win >>= 1;
+        }
+        const size_t off = ((((size_t)rc.n * D + id) * Hin + ih) * Win + iw) * (size_t)Cin + kp.ci;
+        v = *reinterpret_cast<const f32x4*>(x + off);
     }
-    const size_t off = ((((size_t)rc.n * D + id) * Hin + ih) * Win + iw) * (size_t)Cin + ci;
-    v = *reinterpret_cast<const f32x4*>(x + off);
+    return v;
+}
+
+__device__ __forceinline__ f32x4 finish_a(f32x4 v, bool valid, const float* __restrict__ pre_a, const float* __restrict__ pre_b,
+                                          int n, int ci, int Cin, int pre_relu, int pre_group) {
     if (pre_a) {
-        const size_t g = (size_t)(rc.n / pre_group) * Cin + ci;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(pre_a + g);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(pre_b + g);
+        if (valid) {
+            const size_t g = (size_t)(n / pre_group) * Cin + ci;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(pre_a + g);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(pre_b + g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.f);
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.f);
+        }
     } else if (pre_relu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -103,12 +125,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_con
     }
 
     f32x4 ra[AP], rb[BP];
+    bool va[AP];
+    int cur_ci = 0;
     auto load_tiles = [&](int kt) {
         const int k = kt * BK + kq * 4;
+        const KPos kp = decode_k(k, Ktot, p.Cin, p.KW, KHW, pd, ph, pw);
+        cur_ci = kp.ci;
 #pragma unroll
-        for (int i = 0; i < AP; ++i)
-            ra[i] = gather_a(p.x, p.pre_a, p.pre_b, rc[i], rok[i], k, Ktot, p.D, p.H, p.W, p.Cin, p.KH, p.KW, KHW, pd, ph,
-                             pw, p.upsample, p.pre_relu, p.pre_group);
+        for (int i = 0; i < AP; ++i) ra[i] = issue_a(p.x, rc[i], rok[i], kp, p.D, p.H, p.W, p.Cin, p.upsample, va[i]);
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             const int co = n0 + i * RPP + lrow;
@@ -119,7 +143,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_con
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf * BM * LD + (i * RPP + lrow) * LD + kq * 4]) = ra[i];
+        for (int i = 0; i < AP; ++i)
+            *reinterpret_cast<f32x4*>(&As[buf * BM * LD + (i * RPP + lrow) * LD + kq * 4]) =
+                finish_a(ra[i], va[i], p.pre_a, p.pre_b, rc[i].n, cur_ci, p.Cin, p.pre_relu, p.pre_group);
 #pragma unroll
         for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * BN * LD + (i * RPP + lrow) * LD + kq * 4]) = rb[i];
     };
@@ -283,11 +309,19 @@ __global__ __launch_bounds__(64 * WI * WJ) void conv_wgrad_kernel(const dgmr_wgr
     const int KHW = p.KH * p.KW;
     const int pd = p.KD >> 1, ph = p.KH >> 1, pw = p.KW >> 1;
 
+    // this thread's XP positions on the K axis never change: decode them once
+    KPos kps[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) kps[i] = decode_k(k0 + (lq + i * TPR) * 4, Ktot, p.Cin, p.KW, KHW, pd, ph, pw);
+
     f32x4 ry[YP], rx[XP];
+    bool vx[XP];
+    int cur_n = 0;
     auto load_tiles = [&](int r0) {
         const int m = r0 + lr;
         const bool ok = m < r_end;
         const RowCoord rc = decode_row(ok ? m : 0, p.D, p.H, p.W);
+        cur_n = rc.n;
 #pragma unroll
         for (int i = 0; i < YP; ++i) {
             const int co = co0 + (lq + i * TPR) * 4;
@@ -296,17 +330,15 @@ __global__ __launch_bounds__(64 * WI * WJ) void conv_wgrad_kernel(const dgmr_wgr
             ry[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < XP; ++i) {
-            const int k = k0 + (lq + i * TPR) * 4;
-            rx[i] = gather_a(p.x, p.pre_a, p.pre_b, rc, ok, k, Ktot, p.D, p.H, p.W, p.Cin, p.KH, p.KW, KHW, pd, ph, pw,
-                             p.upsample, p.pre_relu, p.pre_group);
-        }
+        for (int i = 0; i < XP; ++i) rx[i] = issue_a(p.x, rc, ok, kps[i], p.D, p.H, p.W, p.Cin, p.upsample, vx[i]);
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < YP; ++i) *reinterpret_cast<f32x4*>(&Ys[buf * BR * LDY + lr * LDY + (lq + i * TPR) * 4]) = ry[i];
 #pragma unroll
-        for (int i = 0; i < XP; ++i) *reinterpret_cast<f32x4*>(&Xs[buf * BR * LDX + lr * LDX + (lq + i * TPR) * 4]) = rx[i];
+        for (int i = 0; i < XP; ++i)
+            *reinterpret_cast<f32x4*>(&Xs[buf * BR * LDX + lr * LDX + (lq + i * TPR) * 4]) =
+                finish_a(rx[i], vx[i], p.pre_a, p.pre_b, cur_n, kps[i].ci, p.Cin, p.pre_relu, p.pre_group);
     };
 
     f32x16 acc[TM][TN];

@@ -1,0 +1,100 @@
+"""Micro-benchmark of the conv kernels through the C ABI (GPU only).  python tools/conv_bench.py [--bwd]"""
+import ctypes
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from skillful_nowcasting_amd import ops
+from skillful_nowcasting_amd._lib import WgradArgs, call, load
+
+SHAPES = [
+    # name, N, D, H, W (output), Cin, Cout, k(d,h,w), upsample, bn
+    ("up_g4.first t1", 16, 1, 128, 128, 96, 96, (1, 3, 3), True, True),
+    ("up_g4.first T18", 288, 1, 128, 128, 96, 96, (1, 3, 3), True, True),
+    ("up_g4.last T18", 288, 1, 128, 128, 96, 48, (1, 3, 3), False, True),
+    ("up_g3.first t1", 16, 1, 64, 64, 192, 192, (1, 3, 3), True, True),
+    ("up_g2.first t1", 16, 1, 32, 32, 384, 384, (1, 3, 3), True, True),
+    ("up_g2.first T18", 288, 1, 32, 32, 384, 384, (1, 3, 3), True, True),
+    ("g1.first t1", 16, 1, 8, 8, 768, 768, (1, 3, 3), False, True),
+    ("g1.first T18", 288, 1, 8, 8, 768, 768, (1, 3, 3), False, True),
+    ("gru1.gate", 16, 1, 8, 8, 1152, 384, (1, 3, 3), False, False),
+    ("gru1.h-only", 16, 1, 8, 8, 384, 384, (1, 3, 3), False, False),
+    ("gru4.gate", 16, 1, 64, 64, 144, 48, (1, 3, 3), False, False),
+    ("gru_1x1_4 T18", 288, 1, 64, 64, 48, 96, (1, 1, 1), False, False),
+    ("tempD.d1.last 3d", 32, 22, 64, 64, 48, 48, (3, 3, 3), False, False),
+    ("tempD.d1.first 3d", 32, 22, 64, 64, 4, 48, (3, 3, 3), False, False),
+    ("spatD.d2.first f8", 256, 1, 32, 32, 48, 96, (1, 3, 3), False, False),
+    ("spatD.d5 f8", 256, 1, 4, 4, 384, 768, (1, 3, 3), False, False),
+]
+
+
+def bench(fn, iters=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    load()
+    dev = "cuda"
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    for name, n, d, h, w, cin, cout, ks, up, bn in SHAPES:
+        if only and not any(o in name for o in only):
+            continue
+        kd, kh, kw = ks
+        hin, win = (h // 2, w // 2) if up else (h, w)
+        x = torch.randn(n * d * hin * win * cin, device=dev)
+        wt = torch.randn(cout * kd * kh * kw * cin, device=dev) * 0.05
+        y = torch.empty(n * d * h * w * cout, device=dev)
+        bias = torch.randn(cout, device=dev)
+        scale = torch.full((1,), 0.5, device=dev)
+        a = torch.rand(cin, device=dev) + 0.5
+        b = torch.randn(cin, device=dev) * 0.1
+        flops = 2.0 * n * d * h * w * cout * cin * kd * kh * kw
+
+        def fwd():
+            ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, d, h, w, cin, cout, kd, kh, kw, upsample=up,
+                             pre_a=a if bn else None, pre_b=b if bn else None, pre_group=n)
+
+        ms = bench(fwd)
+        line = f"{name:22s} M={n*d*h*w:8d} K={cin*kd*kh*kw:6d} N={cout:4d}  fwd {ms*1e3:9.1f} us {flops/ms/1e9:7.1f} TF"
+        if "--bwd" in sys.argv:
+            m = n * d * h * w
+            k = cin * kd * kh * kw
+            ns = ops.call_nsplit(m, cout, k)
+            partial = torch.empty(ns * cout * k, device=dev)
+            wa = WgradArgs()
+            wa.x, wa.dy, wa.partial = x.data_ptr(), y.data_ptr(), partial.data_ptr()
+            wa.pre_a, wa.pre_b = (a.data_ptr(), b.data_ptr()) if bn else (None, None)
+            wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, d, h, w, cin, cout
+            wa.KD, wa.KH, wa.KW = kd, kh, kw
+            wa.upsample, wa.pre_relu, wa.pre_group, wa.nsplit = int(up), 0, n, ns
+
+            def wg():
+                call("dgmr_conv_wgrad", ctypes.byref(wa), ops._stream())
+
+            ms2 = bench(wg)
+            line += f" | wgrad ns={ns:4d} {ms2*1e3:9.1f} us {flops/ms2/1e9:7.1f} TF"
+            if not up:
+                dx = torch.empty_like(x)
+                wflip = torch.empty_like(wt)
+
+                def dg():
+                    ops._launch_conv(y, wflip.data_ptr(), None, scale, dx, n, d, h, w, cout, cin, kd, kh, kw, mask_src=x,
+                                     mask_a=a if bn else None, mask_b=b if bn else None, mask_group=n)
+
+                ms3 = bench(dg)
+                line += f" | dgrad {ms3*1e3:9.1f} us {flops/ms3/1e9:7.1f} TF"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
