@@ -228,18 +228,24 @@ class ConvFn(Function):
         _launch_conv(x, _p(w), bias, scale, y, n, d, h, wd, cin, cout, kd, kh, kw, upsample=spec.upsample,
                      pre_relu=spec.pre_relu, pre_a=bn.a if bn else None, pre_b=bn.b if bn else None,
                      pre_group=bn.group_size if bn else 1, residual=residual, act_relu=spec.act_relu)
-        ctx.spec = spec
+        ctx.spec = spec  # flags only are read from it in backward; its tensors are re-read from saved_tensors
         ctx.has_residual = residual is not None
-        ctx.params = (w, bias)
-        ctx.save_for_backward(x, scale, y if spec.act_relu else None)
+        # parameters are kept as-is (checkpointing hands back DETACHED copies of saved tensors: .grad must land on the real ones)
+        ctx.params = (w, bias, scale if spec.gamma_scale else None)
+        sn = spec.sn
+        # Every tensor the backward reads goes through save_for_backward: under activation checkpointing
+        # (dgmr/dgmr.py:150,176) the saved tensors are replaced by those of the RECOMPUTED forward, whose sigma / u / v
+        # and BatchNorm statistics differ from the first forward's; a tensor stashed on ctx would not be.
+        ctx.save_for_backward(x, scale, y if spec.act_relu else None, sn.u if sn else None, sn.v if sn else None,
+                              bn.a if bn else None, bn.b if bn else None, bn.mean if bn else None, bn.rstd if bn else None)
         ctx.geom = (n, cin, cout, d, h, wd, kd, kh, kw)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         spec: ConvSpec = ctx.spec
-        x, scale, y_act = ctx.saved_tensors
-        w, bias = ctx.params
+        x, scale, y_act, sn_u, sn_v, bn_a, bn_b, bn_mean, bn_rstd = ctx.saved_tensors
+        w, bias, scale_param = ctx.params
         n, cin, cout, d, h, wd, kd, kh, kw = ctx.geom
         dy = to_cl(dy)
         dev = dy.device
@@ -262,7 +268,7 @@ class ConvFn(Function):
             partial = torch.empty(ns * cout * k, device=dev, dtype=torch.float32)
             wa = WgradArgs()
             wa.x, wa.dy, wa.partial = _p(x), _p(dy), _p(partial)
-            wa.pre_a, wa.pre_b = (_p(bn.a), _p(bn.b)) if bn else (None, None)
+            wa.pre_a, wa.pre_b = (_p(bn_a), _p(bn_b)) if bn else (None, None)
             wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, d, h, wd, cin, cout
             wa.KD, wa.KH, wa.KW = kd, kh, kw
             wa.upsample, wa.pre_relu, wa.pre_group, wa.nsplit = int(spec.upsample), int(spec.pre_relu), (bn.group_size if bn else 1), ns
@@ -277,11 +283,11 @@ class ConvFn(Function):
                 dot = torch.zeros(1, device=dev, dtype=torch.float32)
                 call("dgmr_wgrad_reduce", _p(partial), ns, cout * k, _p(w), _p(g), _p(dot), st)
                 if spec.sn is not None:
-                    call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), _p(spec.sn.u), _p(spec.sn.v), cout, cin,
+                    call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), _p(sn_u), _p(sn_v), cout, cin,
                          kd * kh * kw, 1, st)
                 else:  # learnable scalar gain: d scale = <G, W>, dW = scale * G
-                    if spec.gamma_scale and scale.requires_grad:
-                        gs = grad_buffer(scale)
+                    if scale_param is not None and scale_param.requires_grad:
+                        gs = grad_buffer(scale_param)
                         call("dgmr_axpby", _p(gs), _p(dot), _p(gs), 1.0, 1.0, 1, st)
                     call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), None, None, cout, cin, kd * kh * kw, 1, st)
         # ---- input ----
@@ -293,23 +299,23 @@ class ConvFn(Function):
                 _launch_conv(dy, _p(wt), None, scale, hi, n, d, h, wd, cout, cin, kd, kh, kw)
                 g = empty_cl(x.shape, dy)
                 call("dgmr_pool_fwd", _p(hi), None, _p(g), n, d, h, wd, cin, 1, 1.0, _p(x) if (bn or spec.pre_relu) else None,
-                     _p(bn.a) if bn else None, _p(bn.b) if bn else None, bn.group_size if bn else 1, st)
+                     _p(bn_a) if bn else None, _p(bn_b) if bn else None, bn.group_size if bn else 1, st)
             else:
                 g = empty_cl(x.shape, dy)
                 _launch_conv(dy, _p(wt), None, scale, g, n, d, h, wd, cout, cin, kd, kh, kw,
-                             mask_src=x if (bn or spec.pre_relu) else None, mask_a=bn.a if bn else None,
-                             mask_b=bn.b if bn else None, mask_group=bn.group_size if bn else 1)
+                             mask_src=x if (bn or spec.pre_relu) else None, mask_a=bn_a if bn else None,
+                             mask_b=bn_b if bn else None, mask_group=bn.group_size if bn else 1)
             if bn is None:
                 dx = g
             else:
                 c = cin
                 r = x.numel() // (c * bn.groups)
                 sums = torch.zeros(bn.groups * 2 * c, device=dev, dtype=torch.float64)
-                call("dgmr_bn_bwd_reduce", _p(g), _p(x), _p(bn.mean), _p(bn.rstd), _p(sums), bn.groups, r, c, st)
+                call("dgmr_bn_bwd_reduce", _p(g), _p(x), _p(bn_mean), _p(bn_rstd), _p(sums), bn.groups, r, c, st)
                 dx = empty_cl(x.shape, dy)
                 dgam = grad_buffer(bn.gamma) if (bn.gamma is not None and bn.gamma.requires_grad) else None
                 dbet = grad_buffer(bn.beta) if (bn.beta is not None and bn.beta.requires_grad) else None
-                call("dgmr_bn_bwd_apply", _p(g), _p(x), _p(bn.mean), _p(bn.rstd), _p(bn.gamma), _p(sums), None, _p(dx), _p(dgam),
+                call("dgmr_bn_bwd_apply", _p(g), _p(x), _p(bn_mean), _p(bn_rstd), _p(bn.gamma), _p(sums), None, _p(dx), _p(dgam),
                      _p(dbet), bn.groups, r, c, int(bn.train), st)
         d_res = dy if ctx.has_residual else None
         return dx, None, None, None, d_res, None, None, None
@@ -627,21 +633,21 @@ class BatchNorm1dFn(Function):
         y = torch.empty_like(x)
         call("dgmr_affine", _p(x), _p(st.a), _p(st.b), _p(y), 1, n, c, 0, _stream())
         ctx.st = st
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, st.mean, st.rstd)  # see ConvFn.forward: nothing tensor-valued may be read from ctx.st
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x, mean, rstd = ctx.saved_tensors
         st: BNState = ctx.st
         n, c = x.shape
         dy = dy.contiguous()
         sums = torch.zeros(2 * c, device=x.device, dtype=torch.float64)
-        call("dgmr_bn_bwd_reduce", _p(dy), _p(x), _p(st.mean), _p(st.rstd), _p(sums), 1, n, c, _stream())
+        call("dgmr_bn_bwd_reduce", _p(dy), _p(x), _p(mean), _p(rstd), _p(sums), 1, n, c, _stream())
         dx = torch.empty_like(x)
         dgam = grad_buffer(st.gamma) if st.gamma.requires_grad else None
         dbet = grad_buffer(st.beta) if st.beta.requires_grad else None
-        call("dgmr_bn_bwd_apply", _p(dy), _p(x), _p(st.mean), _p(st.rstd), _p(st.gamma), _p(sums), None, _p(dx), _p(dgam), _p(dbet),
+        call("dgmr_bn_bwd_apply", _p(dy), _p(x), _p(mean), _p(rstd), _p(st.gamma), _p(sums), None, _p(dx), _p(dgam), _p(dbet),
              1, n, c, int(st.train), _stream())
         return dx, None, None, None, None, None, None, None, None
 
@@ -656,16 +662,14 @@ class SNLinear1Fn(Function):
         n, c = x.shape
         y = torch.empty(n, 1, device=x.device, dtype=torch.float32)
         call("dgmr_linear1_fwd", _p(x), _p(w), _p(bias), _p(sn.inv_sigma), _p(y), n, c, _stream())
-        ctx.sn = sn
         ctx.params = (w, bias)
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, sn.inv_sigma, sn.u, sn.v)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x, inv_sigma, sn_u, sn_v = ctx.saved_tensors
         w, bias = ctx.params
-        sn: SNCall = ctx.sn
         n, c = x.shape
         dy = dy.contiguous()
         dev = x.device
@@ -673,7 +677,7 @@ class SNLinear1Fn(Function):
         g = torch.empty(c, device=dev, dtype=torch.float32)
         gb = torch.empty(1, device=dev, dtype=torch.float32)
         st = _stream()
-        call("dgmr_linear1_bwd", _p(dy), _p(x), _p(w), _p(sn.inv_sigma), _p(dx), _p(g), _p(gb), n, c, st)
+        call("dgmr_linear1_bwd", _p(dy), _p(x), _p(w), _p(inv_sigma), _p(dx), _p(g), _p(gb), n, c, st)
         if bias is not None and bias.requires_grad:
             b = grad_buffer(bias)
             call("dgmr_axpby", _p(b), _p(gb), _p(b), 1.0, 1.0, 1, st)
@@ -681,7 +685,7 @@ class SNLinear1Fn(Function):
             dot = torch.zeros(1, device=dev, dtype=torch.float32)
             g2 = torch.empty_like(g)
             call("dgmr_wgrad_reduce", _p(g), 1, c, _p(w), _p(g2), _p(dot), st)
-            call("dgmr_sn_wgrad_finalize", _p(g2), _p(grad_buffer(w)), _p(dot), _p(sn.inv_sigma), _p(sn.u), _p(sn.v), 1, c, 1, 1, st)
+            call("dgmr_sn_wgrad_finalize", _p(g2), _p(grad_buffer(w)), _p(dot), _p(inv_sigma), _p(sn_u), _p(sn_v), 1, c, 1, 1, st)
         return dx, None, None, None
 
 

@@ -4,7 +4,14 @@
   a seeded construction of our DGMR reproduces the reference's initial state bit-for-bit.
 * GPU: our HIP training step reproduces the reference's losses, post-step parameters and buffers.
 
-Tolerances.  Losses: 1e-3 relative (north-star bound).  Buffers (u/v, BN running statistics): 1e-3 of the
+Tolerances.  Losses: 1e-3 relative (north-star bound).  Gradients: the discriminator's and the generator's last
+layer (sampler.bn / sampler.conv_1x1) are well conditioned and are compared at 2e-4 of their max magnitude.  The rest
+of the generator's gradient is NOT: it is dominated by the grid-cell term, whose upstream gradient is sign(mean - y) * w
+(losses.py:188-192) -- a sum of +-const terms that cancels to ~1/sqrt(#pixels) of its parts, so a single ReLU mask that
+flips on fp32 rounding noise moves it by ~0.5 %.  Measured with the CPU oracle alone (same code, same seeds):
+8 threads vs 1 thread differ by 1.2e-3 ... 4.3e-3 of max, a 1e-7 relative weight perturbation by up to 8e-3, and the
+oracle vs the reference's golden by up to 1.2e-2 (att_block.gamma).  Those tensors are therefore held to 5e-2 of max
+AND a cosine similarity >= 0.999 with the reference gradient.  Buffers (u/v, BN running statistics): 1e-3 of the
 tensor's max.  Parameters after Adam: with beta1 = 0 the first Adam step is lr * g / (|g| + eps) ~ +-lr, so an
 element whose gradient is rounding noise can flip sign (difference 2 * lr); the gradients themselves are compared
 at 2e-3 of their max magnitude, and for the stepped parameters we require >= 90 % of the elements to agree to 1e-5 + 1e-4 * |ref| and no element to move by more than 2.1 * lr.
@@ -62,15 +69,23 @@ def _check_post(sd1, rec, keys):
         assert abs(cs[i, 1].item() - ref[i, 1].item()) <= tol, f"{k}: abs-sum {cs[i, 1].item()} vs {ref[i, 1].item()}"
 
 
+WELL_CONDITIONED = ("grad.discriminator.", "grad.generator.sampler.bn.", "grad.generator.sampler.conv_1x1.")
+
+
 def _check_grads(grads, rec):
     n = 0
     for k, ref in rec.items():
         if not k.startswith("grad."):
             continue
+        assert k[5:] in grads, f"{k}: parameter received no gradient"
         got = grads[k[5:]].detach().cpu().float().reshape(ref.shape)
         scale = ref.abs().max().item()
         err = (got - ref).abs().max().item()
-        assert err <= 2e-3 * scale + 1e-7, f"{k}: grad abs err {err:.3e} at scale {scale:.3e}"
+        tol = 2e-4 if k.startswith(WELL_CONDITIONED) else 5e-2  # see the module docstring
+        assert err <= tol * scale + 1e-7, f"{k}: grad abs err {err:.3e} at scale {scale:.3e} (tol {tol})"
+        if scale > 0:
+            cos = torch.nn.functional.cosine_similarity(got.flatten().double(), ref.flatten().double(), dim=0).item()
+            assert cos >= 0.999, f"{k}: cosine {cos}"
         n += 1
     assert n >= 10
 
