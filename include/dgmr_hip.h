@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGMR_ABI_VERSION 1
+#define DGMR_ABI_VERSION 2
 
 int dgmr_abi_version(void);
 const char* dgmr_last_error(void);
@@ -86,22 +86,26 @@ typedef struct dgmr_wgrad_args {
     int32_t N, D, H, W, Cin, Cout, KD, KH, KW;
     int32_t upsample, pre_relu, pre_group;
     int32_t nsplit;      /* >= 1: the M = N*D*H*W reduction is cut into nsplit contiguous slabs */
-    int32_t reserved;
+    int32_t groups;      /* >= 1, divides N and nsplit: consecutive N/groups samples form a group (one spectral-norm call:
+                            forecast step / frame); a slab never straddles two groups */
 } dgmr_wgrad_args;
 
 /* Weight-gradient partial sums: partial[s] = dy[slab s]^T * im2col(pre(x))[slab s]. */
 int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream);
-/* Suggested nsplit for a problem (pure host arithmetic). */
-int dgmr_conv_wgrad_nsplit(int M, int Cout, int K);
+/* Suggested nsplit (a multiple of groups) for a problem (pure host arithmetic). */
+int dgmr_conv_wgrad_nsplit(int M, int Cout, int K, int groups);
 
-/* g[Cout*K] = sum_s partial[s]; *dot += <g, w> (dot must be zeroed by the caller / previous finalize). */
-int dgmr_wgrad_reduce(const float* partial, int nsplit, int64_t numel, const float* w, float* g, float* dot, void* stream);
-/* Spectral-norm chain rule (torch/nn/utils/parametrizations.py:515-521):
- *   gw[i][k] (+)= g[i][k]*inv_sigma - dot*inv_sigma^2 * u[i]*v[perm(k)],  then *dot = 0.
- * v is stored in torch's logical (ci, kd, kh, kw) order, w/g in physical (kd,kh,kw,ci) order.
- * accumulate != 0 adds into gw instead of overwriting.  u == v == NULL: plain scaled conv (no rank-1 term). */
+/* With P_q = sum of group q's slabs:  g[Cout*K] = sum_q scale[q] * P_q  (scale == NULL: 1);  dot[q] += <P_q, w>  (dot == NULL:
+ * skipped; otherwise [groups], zeroed by the caller / the previous finalize).  groups <= 32. */
+int dgmr_wgrad_reduce(const float* partial, int nsplit, int groups, int64_t numel, const float* w, const float* scale, float* g,
+                      float* dot, void* stream);
+/* Spectral-norm chain rule (torch/nn/utils/parametrizations.py:515-521), summed over the `groups` calls of the module that
+ * one batched launch covered (g already carries the 1/sigma_q factors, see dgmr_wgrad_reduce):
+ *   gw[i][k] (+)= g[i][k] - sum_q dot[q]*inv_sigma[q]^2 * u[q][i]*v[q][perm(k)],  then dot[0..groups) = 0.
+ * u: [groups][Cout], v: [groups][K] in torch's logical (ci, kd, kh, kw) order; w/g in physical (kd,kh,kw,ci) order.
+ * accumulate != 0 adds into gw instead of overwriting.  u == v == NULL: no rank-1 term (plain or scalar-gain conv). */
 int dgmr_sn_wgrad_finalize(const float* g, float* gw, float* dot, const float* inv_sigma, const float* u, const float* v,
-                           int Cout, int Cin, int taps, int accumulate, void* stream);
+                           int Cout, int Cin, int taps, int groups, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Spectral-norm power iteration — torch/nn/utils/parametrizations.py:454-521, called on every
@@ -114,6 +118,15 @@ int dgmr_sn_wgrad_finalize(const float* g, float* gw, float* dot, const float* i
 int dgmr_spectral_sigma(const float* w, float* u, float* v, float* u_save, float* v_save, float* inv_sigma,
                         float* scratch, float* tmp /* [Cout + K] */, int Cout, int Cin, int taps, float eps, int train,
                         void* stream);
+/* T consecutive train-mode calls of ONE module (a sampler conv is called once per forecast step, a discriminator conv once
+ * per frame: generators.py:153-178, discriminators.py:119-133,201-226) in one go.  gram = W W^T [Cout][Cout] (computed by the
+ * caller with dgmr_conv_fwd on the [Cout][K] weight matrix, valid until W changes): the T dependent power iterations then
+ * run on gram alone and W is read twice instead of 2T times.  Outputs per call t: inv_sigma[t], u_hist[t][Cout],
+ * v_hist[t][K] (the vectors sigma_t was computed with); u, v are left at their values after call T.  T <= 32.
+ * tmp: [Cout + T] floats; scratch as above. */
+int dgmr_spectral_sigma_seq(const float* w, const float* gram, float* u, float* v, float* u_hist, float* v_hist,
+                            float* inv_sigma, float* scratch, float* tmp, int Cout, int Cin, int taps, float eps, int T,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-channel reductions / BatchNorm — torch.nn.BatchNorm2d (common.py:38-39,108-109; generators.py:113)
@@ -162,6 +175,9 @@ int dgmr_frames_s2d_bwd(const float* dout, const int32_t* idx, float* dframes /*
 /* channels-last [B][h][w][4C] -> frames[b][t][c][2h][2w] (PixelShuffle(2)) and its backward. */
 int dgmr_d2s_frames(const float* x, float* frames, int B, int T, int t, int C, int h, int w, void* stream);
 int dgmr_d2s_frames_bwd(const float* dframes, float* dx, int B, int T, int t, int C, int h, int w, void* stream);
+/* dst[t][n][i] = src[n][t][i], i < inner (inner % 4 == 0): frames of a [N][T][H][W][C] tensor to a frame-major batch
+ * (discriminators.py:119-120 `x[:, :, idx]` for every idx at once) and back. */
+int dgmr_permute_nt(const float* src, float* dst, int N, int T, int64_t inner, void* stream);
 /* Strided channel copy: dst[r][dst_off + c*dst_cstride] (+)= src[r][src_off + c*src_cstride], c < C.
  * Implements torch.cat(dim=1) / channel slicing / "b t c h w -> b (c t) h w" on channels-last tensors. */
 int dgmr_copy_channels(const float* src, float* dst, int64_t R, int C, int src_C, int src_off, int src_cstride, int dst_C,
@@ -206,11 +222,12 @@ int dgmr_attention_bwd(const float* dout, const float* q, const float* k, const 
  * ---------------------------------------------------------------------------------------------- */
 int dgmr_relu_sum_hw_fwd(const float* x, float* y, int N, int HW, int C, void* stream);
 int dgmr_relu_sum_hw_bwd(const float* dy, const float* x, float* dx, int N, int HW, int C, void* stream);
-/* y[n] = scale * <x[n], w> + bias */
-int dgmr_linear1_fwd(const float* x, const float* w, const float* bias, const float* scale, float* y, int N, int C, void* stream);
-/* dx[n][c] = dy[n]*scale*w[c]; gw_raw[c] = sum_n dy[n]*x[n][c]; gb = sum_n dy[n] */
+/* y[n] = scale[n / scale_group] * <x[n], w> + bias   (scale_group rows per spectral-norm call; <= 0: all N rows) */
+int dgmr_linear1_fwd(const float* x, const float* w, const float* bias, const float* scale, float* y, int N, int C,
+                     int scale_group, void* stream);
+/* dx[n][c] = dy[n]*scale[q]*w[c]; gw_raw[q][c] = sum_{n in group q} dy[n]*x[n][c]; gb = sum_n dy[n]   (q = n / scale_group) */
 int dgmr_linear1_bwd(const float* dy, const float* x, const float* w, const float* scale, float* dx, float* gw_raw, float* gb,
-                     int N, int C, void* stream);
+                     int N, int C, int scale_group, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Losses — dgmr/losses.py:172-192,307-319; dgmr/dgmr.py:20-33.

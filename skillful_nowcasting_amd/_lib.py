@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdgmr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 P = c_void_p  # every device pointer and the stream travel as void*
 
@@ -35,7 +35,7 @@ class WgradArgs(Structure):
         ("x", P), ("dy", P), ("pre_a", P), ("pre_b", P), ("partial", P),
         ("N", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
         ("KD", c_int32), ("KH", c_int32), ("KW", c_int32), ("upsample", c_int32), ("pre_relu", c_int32),
-        ("pre_group", c_int32), ("nsplit", c_int32), ("reserved", c_int32),
+        ("pre_group", c_int32), ("nsplit", c_int32), ("groups", c_int32),
     ]
 
 
@@ -45,10 +45,11 @@ SIGNATURES = {
     "dgmr_conv_fwd": [POINTER(ConvArgs), P],
     "dgmr_conv_flip_weights": [P, P, i, i, i, i, i, P],
     "dgmr_conv_wgrad": [POINTER(WgradArgs), P],
-    "dgmr_conv_wgrad_nsplit": [i, i, i],
-    "dgmr_wgrad_reduce": [P, i, L, P, P, P, P],
-    "dgmr_sn_wgrad_finalize": [P, P, P, P, P, P, i, i, i, i, P],
+    "dgmr_conv_wgrad_nsplit": [i, i, i, i],
+    "dgmr_wgrad_reduce": [P, i, i, L, P, P, P, P, P],
+    "dgmr_sn_wgrad_finalize": [P, P, P, P, P, P, i, i, i, i, i, P],
     "dgmr_spectral_sigma": [P, P, P, P, P, P, P, P, i, i, i, f, i, P],
+    "dgmr_spectral_sigma_seq": [P, P, P, P, P, P, P, P, P, i, i, i, f, i, P],
     "dgmr_bn_stats": [P, P, i, L, i, P],
     "dgmr_bn_finalize": [P, P, P, P, P, P, P, P, P, P, i, L, i, f, f, P],
     "dgmr_bn_bwd_reduce": [P, P, P, P, P, i, L, i, P],
@@ -61,6 +62,7 @@ SIGNATURES = {
     "dgmr_frames_s2d_bwd": [P, P, P, i, i, i, i, i, i, i, i, P],
     "dgmr_d2s_frames": [P, P, i, i, i, i, i, i, P],
     "dgmr_d2s_frames_bwd": [P, P, i, i, i, i, i, i, P],
+    "dgmr_permute_nt": [P, P, i, i, L, P],
     "dgmr_copy_channels": [P, P, L, i, i, i, i, i, i, i, i, P],
     "dgmr_gru_gate_fwd": [P, P, P, L, P],
     "dgmr_gru_gate_bwd": [P, P, P, P, P, L, P],
@@ -74,8 +76,8 @@ SIGNATURES = {
     "dgmr_attention_bwd": [P, P, P, P, P, P, P, P, P, i, i, i, P],
     "dgmr_relu_sum_hw_fwd": [P, P, i, i, i, P],
     "dgmr_relu_sum_hw_bwd": [P, P, P, i, i, i, P],
-    "dgmr_linear1_fwd": [P, P, P, P, P, i, i, P],
-    "dgmr_linear1_bwd": [P, P, P, P, P, P, P, i, i, P],
+    "dgmr_linear1_fwd": [P, P, P, P, P, i, i, i, P],
+    "dgmr_linear1_bwd": [P, P, P, P, P, P, P, i, i, i, P],
     "dgmr_hinge_disc": [P, P, P, P, P, i, i, P],
     "dgmr_grid_cell_loss": [P, i, L, P, f, P, P, f, P, L, P],
     "dgmr_adam": [P, P, P, P, L, f, f, f, f, i, P],

@@ -34,13 +34,15 @@ class GBlock(torch.nn.Module):
         self.first_conv_3x3 = conv2d(input_channels, input_channels, 3, eps=spectral_normalized_eps)
         self.last_conv_3x3 = conv2d(input_channels, output_channels, 3, eps=spectral_normalized_eps)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, calls: int = 1) -> torch.Tensor:
+        """`calls` > 1: x holds `calls` consecutive calls of this block (forecast steps) as one time-major batch; every call
+        keeps its own BatchNorm batch statistics and spectral-norm sigma."""
         if x.shape[1] != self.output_channels:
-            sc = self.conv_1x1(x)
+            sc = self.conv_1x1(x, calls=calls)
         else:
             sc = x
-        x2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x))
-        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2), residual=sc)
+        x2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x, calls), calls=calls)
+        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls), residual=sc, calls=calls)
 
 
 class UpsampleGBlock(torch.nn.Module):
@@ -59,10 +61,10 @@ class UpsampleGBlock(torch.nn.Module):
         self.first_conv_3x3 = conv2d(input_channels, input_channels, 3, eps=spectral_normalized_eps)
         self.last_conv_3x3 = conv2d(input_channels, output_channels, 3, eps=spectral_normalized_eps)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        sc = self.conv_1x1(x, upsample=True)
-        x2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x), upsample=True)
-        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2), residual=sc)
+    def forward(self, x: torch.Tensor, calls: int = 1) -> torch.Tensor:
+        sc = self.conv_1x1(x, upsample=True, calls=calls)
+        x2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x, calls), upsample=True, calls=calls)
+        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls), residual=sc, calls=calls)
 
 
 class DBlock(torch.nn.Module):
@@ -83,17 +85,18 @@ class DBlock(torch.nn.Module):
         self.last_conv_3x3 = conv2d(output_channels, output_channels, 3)
         self.relu = torch.nn.ReLU()
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, calls: int = 1) -> torch.Tensor:
+        """`calls` > 1: x is a frame-major batch of `calls` consecutive calls of this block (one spectral-norm sigma each)."""
         if self.input_channels != self.output_channels:
-            x1 = self.conv_1x1(x)
+            x1 = self.conv_1x1(x, calls=calls)
             if not self.keep_same_output:
                 x1 = ops.avg_pool_add(x1, None, self._pd)
         else:
             x1 = x
-        h = self.first_conv_3x3(x, pre_relu=self.first_relu)
+        h = self.first_conv_3x3(x, pre_relu=self.first_relu, calls=calls)
         if self.keep_same_output:
-            return self.last_conv_3x3(h, pre_relu=True, residual=x1)
-        h = self.last_conv_3x3(h, pre_relu=True)
+            return self.last_conv_3x3(h, pre_relu=True, residual=x1, calls=calls)
+        h = self.last_conv_3x3(h, pre_relu=True, calls=calls)
         return ops.avg_pool_add(h, x1, self._pd)
 
 
@@ -142,20 +145,19 @@ class ContextConditioningStack(torch.nn.Module, PyTorchModelHubMixin):
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         ops.require_hip(x, "context frames")
         b, steps = x.shape[0], x.shape[1]
-        # PixelUnshuffle(2) of every frame, written channels-last and frame-major in one launch
-        s2d = ops.frames_s2d(x, None, pool=False, frame_major=True)
-        scales = ([], [], [], [])
-        for i in range(steps):
-            s = s2d[i * b:(i + 1) * b]
-            for lvl, blk in enumerate((self.d1, self.d2, self.d3, self.d4)):
-                s = blk(s)
-                scales[lvl].append(s)
-        return tuple(self._mixing_layer(scales[lvl], conv) for lvl, conv in
+        # PixelUnshuffle(2) of every frame, written channels-last and frame-major in one launch; the four context steps then
+        # run through d1..d4 as ONE batch of `steps` calls (each call keeps its own spectral-norm sigma)
+        s = ops.frames_s2d(x, None, pool=False, frame_major=True)
+        scales = []
+        for blk in (self.d1, self.d2, self.d3, self.d4):
+            s = blk(s, calls=steps)
+            scales.append(s)
+        return tuple(self._mixing_layer(scales[lvl], conv, steps) for lvl, conv in
                      enumerate((self.conv1, self.conv2, self.conv3, self.conv4)))
 
-    def _mixing_layer(self, inputs, conv_block):
+    def _mixing_layer(self, inputs, conv_block, steps):
         # "b t c h w -> b (c t) h w" (common.py:423) as a channel-interleaving copy, then relu(SN-conv3x3)
-        stacked = ops.cat_channels(inputs, interleave=True)
+        stacked = ops.time_to_channels(inputs, steps)
         return conv_block(stacked, act_relu=True)
 
 

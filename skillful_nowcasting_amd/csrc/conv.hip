@@ -285,7 +285,8 @@ int launch_conv(const dgmr_conv_args& a, int M, int Ktot, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <int BI, int BJ, int WI, int WJ>
 __global__ __launch_bounds__(64 * WI * WJ) void conv_wgrad_kernel(const dgmr_wgrad_args p, const int M, const int Ktot,
-                                                                   const int rows_per_split) {
+                                                                   const int rows_per_split, const int splits_per_group,
+                                                                   const int rows_per_group) {
     constexpr int NT = 64 * WI * WJ;
     constexpr int BR = 32;               // pixels per reduction step
     constexpr int TPR = NT / BR;         // threads per tile row (8 for NT = 256)
@@ -302,8 +303,10 @@ __global__ __launch_bounds__(64 * WI * WJ) void conv_wgrad_kernel(const dgmr_wgr
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wi = wid / WJ, wj = wid % WJ;
     const int k0 = blockIdx.x * BJ, co0 = blockIdx.y * BI;
-    const int r_begin = blockIdx.z * rows_per_split;
-    const int r_end = min(M, r_begin + rows_per_split);
+    // slab z covers rows of ONE group (samples that share a spectral-norm sigma): group = z / splits_per_group
+    const int grp = blockIdx.z / splits_per_group;
+    const int r_begin = grp * rows_per_group + (blockIdx.z - grp * splits_per_group) * rows_per_split;
+    const int r_end = min(min(M, (grp + 1) * rows_per_group), r_begin + rows_per_split);
     const int lr = tid / TPR, lq = tid % TPR;
 
     const int KHW = p.KH * p.KW;
@@ -404,39 +407,69 @@ __global__ void flip_weights_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, size_t numel, const float* __restrict__ w,
-                                    float* __restrict__ g, float* __restrict__ dot) {
-    __shared__ float red[32];
-    float d = 0.f;
+// g[i] = sum_grp scale[grp] * P_grp[i],  dot[grp] += <P_grp, w>   with P_grp = sum of the group's slabs.
+constexpr int WG_MAX_GROUPS = 32;
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int groups, size_t numel,
+                                    const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ g,
+                                    float* __restrict__ dot) {
+    __shared__ float red[WG_MAX_GROUPS][4];
+    const int spg = nsplit / groups;
+    float d[WG_MAX_GROUPS];
+#pragma unroll
+    for (int q = 0; q < WG_MAX_GROUPS; ++q) d[q] = 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * numel + i];
-        g[i] = s;
-        if (w) d = fmaf(s, w[i], d);
+        const float wi = w ? w[i] : 0.f;
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < WG_MAX_GROUPS; ++q) {
+            if (q < groups) {
+                float s = 0.f;
+                for (int k = 0; k < spg; ++k) s += partial[(size_t)(q * spg + k) * numel + i];
+                tot = fmaf(s, scale ? scale[q] : 1.f, tot);
+                d[q] = fmaf(s, wi, d[q]);
+            }
+        }
+        g[i] = tot;
     }
     if (dot) {
-        d = block_sum(d, red);
-        if (threadIdx.x == 0) atomicAdd(dot, d);
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < WG_MAX_GROUPS; ++q) {
+            if (q < groups) {
+                const float v = wave_sum(d[q]);
+                if (lane == 0) red[q][wid] = v;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < groups) atomicAdd(dot + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
     }
 }
 
+// gw (+)= g - sum_grp dot[grp] * inv_sigma[grp]^2 * u[grp][co] * v[grp][perm(k)]   (g already carries the 1/sigma factors)
 __global__ void sn_wgrad_finalize_kernel(const float* __restrict__ g, float* __restrict__ gw, const float* __restrict__ dot,
                                          const float* __restrict__ inv_sigma, const float* __restrict__ u,
-                                         const float* __restrict__ v, int Cout, int Cin, int taps, int accumulate) {
+                                         const float* __restrict__ v, int Cout, int Cin, int taps, int groups, int accumulate) {
     const size_t K = (size_t)Cin * taps;
     const size_t total = (size_t)Cout * K;
-    const float is = inv_sigma[0];
-    const float c = dot[0] * is * is;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int co = i / K;
         const int k = i - (size_t)co * K;
         const int t = k / Cin, ci = k - t * Cin;
-        const float val = u ? g[i] * is - c * u[co] * v[(size_t)ci * taps + t] : g[i] * is;
+        float val = g[i];
+        if (u) {
+            const size_t vj = (size_t)ci * taps + t;
+            for (int q = 0; q < groups; ++q) {
+                const float is = inv_sigma[q];
+                val = fmaf(-dot[q] * is * is * u[(size_t)q * Cout + co], v[(size_t)q * K + vj], val);
+            }
+        }
         gw[i] = accumulate ? gw[i] + val : val;
     }
 }
 
-__global__ void zero1_kernel(float* p) { p[0] = 0.f; }
+__global__ void zero_n_kernel(float* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
 
 }  // namespace
 
@@ -495,15 +528,18 @@ extern "C" int dgmr_conv_flip_weights(const float* w, float* w_t, int Cout, int 
     return 0;
 }
 
-extern "C" int dgmr_conv_wgrad_nsplit(int M, int Cout, int K) {
+extern "C" int dgmr_conv_wgrad_nsplit(int M, int Cout, int K, int groups) {
+    if (groups < 1) groups = 1;
     const int bi = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
     const int64_t tiles = (int64_t)((K + 127) / 128) * ((Cout + bi - 1) / bi);
     int64_t ns = 1024 / tiles;
     const int64_t cap = M / 256;  // at least 256 pixels per slab
     if (ns > cap) ns = cap;
-    if (ns < 1) ns = 1;
     if (ns > 1024) ns = 1024;
-    return (int)ns;
+    // a slab never straddles two groups: round to a multiple of `groups` (>= 1 slab per group)
+    int64_t per = ns / groups;
+    if (per < 1) per = 1;
+    return (int)(per * groups);
 }
 
 extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
@@ -511,49 +547,59 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
     DGMR_CHECK_ARG(a->Cin % 4 == 0 && a->Cout % 4 == 0, "dgmr_conv_wgrad: Cin=%d Cout=%d must be multiples of 4", a->Cin,
                    a->Cout);
     DGMR_CHECK_ARG(a->nsplit >= 1, "dgmr_conv_wgrad: nsplit=%d", a->nsplit);
+    const int groups = a->groups < 1 ? 1 : a->groups;
+    DGMR_CHECK_ARG(a->nsplit % groups == 0 && a->N % groups == 0, "dgmr_conv_wgrad: nsplit=%d / N=%d not divisible by groups=%d",
+                   a->nsplit, a->N, groups);
     const int64_t M64 = (int64_t)a->N * a->D * a->H * a->W;
     DGMR_CHECK_ARG(M64 > 0 && M64 < (1ll << 31), "dgmr_conv_wgrad: M out of range");
     dgmr_wgrad_args p = *a;
     if (p.pre_group < 1) p.pre_group = 1;
     const int M = (int)M64, Ktot = a->KD * a->KH * a->KW * a->Cin;
-    int rows = (M + a->nsplit - 1) / a->nsplit;
+    const int spg = a->nsplit / groups, rows_per_group = M / groups;
+    int rows = (rows_per_group + spg - 1) / spg;
     rows = (rows + 31) / 32 * 32;
     hipStream_t s = (hipStream_t)stream;
     const int kt = (Ktot + 127) / 128;
     ProfScope ps(a->Cout <= 32 ? V_W32 : (a->Cout <= 64 ? V_W64 : V_W128), 2.0 * (double)M64 * (double)Ktot * (double)a->Cout, s);
     if (a->Cout <= 32) {
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), dim3(kt, (a->Cout + 31) / 32, a->nsplit), dim3(256), 0, s, p, M,
-                           Ktot, rows);
+                           Ktot, rows, spg, rows_per_group);
     } else if (a->Cout <= 64) {
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2>), dim3(kt, (a->Cout + 63) / 64, a->nsplit), dim3(256), 0, s, p, M,
-                           Ktot, rows);
+                           Ktot, rows, spg, rows_per_group);
     } else {
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), dim3(kt, (a->Cout + 127) / 128, a->nsplit), dim3(256), 0, s, p,
-                           M, Ktot, rows);
+                           M, Ktot, rows, spg, rows_per_group);
     }
     DGMR_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int dgmr_wgrad_reduce(const float* partial, int nsplit, int64_t numel, const float* w, float* g, float* dot,
-                                 void* stream) {
+extern "C" int dgmr_wgrad_reduce(const float* partial, int nsplit, int groups, int64_t numel, const float* w, const float* scale,
+                                 float* g, float* dot, void* stream) {
     DGMR_CHECK_ARG(partial && g && numel > 0 && nsplit >= 1, "dgmr_wgrad_reduce: bad args");
-    const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, (size_t)numel, w, g,
-                       dot);
+    if (groups < 1) groups = 1;
+    DGMR_CHECK_ARG(groups <= WG_MAX_GROUPS && nsplit % groups == 0, "dgmr_wgrad_reduce: groups=%d (max %d) must divide nsplit=%d",
+                   groups, WG_MAX_GROUPS, nsplit);
+    DGMR_CHECK_ARG(!dot || w, "dgmr_wgrad_reduce: dot needs w");
+    const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 1024);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups, (size_t)numel,
+                       w, scale, g, dot);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int dgmr_sn_wgrad_finalize(const float* g, float* gw, float* dot, const float* inv_sigma, const float* u,
-                                      const float* v, int Cout, int Cin, int taps, int accumulate, void* stream) {
-    DGMR_CHECK_ARG(g && gw && dot && inv_sigma && ((u == nullptr) == (v == nullptr)), "dgmr_sn_wgrad_finalize: null pointer");
+                                      const float* v, int Cout, int Cin, int taps, int groups, int accumulate, void* stream) {
+    DGMR_CHECK_ARG(g && gw && ((u == nullptr) == (v == nullptr)) && (!u || (dot && inv_sigma)), "dgmr_sn_wgrad_finalize: null pointer");
+    if (groups < 1) groups = 1;
+    DGMR_CHECK_ARG(groups <= WG_MAX_GROUPS, "dgmr_sn_wgrad_finalize: groups=%d > %d", groups, WG_MAX_GROUPS);
     const size_t total = (size_t)Cout * Cin * taps;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sn_wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, s, g, gw, dot, inv_sigma, u, v, Cout, Cin, taps,
+    hipLaunchKernelGGL(sn_wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, s, g, gw, dot, inv_sigma, u, v, Cout, Cin, taps, groups,
                        accumulate);
-    hipLaunchKernelGGL(zero1_kernel, dim3(1), dim3(1), 0, s, dot);
+    if (dot) hipLaunchKernelGGL(zero_n_kernel, dim3(1), dim3(64), 0, s, dot, groups);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

@@ -114,6 +114,105 @@ __global__ void sn_finish_eval_kernel(const float* __restrict__ u, const float* 
     if (blockIdx.x == 0 && threadIdx.x == 0) inv_sigma[0] = 1.f / scratch[0];
 }
 
+
+// ---- T calls of one spectral-norm module in one go ---------------------------------------------------------
+// The reference runs one power iteration per module CALL (parametrizations.py:512-513); a sampler / discriminator
+// conv is called once per forecast step / frame, i.e. T dependent iterations on the same W.  With A = W W^T
+// ([Cout][Cout], cached per weight version) the chain never touches W again:
+//     s_t = W^T u_t,  n_t^2 = u_t^T A u_t,  d_t = max(n_t, eps),  v_t = s_t / d_t,  sigma_t = n_t^2 / d_t,
+//     u_{t+1} = W v_t / max(||W v_t||, eps) = (A u_t / d_t) / max(||A u_t|| / d_t, eps)
+// so W is read twice per forward (t0 = W v_0 and S = W^T [u_1..u_T]) instead of 2T times.
+constexpr int SN_TMAX = 32;
+
+// one workgroup: u_1 from t0, then T mat-vecs with A.  u_hist [T][Cout], dnorm [T], inv_sigma [T]; u <- u_T.
+__global__ __launch_bounds__(1024) void sn_gram_chain_kernel(const float* __restrict__ A, const float* __restrict__ t0,
+                                                             const float* __restrict__ scratch, float* __restrict__ u,
+                                                             float* __restrict__ u_hist, float* __restrict__ dnorm,
+                                                             float* __restrict__ inv_sigma, int Cout, int T, float eps) {
+    extern __shared__ float sh[];  // ucur[Cout] | y[Cout] | red[32]
+    float* ucur = sh;
+    float* y = sh + Cout;
+    float* red = sh + 2 * Cout;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    {
+        const float inv = 1.f / fmaxf(sqrtf(scratch[0]), eps);
+        for (int i = threadIdx.x; i < Cout; i += blockDim.x) ucur[i] = t0[i] * inv;
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        float part = 0.f;  // this wave's share of u^T A u
+        float part2 = 0.f;  // and of ||A u||^2
+        for (int i = wid; i < Cout; i += nw) {
+            const float* ar = A + (size_t)i * Cout;
+            float s = 0.f;
+            for (int j = lane; j < Cout; j += 64) s = fmaf(ar[j], ucur[j], s);
+            s = wave_sum(s);
+            if (lane == 0) {
+                y[i] = s;
+                part = fmaf(ucur[i], s, part);
+                part2 = fmaf(s, s, part2);
+            }
+        }
+        // block reductions of part / part2 (lane 0 of each wave holds them)
+        __syncthreads();
+        if (lane == 0) {
+            red[wid] = part;
+            red[16 + wid] = part2;
+        }
+        __syncthreads();
+        float n2 = 0.f, y2 = 0.f;
+        for (int k = 0; k < nw; ++k) {
+            n2 += red[k];
+            y2 += red[16 + k];
+        }
+        const float d = fmaxf(sqrtf(fmaxf(n2, 0.f)), eps);
+        for (int i = threadIdx.x; i < Cout; i += blockDim.x) u_hist[(size_t)t * Cout + i] = ucur[i];
+        if (threadIdx.x == 0) {
+            dnorm[t] = d;
+            inv_sigma[t] = d / n2;
+        }
+        __syncthreads();
+        if (t + 1 < T) {
+            // u_{t+1} = (y / d) / max(||y|| / d, eps)
+            const float invd = 1.f / d;
+            const float inv = invd / fmaxf(sqrtf(y2) * invd, eps);
+            for (int i = threadIdx.x; i < Cout; i += blockDim.x) ucur[i] = y[i] * inv;
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) u[i] = ucur[i];
+}
+
+// S[t][k] = sum_i W[i][k] u_hist[t][i] for all t in one pass over W; v_hist[t][perm(k)] = S / d_t; v <- v_hist[T-1].
+__global__ void sn_cols_seq_kernel(const float* __restrict__ w, const float* __restrict__ u_hist, const float* __restrict__ dnorm,
+                                   float* __restrict__ v, float* __restrict__ v_hist, int Cout, int K, int Cin, int taps, int T) {
+    __shared__ float part[4][SN_TMAX][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + c;
+    float acc[SN_TMAX];
+#pragma unroll
+    for (int t = 0; t < SN_TMAX; ++t) acc[t] = 0.f;
+    if (k < K)
+        for (int i = rg; i < Cout; i += 4) {
+            const float wv = w[(size_t)i * K + k];
+#pragma unroll
+            for (int t = 0; t < SN_TMAX; ++t)
+                if (t < T) acc[t] = fmaf(wv, u_hist[(size_t)t * Cout + i], acc[t]);
+        }
+#pragma unroll
+    for (int t = 0; t < SN_TMAX; ++t) part[rg][t][c] = acc[t];
+    __syncthreads();
+    if (k < K) {
+        const int tp = k / Cin, ci = k - tp * Cin;
+        const size_t j = (size_t)ci * taps + tp;
+        for (int t = rg; t < T; t += 4) {
+            const float s = (part[0][t][c] + part[1][t][c] + part[2][t][c] + part[3][t][c]) / dnorm[t];
+            v_hist[(size_t)t * K + j] = s;
+            if (t == T - 1) v[j] = s;
+        }
+    }
+}
+
 __global__ void zero_kernel(float* p, int n) {
     if (threadIdx.x < n) p[threadIdx.x] = 0.f;
 }
@@ -624,33 +723,46 @@ __global__ void relu_sum_hw_bwd_kernel(const float* __restrict__ dy, const float
 }
 
 __global__ void linear1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                   const float* __restrict__ scale, float* __restrict__ y, int C) {
+                                   const float* __restrict__ scale, float* __restrict__ y, int C, int scale_group) {
     __shared__ float red[32];
     const int n = blockIdx.x;
     float s = 0.f;
     for (int c = threadIdx.x; c < C; c += blockDim.x) s = fmaf(x[(size_t)n * C + c], w[c], s);
     s = block_sum(s, red);
-    if (threadIdx.x == 0) y[n] = s * (scale ? scale[0] : 1.f) + (bias ? bias[0] : 0.f);
+    if (threadIdx.x == 0) y[n] = s * (scale ? scale[n / scale_group] : 1.f) + (bias ? bias[0] : 0.f);
 }
 
+// one thread per (group, channel): dx rows of the group, the group's raw weight gradient; thread (0,0) also the bias gradient
 __global__ void linear1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
                                    const float* __restrict__ scale, float* __restrict__ dx, float* __restrict__ gw_raw,
-                                   float* __restrict__ gb, int N, int C) {
-    const float sc = scale ? scale[0] : 1.f;
-    GRID_STRIDE(c, C) {
+                                   float* __restrict__ gb, int N, int C, int scale_group) {
+    const int groups = N / scale_group;
+    GRID_STRIDE(i, (int64_t)groups * C) {
+        const int c = i % C, q = i / C;
         float g = 0.f;
-        const float wc = w[c] * sc;
-        for (int n = 0; n < N; ++n) {
+        const float wc = w[c] * (scale ? scale[q] : 1.f);
+        for (int n = q * scale_group; n < (q + 1) * scale_group; ++n) {
             const float d = dy[n];
             dx[(size_t)n * C + c] = d * wc;
             g = fmaf(d, x[(size_t)n * C + c], g);
         }
-        gw_raw[c] = g;
-        if (c == 0 && gb) {
+        gw_raw[(size_t)q * C + c] = g;
+        if (i == 0 && gb) {
             float s = 0.f;
             for (int n = 0; n < N; ++n) s += dy[n];
             gb[0] = s;
         }
+    }
+}
+
+// dst[t][n][i] = src[n][t][i]  (16-byte items)
+__global__ void permute_nt_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int N, int T, int64_t inner4) {
+    const int64_t total = (int64_t)N * T * inner4;
+    GRID_STRIDE(j, total) {
+        const int64_t i = j % inner4;
+        const int64_t r = j / inner4;
+        const int n = r % N, t = r / N;
+        dst[j] = src[((int64_t)n * T + t) * inner4 + i];
     }
 }
 
@@ -733,6 +845,27 @@ extern "C" int dgmr_spectral_sigma(const float* w, float* u, float* v, float* u_
         hipLaunchKernelGGL(sn_finish_eval_kernel, dim3(std::min((Cout + K + 255) / 256, 64)), dim3(256), 0, ST, u, v, u_save, v_save,
                            inv_sigma, scratch, Cout, K);
     }
+    hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ST, scratch, 4);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+
+extern "C" int dgmr_spectral_sigma_seq(const float* w, const float* gram, float* u, float* v, float* u_hist, float* v_hist,
+                                       float* inv_sigma, float* scratch, float* tmp, int Cout, int Cin, int taps, float eps,
+                                       int T, void* stream) {
+    DGMR_CHECK_ARG(w && gram && u && v && u_hist && v_hist && inv_sigma && scratch && tmp, "dgmr_spectral_sigma_seq: null pointer");
+    DGMR_CHECK_ARG(Cin % 4 == 0, "dgmr_spectral_sigma_seq: Cin=%d must be a multiple of 4", Cin);
+    DGMR_CHECK_ARG(T >= 1 && T <= SN_TMAX, "dgmr_spectral_sigma_seq: T=%d out of range [1, %d]", T, SN_TMAX);
+    DGMR_CHECK_ARG(Cout <= 8192, "dgmr_spectral_sigma_seq: Cout=%d too large", Cout);
+    const int K = Cin * taps;
+    float* t0 = tmp;           // [Cout]
+    float* dnorm = tmp + Cout; // [T]
+    hipLaunchKernelGGL(sn_rows_kernel, dim3(Cout), dim3(256), 0, ST, w, v, (const float*)nullptr, t0, scratch, K, Cin, taps);
+    const int threads = Cout >= 512 ? 1024 : (Cout >= 128 ? 512 : 256);
+    hipLaunchKernelGGL(sn_gram_chain_kernel, dim3(1), dim3(threads), (2 * Cout + 32) * sizeof(float), ST, gram, t0, scratch, u,
+                       u_hist, dnorm, inv_sigma, Cout, T, eps);
+    hipLaunchKernelGGL(sn_cols_seq_kernel, dim3((K + 63) / 64), dim3(256), 0, ST, w, u_hist, dnorm, v, v_hist, Cout, K, Cin, taps, T);
     hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ST, scratch, 4);
     DGMR_CHECK_LAUNCH();
     return 0;
@@ -960,16 +1093,31 @@ extern "C" int dgmr_relu_sum_hw_bwd(const float* dy, const float* x, float* dx, 
     return 0;
 }
 extern "C" int dgmr_linear1_fwd(const float* x, const float* w, const float* bias, const float* scale, float* y, int N, int C,
-                                void* stream) {
+                                int scale_group, void* stream) {
     DGMR_CHECK_ARG(x && w && y, "dgmr_linear1_fwd: null pointer");
-    hipLaunchKernelGGL(linear1_fwd_kernel, dim3(N), dim3(256), 0, ST, x, w, bias, scale, y, C);
+    if (scale_group < 1) scale_group = N;
+    DGMR_CHECK_ARG(N % scale_group == 0, "dgmr_linear1_fwd: N=%d not divisible by scale_group=%d", N, scale_group);
+    hipLaunchKernelGGL(linear1_fwd_kernel, dim3(N), dim3(256), 0, ST, x, w, bias, scale, y, C, scale_group);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int dgmr_linear1_bwd(const float* dy, const float* x, const float* w, const float* scale, float* dx, float* gw_raw,
-                                float* gb, int N, int C, void* stream) {
+                                float* gb, int N, int C, int scale_group, void* stream) {
     DGMR_CHECK_ARG(dy && x && w && dx && gw_raw, "dgmr_linear1_bwd: null pointer");
-    hipLaunchKernelGGL(linear1_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, dy, x, w, scale, dx, gw_raw, gb, N, C);
+    if (scale_group < 1) scale_group = N;
+    DGMR_CHECK_ARG(N % scale_group == 0, "dgmr_linear1_bwd: N=%d not divisible by scale_group=%d", N, scale_group);
+    const int64_t total = (int64_t)(N / scale_group) * C;
+    hipLaunchKernelGGL(linear1_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, ST, dy, x, w, scale, dx, gw_raw, gb, N, C,
+                       scale_group);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_permute_nt(const float* src, float* dst, int N, int T, int64_t inner, void* stream) {
+    DGMR_CHECK_ARG(src && dst && N > 0 && T > 0 && inner > 0 && inner % 4 == 0, "dgmr_permute_nt: bad args");
+    const int64_t total = (int64_t)N * T * (inner / 4);
+    hipLaunchKernelGGL(permute_nt_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, (const f32x4*)src, (f32x4*)dst, N, T,
+                       inner / 4);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

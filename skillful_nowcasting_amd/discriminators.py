@@ -22,11 +22,8 @@ class Discriminator(torch.nn.Module, PyTorchModelHubMixin):
         return torch.cat([spatial_loss, temporal_loss], dim=1)
 
 
-def _sum_heads(reps):
-    acc = reps[0]
-    for r in reps[1:]:
-        acc = ops.axpby(acc, r)
-    return acc.unsqueeze(1)  # [N, 1, 1]
+def _sum_heads(reps, frames):
+    return ops.sum_groups(reps, frames).unsqueeze(1)  # [frames*N, 1] -> [N, 1, 1]
 
 
 class TemporalDiscriminator(torch.nn.Module, PyTorchModelHubMixin):
@@ -56,17 +53,17 @@ class TemporalDiscriminator(torch.nn.Module, PyTorchModelHubMixin):
         x = ops.frames_s2d(x, None, pool=True, frame_major=False, as_3d=True)
         x = self.d1(x)
         x = self.d2(x)
-        representations = []
-        for idx in range(x.size(2)):
-            rep = x[:, :, idx]
-            for d in self.intermediate_dblocks:
-                rep = d(rep)
-            rep = self.d_last(rep)
-            rep = ops.relu_sum_hw(rep)
-            rep = self.bn(rep)
-            rep = self.fc(rep)
-            representations.append(rep)
-        return _sum_heads(representations)
+        # the reference loops over the remaining frames (discriminators.py:119-133); here they form one frame-major batch and
+        # every block / head runs once, each frame keeping its own spectral-norm sigma and BatchNorm1d batch statistics
+        frames = x.size(2)
+        rep = ops.frames_to_batch(x)
+        for d in self.intermediate_dblocks:
+            rep = d(rep, calls=frames)
+        rep = self.d_last(rep, calls=frames)
+        rep = ops.relu_sum_hw(rep)
+        rep = self.bn(rep, groups=frames)
+        rep = self.fc(rep, calls=frames)
+        return _sum_heads(rep, frames)
 
 
 class SpatialDiscriminator(torch.nn.Module, PyTorchModelHubMixin):
@@ -95,15 +92,15 @@ class SpatialDiscriminator(torch.nn.Module, PyTorchModelHubMixin):
         # frame indices come from the CPU generator exactly as in the reference (discriminators.py:199)
         idxs = torch.randint(low=0, high=x.size()[1], size=(self.num_timesteps,))
         idxs_dev = idxs.to(device=x.device, dtype=torch.int32)
-        representations = []
-        for i in range(self.num_timesteps):
-            rep = ops.frames_s2d(x, idxs_dev[i:i + 1], pool=True)  # AvgPool2d(2) + PixelUnshuffle(2) of frame idx
-            rep = self.d1(rep)
-            for d in self.intermediate_dblocks:
-                rep = d(rep)
-            rep = self.d6(rep)
-            rep = ops.relu_sum_hw(rep)
-            rep = self.bn(rep)
-            rep = self.fc(rep)
-            representations.append(rep)
-        return _sum_heads(representations)
+        frames = self.num_timesteps
+        # AvgPool2d(2) + PixelUnshuffle(2) of the drawn frames, frame-major: the reference's per-frame loop
+        # (discriminators.py:201-226) as one batch of `frames` calls per block
+        rep = ops.frames_s2d(x, idxs_dev, pool=True, frame_major=True)
+        rep = self.d1(rep, calls=frames)
+        for d in self.intermediate_dblocks:
+            rep = d(rep, calls=frames)
+        rep = self.d6(rep, calls=frames)
+        rep = ops.relu_sum_hw(rep)
+        rep = self.bn(rep, groups=frames)
+        rep = self.fc(rep, calls=frames)
+        return _sum_heads(rep, frames)

@@ -47,14 +47,21 @@ class Sampler(torch.nn.Module, PyTorchModelHubMixin):
                   (self.convGRU2, self.gru_conv_1x1_2, self.g2, self.up_g2),
                   (self.convGRU3, self.gru_conv_1x1_3, self.g3, self.up_g3),
                   (self.convGRU4, self.gru_conv_1x1_4, self.g4, self.up_g4))
+        T = self.forecast_steps
         for lvl, (gru, c11, g, upg) in enumerate(levels):
+            # only the ConvGRU is a true recurrence; its T outputs then travel as ONE time-major batch [T*B, C, h, w] through
+            # the 1x1 conv, the G-block and the upsampling G-block (one launch per conv instead of T), every forecast step
+            # keeping its own spectral-norm sigma and BatchNorm batch statistics exactly as the reference's T calls do
             hidden_states = gru.forward_list(hidden_states, init_states[3 - lvl])
-            hidden_states = [c11(h) for h in hidden_states]
-            hidden_states = [g(h) for h in hidden_states]
-            hidden_states = [upg(h) for h in hidden_states]
-        # relu(bn(h)) folded into the 1x1 conv's operand load; PixelShuffle + stack in one layout kernel per step
-        hidden_states = [self.conv_1x1(h, bn=self.bn.prepare(h)) for h in hidden_states]
-        return ops.d2s_frames(hidden_states)
+            h = ops.stack_batch(hidden_states)
+            h = c11(h, calls=T)
+            h = g(h, calls=T)
+            h = upg(h, calls=T)
+            if lvl < 3:
+                hidden_states = ops.unstack_batch(h, T)
+        # relu(bn(h)) folded into the 1x1 conv's operand load; PixelShuffle + stack in one layout pass
+        h = self.conv_1x1(h, bn=self.bn.prepare(h, T), calls=T)
+        return ops.d2s_frames(h, T)
 
 
 class Generator(torch.nn.Module, PyTorchModelHubMixin):

@@ -21,12 +21,14 @@ class ConvGRUCell(torch.nn.Module):
         self.update_gate_conv = SNConv(input_channels, output_channels, kernel_size, eps=sn_eps)
         self.output_conv = SNConv(input_channels, output_channels, kernel_size, eps=sn_eps)
 
-    def forward(self, x, prev_state):
+    def forward(self, x, prev_state, sn=None):
+        """`sn`: optional (read, update, output) spectral-norm records drawn up front for this step (ConvGRU.forward_list)."""
+        sr, su, so = sn if sn is not None else (None, None, None)
         xh = ops.cat_channels([x, prev_state])
-        pre_read = self.read_gate_conv(xh)
-        pre_update = self.update_gate_conv(xh)
+        pre_read = self.read_gate_conv(xh, sn=sr)
+        pre_update = self.update_gate_conv(xh, sn=su)
         gated_input = ops.cat_channels([x, ops.gru_gate(pre_read, prev_state)])
-        pre_c = self.output_conv(gated_input)
+        pre_c = self.output_conv(gated_input, sn=so)
         out = ops.gru_blend(pre_update, prev_state, pre_c)
         return out, out
 
@@ -40,8 +42,15 @@ class ConvGRU(torch.nn.Module):
 
     def forward_list(self, x, hidden_state=None) -> List[torch.Tensor]:
         outputs = []
-        for step in range(len(x)):
-            output, hidden_state = self.cell(x[step], hidden_state)
+        steps = len(x)
+        # the spectral-norm iterations of the cell's three convs do not depend on the data: all `steps` of them are drawn up front
+        # in one pass per conv (dgmr_spectral_sigma_seq), then step t uses record t
+        cell = self.cell
+        seqs = [c._sigma(steps) for c in (cell.read_gate_conv, cell.update_gate_conv, cell.output_conv)]
+        for step in range(steps):
+            # groups == 1: a single step, or eval mode (no iteration: every step sees the same sigma)
+            sn = tuple(q.at(step) if q.groups > 1 else q for q in seqs)
+            output, hidden_state = cell(x[step], hidden_state, sn)
             outputs.append(output)
         return outputs
 

@@ -77,8 +77,22 @@ class _SpectralNormBase(nn.Module):
     def weight_orig(self) -> torch.Tensor:
         return self.parametrizations.weight.original
 
-    def _sigma(self) -> ops.SNCall:
+    def _gram(self) -> torch.Tensor:
+        """W W^T, recomputed only when the optimiser (or a load_state_dict) has changed W."""
+        w = self.weight_orig
+        tag = (w._version, ops.weights_epoch(), w.data_ptr())
+        hit = getattr(self, "_gram_cache", None)
+        if hit is None or hit[0] != tag:
+            hit = (tag, ops.weight_gram(w))
+            self._gram_cache = hit
+        return hit[1]
+
+    def _sigma(self, calls: int = 1) -> ops.SNCall:
+        """Spectral-norm record of `calls` consecutive calls of this module (train: one power iteration per call)."""
         vec = getattr(self.parametrizations.weight, "0")
+        if calls > 1 and self.training:
+            return ops.spectral_sigma_seq(self.weight_orig, self._gram(), vec._u, vec._v, self._scratch, self.eps, calls)
+        # one call, or eval mode (no iteration: every call sees the same sigma)
         return ops.spectral_sigma(self.weight_orig, vec._u, vec._v, self._scratch, self.eps, self.training)
 
 
@@ -92,8 +106,11 @@ class SNConv(_SpectralNormBase):
         self._init_sn(w, b, eps)
 
     def forward(self, x, *, pre_relu: bool = False, bn: Optional[BNState] = None, upsample: bool = False, residual=None,
-                act_relu: bool = False):
-        sn = self._sigma()
+                act_relu: bool = False, calls: int = 1, sn: Optional[ops.SNCall] = None):
+        """`calls` > 1: x is a batch of `calls` groups (forecast steps / frames), each group being one call of this module in
+        the reference (own power iteration, own sigma).  `sn`: a record drawn earlier with `_sigma` (ConvGRU steps)."""
+        if sn is None:
+            sn = self._sigma(calls)
         spec = ConvSpec(upsample=upsample, pre_relu=pre_relu, bn=bn, sn=sn, act_relu=act_relu)
         return ops.conv(x, self.weight_orig, self.bias, sn.inv_sigma, residual, spec)
 
@@ -111,8 +128,8 @@ class SNLinear1(_SpectralNormBase):
         nn.init.uniform_(b, -bound, bound)
         self._init_sn(w, b, eps)
 
-    def forward(self, x):
-        sn = self._sigma()
+    def forward(self, x, calls: int = 1):
+        sn = self._sigma(calls)
         return ops.SNLinear1Fn.apply(x, self.weight_orig, self.bias, sn)
 
 
@@ -155,6 +172,7 @@ class BatchNorm(nn.BatchNorm2d):
 class BatchNorm1d(nn.BatchNorm1d):
     """BatchNorm1d over [N, C] through the HIP kernels (discriminator heads)."""
 
-    def forward(self, x):
+    def forward(self, x, groups: int = 1):
+        """`groups` > 1: x is [groups*N, C]; each group is one call of the reference's module (own batch statistics)."""
         return ops.BatchNorm1dFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked,
-                                       self.eps, self.momentum, self.training)
+                                       self.eps, self.momentum, self.training, groups)

@@ -31,6 +31,10 @@ def bump_weights_epoch():
     _WEIGHTS_EPOCH += 1
 
 
+def weights_epoch() -> int:
+    return _WEIGHTS_EPOCH
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -84,9 +88,16 @@ def grad_buffer(p: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------
 @dataclass
 class SNCall:
-    inv_sigma: torch.Tensor  # [1]
-    u: torch.Tensor  # copies of the u, v that sigma was computed with (the module buffers move on)
-    v: torch.Tensor
+    """Record of `groups` consecutive calls of one spectral-norm module (1 for an ordinary call)."""
+
+    inv_sigma: torch.Tensor  # [groups]
+    u: torch.Tensor  # [groups, Cout]  copies of the u, v that sigma was computed with (the module buffers move on)
+    v: torch.Tensor  # [groups, K]
+    groups: int = 1
+
+    def at(self, t: int) -> "SNCall":
+        """The t-th call of a sequence as a single-call record (views, no copies)."""
+        return SNCall(self.inv_sigma[t:t + 1], self.u[t:t + 1], self.v[t:t + 1], 1)
 
 
 def spectral_sigma(w: torch.Tensor, u: torch.Tensor, v: torch.Tensor, scratch: torch.Tensor, eps: float, train: bool) -> SNCall:
@@ -102,7 +113,35 @@ def spectral_sigma(w: torch.Tensor, u: torch.Tensor, v: torch.Tensor, scratch: t
     tmp = torch.empty(cout + k, device=w.device, dtype=torch.float32)
     call("dgmr_spectral_sigma", _p(w), _p(u), _p(v), _p(u_save), _p(v_save), _p(inv_sigma), _p(scratch), _p(tmp), cout, cin,
          taps, float(eps), int(bool(train)), _stream())
-    return SNCall(inv_sigma, u_save, v_save)
+    return SNCall(inv_sigma, u_save.view(1, -1), v_save.view(1, -1), 1)
+
+
+def weight_gram(w: torch.Tensor) -> torch.Tensor:
+    """A = W W^T ([Cout, Cout]) of a conv / linear weight seen as the [Cout, K] matrix, on the MFMA conv kernel:
+    the weight tensor is handed in both as the 'image' (Cout pixels of K channels) and as the 1x1 filter bank."""
+    require_hip(w, "spectral-norm weight")
+    cout = w.shape[0]
+    k = w.numel() // cout
+    a = torch.empty(cout, cout, device=w.device, dtype=torch.float32)
+    _launch_conv(w, _p(w), None, None, a, 1, 1, cout, 1, k, cout, 1, 1, 1)
+    return a
+
+
+def spectral_sigma_seq(w: torch.Tensor, gram: torch.Tensor, u: torch.Tensor, v: torch.Tensor, scratch: torch.Tensor, eps: float,
+                       calls: int) -> SNCall:
+    """`calls` consecutive train-mode calls of one module (one power iteration each) in one go; see dgmr_spectral_sigma_seq."""
+    require_hip(w, "spectral-norm weight")
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w.numel() // (cout * cin)
+    k = cin * taps
+    dev = w.device
+    inv_sigma = torch.empty(calls, device=dev, dtype=torch.float32)
+    u_hist = torch.empty(calls, cout, device=dev, dtype=torch.float32)
+    v_hist = torch.empty(calls, k, device=dev, dtype=torch.float32)
+    tmp = torch.empty(cout + calls, device=dev, dtype=torch.float32)
+    call("dgmr_spectral_sigma_seq", _p(w), _p(gram), _p(u), _p(v), _p(u_hist), _p(v_hist), _p(inv_sigma), _p(scratch), _p(tmp),
+         cout, cin, taps, float(eps), calls, _stream())
+    return SNCall(inv_sigma, u_hist, v_hist, calls)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -165,6 +204,11 @@ class ConvSpec:
     gamma_scale: bool = False  # scale tensor is a learnable scalar parameter (Attention.gamma)
     act_relu: bool = False  # relu on the output (F.relu(conv(..)), common.py:424)
 
+    @property
+    def groups(self) -> int:
+        """Number of module calls one launch covers (consecutive N/groups samples share a sigma)."""
+        return self.sn.groups if self.sn is not None else 1
+
 
 _flip_cache = {}
 
@@ -225,9 +269,13 @@ class ConvFn(Function):
         if residual is not None:
             residual = to_cl(residual)
         bn = spec.bn
+        groups = spec.groups
+        if n % groups:
+            raise RuntimeError(f"conv: batch {n} is not divisible into {groups} spectral-norm call groups")
         _launch_conv(x, _p(w), bias, scale, y, n, d, h, wd, cin, cout, kd, kh, kw, upsample=spec.upsample,
                      pre_relu=spec.pre_relu, pre_a=bn.a if bn else None, pre_b=bn.b if bn else None,
-                     pre_group=bn.group_size if bn else 1, residual=residual, act_relu=spec.act_relu)
+                     pre_group=bn.group_size if bn else 1, residual=residual, act_relu=spec.act_relu,
+                     scale_group=n // groups)
         ctx.spec = spec  # flags only are read from it in backward; its tensors are re-read from saved_tensors
         ctx.has_residual = residual is not None
         # parameters are kept as-is (checkpointing hands back DETACHED copies of saved tensors: .grad must land on the real ones)
@@ -263,8 +311,10 @@ class ConvFn(Function):
             tmp = torch.empty(2 * cout, device=dev, dtype=torch.float64)
             call("dgmr_colsum", _p(dy), _p(grad_buffer(bias)), _p(tmp), m, cout, 1, st)
         # ---- weight (and scale) ----
+        groups = spec.groups
+        taps = kd * kh * kw
         if w.requires_grad:
-            ns = call_nsplit(m, cout, k)
+            ns = call_nsplit(m, cout, k, groups)
             partial = torch.empty(ns * cout * k, device=dev, dtype=torch.float32)
             wa = WgradArgs()
             wa.x, wa.dy, wa.partial = _p(x), _p(dy), _p(partial)
@@ -272,31 +322,31 @@ class ConvFn(Function):
             wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, d, h, wd, cin, cout
             wa.KD, wa.KH, wa.KW = kd, kh, kw
             wa.upsample, wa.pre_relu, wa.pre_group, wa.nsplit = int(spec.upsample), int(spec.pre_relu), (bn.group_size if bn else 1), ns
+            wa.groups = groups
             call("dgmr_conv_wgrad", ctypes.byref(wa), st)
             gw = grad_buffer(w)
+            g = torch.empty(cout * k, device=dev, dtype=torch.float32)
             if scale is None:
-                g = torch.empty(cout * k, device=dev, dtype=torch.float32)
-                call("dgmr_wgrad_reduce", _p(partial), ns, cout * k, None, _p(g), None, st)
-                call("dgmr_axpby", _p(gw), _p(g), _p(gw), 1.0, 1.0, cout * k, st)
+                call("dgmr_wgrad_reduce", _p(partial), ns, 1, cout * k, None, None, _p(g), None, st)
+                call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), None, None, None, None, cout, cin, taps, 1, 1, st)
             else:
-                g = torch.empty(cout * k, device=dev, dtype=torch.float32)
-                dot = torch.zeros(1, device=dev, dtype=torch.float32)
-                call("dgmr_wgrad_reduce", _p(partial), ns, cout * k, _p(w), _p(g), _p(dot), st)
+                # g = sum_q P_q / sigma_q ; dot[q] = <P_q, W>   (P_q: raw weight gradient over the rows of call q)
+                dot = torch.zeros(groups, device=dev, dtype=torch.float32)
+                call("dgmr_wgrad_reduce", _p(partial), ns, groups, cout * k, _p(w), _p(scale), _p(g), _p(dot), st)
                 if spec.sn is not None:
-                    call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), _p(sn_u), _p(sn_v), cout, cin,
-                         kd * kh * kw, 1, st)
-                else:  # learnable scalar gain: d scale = <G, W>, dW = scale * G
+                    call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), _p(sn_u), _p(sn_v), cout, cin, taps, groups, 1, st)
+                else:  # learnable scalar gain: d scale = <P, W>, dW = scale * P
                     if scale_param is not None and scale_param.requires_grad:
                         gs = grad_buffer(scale_param)
                         call("dgmr_axpby", _p(gs), _p(dot), _p(gs), 1.0, 1.0, 1, st)
-                    call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), None, None, cout, cin, kd * kh * kw, 1, st)
+                    call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), None, None, None, None, cout, cin, taps, 1, 1, st)
         # ---- input ----
         dx = None
         if ctx.needs_input_grad[0]:
             wt = _flipped_weight(w)
             if spec.upsample:
                 hi = empty_cl((n, cin, h, wd) if x.dim() == 4 else (n, cin, d, h, wd), dy)
-                _launch_conv(dy, _p(wt), None, scale, hi, n, d, h, wd, cout, cin, kd, kh, kw)
+                _launch_conv(dy, _p(wt), None, scale, hi, n, d, h, wd, cout, cin, kd, kh, kw, scale_group=n // groups)
                 g = empty_cl(x.shape, dy)
                 call("dgmr_pool_fwd", _p(hi), None, _p(g), n, d, h, wd, cin, 1, 1.0, _p(x) if (bn or spec.pre_relu) else None,
                      _p(bn_a) if bn else None, _p(bn_b) if bn else None, bn.group_size if bn else 1, st)
@@ -304,7 +354,7 @@ class ConvFn(Function):
                 g = empty_cl(x.shape, dy)
                 _launch_conv(dy, _p(wt), None, scale, g, n, d, h, wd, cout, cin, kd, kh, kw,
                              mask_src=x if (bn or spec.pre_relu) else None, mask_a=bn_a if bn else None,
-                             mask_b=bn_b if bn else None, mask_group=bn.group_size if bn else 1)
+                             mask_b=bn_b if bn else None, mask_group=bn.group_size if bn else 1, scale_group=n // groups)
             if bn is None:
                 dx = g
             else:
@@ -321,10 +371,10 @@ class ConvFn(Function):
         return dx, None, None, None, d_res, None, None, None
 
 
-def call_nsplit(m: int, cout: int, k: int) -> int:
+def call_nsplit(m: int, cout: int, k: int, groups: int = 1) -> int:
     from ._lib import load
 
-    return int(load().dgmr_conv_wgrad_nsplit(m, cout, k))
+    return int(load().dgmr_conv_wgrad_nsplit(m, cout, k, groups))
 
 
 def conv(x, w, bias=None, scale=None, residual=None, spec: Optional[ConvSpec] = None):
@@ -406,14 +456,15 @@ class D2SFramesFn(Function):
     """T channels-last maps [B,4C,h,w] -> PixelShuffle(2) -> stacked frames [B,T,C,2h,2w] (generators.py:178-181)."""
 
     @staticmethod
-    def forward(ctx, *xs):
-        xs = [to_cl(x) for x in xs]
-        require_hip(xs[0])
-        b, c4, h, w = xs[0].shape
-        c, t = c4 // 4, len(xs)
-        frames = torch.empty(b, t, c, 2 * h, 2 * w, device=xs[0].device, dtype=torch.float32)
-        for i, x in enumerate(xs):
-            call("dgmr_d2s_frames", _p(x), _p(frames), b, t, i, c, h, w, _stream())
+    def forward(ctx, x, t: int):
+        x = to_cl(x)
+        require_hip(x)
+        tb, c4, h, w = x.shape
+        c, b = c4 // 4, tb // t
+        frames = torch.empty(b, t, c, 2 * h, 2 * w, device=x.device, dtype=torch.float32)
+        n = b * c4 * h * w
+        for i in range(t):
+            call("dgmr_d2s_frames", x.data_ptr() + 4 * n * i, _p(frames), b, t, i, c, h, w, _stream())
         ctx.geom = (b, t, c, h, w)
         return frames
 
@@ -421,16 +472,16 @@ class D2SFramesFn(Function):
     def backward(ctx, dfr):
         b, t, c, h, w = ctx.geom
         dfr = dfr.contiguous()
-        outs = []
+        dx = empty_cl((t * b, 4 * c, h, w), dfr)
+        n = b * 4 * c * h * w
         for i in range(t):
-            dx = empty_cl((b, 4 * c, h, w), dfr)
-            call("dgmr_d2s_frames_bwd", _p(dfr), _p(dx), b, t, i, c, h, w, _stream())
-            outs.append(dx)
-        return tuple(outs)
+            call("dgmr_d2s_frames_bwd", _p(dfr), dx.data_ptr() + 4 * n * i, b, t, i, c, h, w, _stream())
+        return dx, None
 
 
-def d2s_frames(xs: Sequence[torch.Tensor]):
-    return D2SFramesFn.apply(*xs)
+def d2s_frames(x: torch.Tensor, t: int):
+    """Time-major batch [T*B, 4C, h, w] -> PixelShuffle(2) -> frames [B, T, C, 2h, 2w]."""
+    return D2SFramesFn.apply(x, t)
 
 
 class CatChannelsFn(Function):
@@ -625,13 +676,16 @@ class BatchNorm1dFn(Function):
     """torch.nn.BatchNorm1d on [N, C] (discriminators.py:102,129,194,218), batch statistics in train mode."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, eps, momentum, train):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, eps, momentum, train, groups=1):
         require_hip(x)
         x = x.contiguous()
         n, c = x.shape
-        st = bn_prepare(x.view(n, c, 1, 1), gamma, beta, running_mean, running_var, nbt, eps, momentum, train)
+        st = bn_prepare(x.view(n, c, 1, 1), gamma, beta, running_mean, running_var, nbt, eps, momentum, train, groups)
         y = torch.empty_like(x)
-        call("dgmr_affine", _p(x), _p(st.a), _p(st.b), _p(y), 1, n, c, 0, _stream())
+        if st.groups > 1:
+            call("dgmr_affine", _p(x), _p(st.a), _p(st.b), _p(y), st.groups, n // st.groups, c, 0, _stream())
+        else:
+            call("dgmr_affine", _p(x), _p(st.a), _p(st.b), _p(y), 1, n, c, 0, _stream())
         ctx.st = st
         ctx.save_for_backward(x, st.mean, st.rstd)  # see ConvFn.forward: nothing tensor-valued may be read from ctx.st
         return y
@@ -642,26 +696,30 @@ class BatchNorm1dFn(Function):
         st: BNState = ctx.st
         n, c = x.shape
         dy = dy.contiguous()
-        sums = torch.zeros(2 * c, device=x.device, dtype=torch.float64)
-        call("dgmr_bn_bwd_reduce", _p(dy), _p(x), _p(mean), _p(rstd), _p(sums), 1, n, c, _stream())
+        gq = st.groups
+        sums = torch.zeros(gq * 2 * c, device=x.device, dtype=torch.float64)
+        call("dgmr_bn_bwd_reduce", _p(dy), _p(x), _p(mean), _p(rstd), _p(sums), gq, n // gq, c, _stream())
         dx = torch.empty_like(x)
         dgam = grad_buffer(st.gamma) if st.gamma.requires_grad else None
         dbet = grad_buffer(st.beta) if st.beta.requires_grad else None
         call("dgmr_bn_bwd_apply", _p(dy), _p(x), _p(mean), _p(rstd), _p(st.gamma), _p(sums), None, _p(dx), _p(dgam), _p(dbet),
-             1, n, c, int(st.train), _stream())
-        return dx, None, None, None, None, None, None, None, None
+             gq, n // gq, c, int(st.train), _stream())
+        return dx, None, None, None, None, None, None, None, None, None
 
 
 class SNLinear1Fn(Function):
-    """spectral_norm(Linear(C, 1)) (discriminators.py:100,192)."""
+    """spectral_norm(Linear(C, 1)) (discriminators.py:100,192); `sn.groups` calls (frames) per launch."""
 
     @staticmethod
     def forward(ctx, x, w, bias, sn: SNCall):
         require_hip(x)
         x = x.contiguous()
         n, c = x.shape
+        if n % sn.groups:
+            raise RuntimeError(f"linear: {n} rows are not divisible into {sn.groups} spectral-norm call groups")
         y = torch.empty(n, 1, device=x.device, dtype=torch.float32)
-        call("dgmr_linear1_fwd", _p(x), _p(w), _p(bias), _p(sn.inv_sigma), _p(y), n, c, _stream())
+        call("dgmr_linear1_fwd", _p(x), _p(w), _p(bias), _p(sn.inv_sigma), _p(y), n, c, n // sn.groups, _stream())
+        ctx.groups = sn.groups
         ctx.params = (w, bias)
         ctx.save_for_backward(x, sn.inv_sigma, sn.u, sn.v)
         return y
@@ -671,22 +729,180 @@ class SNLinear1Fn(Function):
         x, inv_sigma, sn_u, sn_v = ctx.saved_tensors
         w, bias = ctx.params
         n, c = x.shape
+        gq = ctx.groups
         dy = dy.contiguous()
         dev = x.device
         dx = torch.empty_like(x)
-        g = torch.empty(c, device=dev, dtype=torch.float32)
+        g = torch.empty(gq * c, device=dev, dtype=torch.float32)
         gb = torch.empty(1, device=dev, dtype=torch.float32)
         st = _stream()
-        call("dgmr_linear1_bwd", _p(dy), _p(x), _p(w), _p(inv_sigma), _p(dx), _p(g), _p(gb), n, c, st)
+        call("dgmr_linear1_bwd", _p(dy), _p(x), _p(w), _p(inv_sigma), _p(dx), _p(g), _p(gb), n, c, n // gq, st)
         if bias is not None and bias.requires_grad:
             b = grad_buffer(bias)
             call("dgmr_axpby", _p(b), _p(gb), _p(b), 1.0, 1.0, 1, st)
         if w.requires_grad:
-            dot = torch.zeros(1, device=dev, dtype=torch.float32)
-            g2 = torch.empty_like(g)
-            call("dgmr_wgrad_reduce", _p(g), 1, c, _p(w), _p(g2), _p(dot), st)
-            call("dgmr_sn_wgrad_finalize", _p(g2), _p(grad_buffer(w)), _p(dot), _p(inv_sigma), _p(sn_u), _p(sn_v), 1, c, 1, 1, st)
+            dot = torch.zeros(gq, device=dev, dtype=torch.float32)
+            g2 = torch.empty(c, device=dev, dtype=torch.float32)
+            call("dgmr_wgrad_reduce", _p(g), gq, gq, c, _p(w), _p(inv_sigma), _p(g2), _p(dot), st)
+            call("dgmr_sn_wgrad_finalize", _p(g2), _p(grad_buffer(w)), _p(dot), _p(inv_sigma), _p(sn_u), _p(sn_v), 1, c, 1, gq, 1, st)
         return dx, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# batch <-> list / time <-> channel layout moves for the T-batched modules
+# ---------------------------------------------------------------------------------------------------
+def _copy(src_ptr, dst_ptr, n):
+    call("dgmr_axpby", src_ptr, None, dst_ptr, 1.0, 0.0, n, _stream())
+
+
+class StackBatchFn(Function):
+    """T tensors [B, ...] -> one [T*B, ...] (time-major): the per-step outputs of a ConvGRU become ONE batch, so that the
+    1x1 / G-block / upsample-G-block convs of all forecast steps run as one launch (generators.py:153-171)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [to_cl(x) for x in xs]
+        require_hip(xs[0])
+        b = xs[0].shape[0]
+        out = empty_cl((b * len(xs),) + tuple(xs[0].shape[1:]), xs[0])
+        n = xs[0].numel()
+        for i, x in enumerate(xs):
+            _copy(_p(x), out.data_ptr() + 4 * n * i, n)
+        ctx.t, ctx.b = len(xs), b
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = to_cl(dout)
+        n = dout.numel() // ctx.t
+        outs = []
+        for i in range(ctx.t):
+            g = empty_cl((ctx.b,) + tuple(dout.shape[1:]), dout)
+            _copy(dout.data_ptr() + 4 * n * i, _p(g), n)
+            outs.append(g)
+        return tuple(outs)
+
+
+def stack_batch(xs):
+    return StackBatchFn.apply(*xs)
+
+
+class UnstackBatchFn(Function):
+    """[T*B, ...] -> T tensors [B, ...]; the backward writes each gradient into its slot of one buffer."""
+
+    @staticmethod
+    def forward(ctx, x, t: int):
+        require_hip(x)
+        x = to_cl(x)
+        b = x.shape[0] // t
+        n = x.numel() // t
+        outs = []
+        for i in range(t):
+            o = empty_cl((b,) + tuple(x.shape[1:]), x)
+            _copy(x.data_ptr() + 4 * n * i, _p(o), n)
+            outs.append(o)
+        ctx.t, ctx.shape = t, tuple(x.shape)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        ref = next(d for d in douts if d is not None)
+        dx = empty_cl(ctx.shape, ref)
+        n = dx.numel() // ctx.t
+        for i, d in enumerate(douts):
+            if d is None:
+                call("dgmr_fill", dx.data_ptr() + 4 * n * i, 0.0, n, _stream())
+            else:
+                _copy(_p(to_cl(d)), dx.data_ptr() + 4 * n * i, n)
+        return dx, None
+
+
+def unstack_batch(x, t: int):
+    return list(UnstackBatchFn.apply(x, t))
+
+
+class TimeToChannelsFn(Function):
+    """[T*B, C, h, w] (time-major batch) -> [B, C*T, h, w] with channel index c*T + t: einops 'b t c h w -> b (c t) h w'
+    (common.py:423) read straight from the batched D-block output."""
+
+    @staticmethod
+    def forward(ctx, x, t: int):
+        require_hip(x)
+        x = to_cl(x)
+        tb, c, h, w = x.shape
+        b = tb // t
+        out = empty_cl((b, c * t, h, w), x)
+        r = b * h * w
+        for i in range(t):
+            call("dgmr_copy_channels", x.data_ptr() + 4 * r * c * i, _p(out), r, c, c, 0, 1, c * t, i, t, 0, _stream())
+        ctx.geom = (t, b, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        t, b, c, h, w = ctx.geom
+        dout = to_cl(dout)
+        dx = empty_cl((t * b, c, h, w), dout)
+        r = b * h * w
+        for i in range(t):
+            call("dgmr_copy_channels", _p(dout), dx.data_ptr() + 4 * r * c * i, r, c, c * t, i, t, c, 0, 1, 0, _stream())
+        return dx, None
+
+
+def time_to_channels(x, t: int):
+    return TimeToChannelsFn.apply(x, t)
+
+
+class FramesToBatchFn(Function):
+    """[N, C, T, h, w] (channels_last_3d, i.e. N T h w C) -> frame-major batch [T*N, C, h, w]: every `x[:, :, idx]` of the
+    temporal discriminator's loop at once (discriminators.py:119-120)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        require_hip(x)
+        x = to_cl(x)
+        n, c, t, h, w = x.shape
+        out = empty_cl((t * n, c, h, w), x)
+        call("dgmr_permute_nt", _p(x), _p(out), n, t, h * w * c, _stream())
+        ctx.geom = (n, c, t, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, c, t, h, w = ctx.geom
+        dout = to_cl(dout)
+        dx = empty_cl((n, c, t, h, w), dout)
+        call("dgmr_permute_nt", _p(dout), _p(dx), t, n, h * w * c, _stream())
+        return dx
+
+
+frames_to_batch = FramesToBatchFn.apply
+
+
+class SumGroupsFn(Function):
+    """[G*N, 1] -> [N, 1]: sum over the G frame groups (torch.sum(torch.stack(reps, dim=1), dim=1), discriminators.py:134-137)."""
+
+    @staticmethod
+    def forward(ctx, x, groups: int):
+        require_hip(x)
+        x = x.contiguous()
+        n = x.shape[0] // groups
+        out = torch.empty(n, 1, device=x.device, dtype=torch.float32)
+        tmp = torch.empty(2 * n, device=x.device, dtype=torch.float64)
+        call("dgmr_colsum", _p(x), _p(out), _p(tmp), groups, n, 0, _stream())
+        ctx.groups, ctx.n = groups, n
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        dx = torch.empty(ctx.groups * ctx.n, 1, device=dout.device, dtype=torch.float32)
+        for i in range(ctx.groups):
+            _copy(_p(dout), dx.data_ptr() + 4 * ctx.n * i, ctx.n)
+        return dx, None
+
+
+sum_groups = SumGroupsFn.apply
 
 
 # ---------------------------------------------------------------------------------------------------
