@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGMR_ABI_VERSION 2
+#define DGMR_ABI_VERSION 3
 
 int dgmr_abi_version(void);
 const char* dgmr_last_error(void);
@@ -67,15 +67,32 @@ typedef struct dgmr_conv_args {
     int32_t pre_group;     /* samples per pre_a/pre_b group */
     int32_t mask_group;
     int32_t act_relu;      /* 1: relu after scale+bias, before the residual add (F.relu(conv(..)), common.py:424) */
+    /* -- ABI 3 -- */
+    int32_t w_cin;         /* weights are the input-channel slice [w_coff, w_coff+Cin) of a [Cout][KD][KH][KW][w_cin] tensor
+                              (the x / h halves of a ConvGRU conv applied to torch.cat([x, h], 1): ConvGRU.py:69,79); 0: dense */
+    int32_t w_coff;
+    int32_t epi_mode;      /* DGMR_EPI_*: fused tail after scale+bias (replaces act_relu / residual / mask when != PLAIN) */
+    int32_t ksplit;        /* out: ignored on input; the library splits K itself when splitk_ws is given and the grid is small */
+    const float* gru_h;    /* [M][Cout] previous hidden state (GRU modes) */
+    const float* gru_pu;   /* [M][Cout] update-gate pre-activation (DGMR_EPI_GRU_BLEND) */
+    float* pre_out;        /* [M][Cout] receives the pre-activation (scale+bias applied) in the GRU modes (needed by the backward) */
+    float* splitk_ws;      /* NULL, or scratch for split-K partial sums */
+    int64_t splitk_ws_bytes;
 } dgmr_conv_args;
+
+#define DGMR_EPI_PLAIN 0
+#define DGMR_EPI_GRU_GATE 1  /* pre_out = v ; y = sigmoid(v) * gru_h                              (ConvGRU.py:69-71,78) */
+#define DGMR_EPI_GRU_BLEND 2 /* pre_out = v ; y = s*gru_h + (1-s)*relu(v), s = sigmoid(gru_pu)     (ConvGRU.py:80-84) */
 
 /* y = act(conv(pre(x), w) (+addend) *scale + bias) (+residual), masked.  Forward AND data-gradient (the
  * latter with dgmr_conv_flip_weights()'ed weights and dy as x). */
 int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream);
 
-/* w_t[Cin][KD][KH][KW][Cout] = w[Cout][KD-1-kd][KH-1-kh][KW-1-kw][Cin]: weights of the transposed
- * (data-gradient) convolution. */
-int dgmr_conv_flip_weights(const float* w, float* w_t, int Cout, int Cin, int KD, int KH, int KW, void* stream);
+/* w_t[Cin][KD][KH][KW][Cout] = w[Cout][KD-1-kd][KH-1-kh][KW-1-kw][w_coff + ci]: weights of the transposed
+ * (data-gradient) convolution, for the input-channel slice [w_coff, w_coff+Cin) of a tensor with w_cin input channels
+ * (w_cin == 0: dense, w_cin = Cin). */
+int dgmr_conv_flip_weights(const float* w, float* w_t, int Cout, int Cin, int KD, int KH, int KW, int w_cin, int w_coff,
+                           void* stream);
 
 typedef struct dgmr_wgrad_args {
     const float* x;      /* forward input, as in dgmr_conv_args (pre_* / upsample applied on load) */
@@ -99,6 +116,11 @@ int dgmr_conv_wgrad_nsplit(int M, int Cout, int K, int groups);
  * skipped; otherwise [groups], zeroed by the caller / the previous finalize).  groups <= 32. */
 int dgmr_wgrad_reduce(const float* partial, int nsplit, int groups, int64_t numel, const float* w, const float* scale, float* g,
                       float* dot, void* stream);
+/* Same for a weight gradient computed on an input-channel slice: partial is [nsplit][Cout][taps][cin_slice]; element
+ * (co, tap, ci) is written to / dotted with index (co*taps + tap)*cin_total + coff + ci of g / w.  Two calls (x and h halves)
+ * fill one g and accumulate one set of dots. */
+int dgmr_wgrad_reduce_slice(const float* partial, int nsplit, int groups, int Cout, int taps, int cin_slice, int cin_total, int coff,
+                            const float* w, const float* scale, float* g, float* dot, void* stream);
 /* Spectral-norm chain rule (torch/nn/utils/parametrizations.py:515-521), summed over the `groups` calls of the module that
  * one batched launch covered (g already carries the 1/sigma_q factors, see dgmr_wgrad_reduce):
  *   gw[i][k] (+)= g[i][k] - sum_q dot[q]*inv_sigma[q]^2 * u[q][i]*v[q][perm(k)],  then dot[0..groups) = 0.

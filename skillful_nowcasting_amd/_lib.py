@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdgmr_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 P = c_void_p  # every device pointer and the stream travel as void*
 
@@ -25,6 +25,8 @@ class ConvArgs(Structure):
         ("N", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
         ("KD", c_int32), ("KH", c_int32), ("KW", c_int32), ("upsample", c_int32), ("pre_relu", c_int32),
         ("scale_group", c_int32), ("pre_group", c_int32), ("mask_group", c_int32), ("act_relu", c_int32),
+        ("w_cin", c_int32), ("w_coff", c_int32), ("epi_mode", c_int32), ("ksplit", c_int32),
+        ("gru_h", P), ("gru_pu", P), ("pre_out", P), ("splitk_ws", P), ("splitk_ws_bytes", c_int64),
     ]
 
 
@@ -43,10 +45,11 @@ i, f, L = c_int, c_float, c_int64
 # name -> argtypes (every function returns int except the two noted below); must match include/dgmr_hip.h
 SIGNATURES = {
     "dgmr_conv_fwd": [POINTER(ConvArgs), P],
-    "dgmr_conv_flip_weights": [P, P, i, i, i, i, i, P],
+    "dgmr_conv_flip_weights": [P, P, i, i, i, i, i, i, i, P],
     "dgmr_conv_wgrad": [POINTER(WgradArgs), P],
     "dgmr_conv_wgrad_nsplit": [i, i, i, i],
     "dgmr_wgrad_reduce": [P, i, i, L, P, P, P, P, P],
+    "dgmr_wgrad_reduce_slice": [P, i, i, i, i, i, i, i, P, P, P, P, P],
     "dgmr_sn_wgrad_finalize": [P, P, P, P, P, P, i, i, i, i, i, P],
     "dgmr_spectral_sigma": [P, P, P, P, P, P, P, P, i, i, i, f, i, P],
     "dgmr_spectral_sigma_seq": [P, P, P, P, P, P, P, P, P, i, i, i, f, i, P],

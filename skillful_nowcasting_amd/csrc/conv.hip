@@ -92,8 +92,39 @@ __device__ __forceinline__ f32x4 finish_a(f32x4 v, bool valid, const float* __re
     return v;
 }
 
+__device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// One output element: (acc + addend) * scale + bias, then the fused tail selected by epi_mode.  Shared by the in-kernel
+// epilogue and the split-K reduce kernel.
+__device__ __forceinline__ void epilogue_store(const dgmr_conv_args& p, float v, int n, int col, size_t idx) {
+    if (p.addend) v += p.addend[idx];
+    if (p.scale) v *= p.scale[n / p.scale_group];
+    if (p.bias) v += p.bias[col];
+    if (p.epi_mode == DGMR_EPI_GRU_GATE) {  // r * h with r = sigmoid(pre)   (ConvGRU.py:69-71,78)
+        p.pre_out[idx] = v;
+        v = sigmoid_(v) * p.gru_h[idx];
+    } else if (p.epi_mode == DGMR_EPI_GRU_BLEND) {  // u*h + (1-u)*relu(pre_c)   (ConvGRU.py:80-84)
+        p.pre_out[idx] = v;
+        const float s = sigmoid_(p.gru_pu[idx]);
+        v = s * p.gru_h[idx] + (1.f - s) * fmaxf(v, 0.f);
+    } else {
+        if (p.act_relu) v = fmaxf(v, 0.f);
+        if (p.residual) v += p.residual[idx];
+        if (p.mask_src) {
+            float ms = p.mask_src[idx];
+            if (p.mask_a) {
+                const size_t g = (size_t)(n / p.mask_group) * p.Cout + col;
+                ms = fmaf(ms, p.mask_a[g], p.mask_b[g]);
+            }
+            v = ms > 0.f ? v : 0.f;
+        }
+    }
+    p.y[idx] = v;
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_conv_args p, const int M, const int Ktot) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_conv_args p, const int M, const int Ktot,
+                                                                   const int kt_per_split) {
     constexpr int NT = 64 * WM * WN;
     constexpr int LD = BK + 4;
     constexpr int KQ = BK / 4;
@@ -114,6 +145,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_con
 
     const int KHW = p.KH * p.KW;
     const int pd = p.KD >> 1, ph = p.KH >> 1, pw = p.KW >> 1;
+    const size_t wrow = (size_t)p.KD * KHW * p.w_cin;  // weight row stride (floats)
 
     RowCoord rc[AP];
     bool rok[AP];
@@ -133,11 +165,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_con
         cur_ci = kp.ci;
 #pragma unroll
         for (int i = 0; i < AP; ++i) ra[i] = issue_a(p.x, rc[i], rok[i], kp, p.D, p.H, p.W, p.Cin, p.upsample, va[i]);
+        // weights may be an input-channel slice [w_coff, w_coff + Cin) of a [Cout][taps][w_cin] tensor (ConvGRU x / h parts)
+        const int tap = k / p.Cin;
+        const size_t wk = (size_t)tap * p.w_cin + p.w_coff + kp.ci;
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             const int co = n0 + i * RPP + lrow;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (co < p.Cout && k < Ktot) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)co * Ktot + k);
+            if (co < p.Cout && k < Ktot) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)co * wrow + wk);
             rb[i] = v;
         }
     };
@@ -158,12 +193,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (Ktot + BK - 1) / BK;
-    load_tiles(0);
+    // split-K: blockIdx.z owns k tiles [kt0, kt1); partial sums go to the workspace, the reduce kernel finishes
+    const int nk_all = (Ktot + BK - 1) / BK;
+    const int kt0 = blockIdx.z * kt_per_split;
+    const int nk = min(nk_all, kt0 + kt_per_split);
+    load_tiles(kt0);
     store_tiles(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
         if (kt + 1 < nk) load_tiles(kt + 1);
         const float* Ab = As + cur * BM * LD + (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
         const float* Bb = Bs + cur * BN * LD + (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
@@ -186,8 +224,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_con
         __syncthreads();
     }
 
-    // Epilogue: (acc + addend) * scale + bias + residual, masked.  Lane = output channel, 16 rows per MFMA block.
+    // Epilogue.  Lane = output channel, 16 rows per MFMA block.
     const int DHW = p.D * p.H * p.W;
+    float* ws = gridDim.z > 1 ? p.splitk_ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -195,29 +234,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_con
             const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row >= M) continue;
             const int n = row / DHW;
-            const float sc = p.scale ? p.scale[n / p.scale_group] : 1.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
                 if (col >= p.Cout) continue;
                 const size_t idx = (size_t)row * p.Cout + col;
-                float v = acc[i][j][r];
-                if (p.addend) v += p.addend[idx];
-                v *= sc;
-                if (p.bias) v += p.bias[col];
-                if (p.act_relu) v = fmaxf(v, 0.f);
-                if (p.residual) v += p.residual[idx];
-                if (p.mask_src) {
-                    float ms = p.mask_src[idx];
-                    if (p.mask_a) {
-                        const size_t g = (size_t)(n / p.mask_group) * p.Cout + col;
-                        ms = fmaf(ms, p.mask_a[g], p.mask_b[g]);
-                    }
-                    v = ms > 0.f ? v : 0.f;
-                }
-                p.y[idx] = v;
+                if (ws) ws[idx] = acc[i][j][r];
+                else epilogue_store(p, acc[i][j][r], n, col, idx);
             }
         }
+    }
+}
+
+// y = epilogue(sum_z ws[z]) for a split-K launch; one thread per output element (these problems are small by construction).
+__global__ void splitk_reduce_kernel(const dgmr_conv_args p, const int M, const int S) {
+    const size_t total = (size_t)M * p.Cout;
+    const int DHW = p.D * p.H * p.W;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int z = 0; z < S; ++z) v += p.splitk_ws[(size_t)z * total + idx];
+        const int row = idx / p.Cout, col = idx - (size_t)row * p.Cout;
+        epilogue_store(p, v, row / DHW, col, idx);
     }
 }
 
@@ -275,8 +312,17 @@ const char* const kVariantNames[V_COUNT] = {
 
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_conv(const dgmr_conv_args& a, int M, int Ktot, hipStream_t s) {
-    dim3 grid((M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(64 * WM * WN), 0, s, a, M, Ktot);
+    const int nk = (Ktot + BK - 1) / BK;
+    const int S = a.ksplit > 1 ? a.ksplit : 1;
+    const int per = (nk + S - 1) / S;
+    const int Seff = (nk + per - 1) / per;  // no empty splits
+    dim3 grid((M + BM - 1) / BM, (a.Cout + BN - 1) / BN, Seff);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(64 * WM * WN), 0, s, a, M, Ktot, per);
+    if (Seff > 1) {
+        const size_t total = (size_t)M * a.Cout;
+        const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a, M, Seff);
+    }
     return 0;
 }
 
@@ -395,30 +441,40 @@ __global__ __launch_bounds__(64 * WI * WJ) void conv_wgrad_kernel(const dgmr_wgr
         }
 }
 
-__global__ void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int taps) {
-    // wt[ci][taps-1-t][co] = w[co][t][ci]; one thread per (ci, t, co) destination element, co fastest.
+__global__ void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int taps, int w_cin,
+                                    int w_coff) {
+    // wt[ci][taps-1-t][co] = w[co][t][w_coff + ci]; one thread per (ci, t, co) destination element, co fastest.
     const size_t total = (size_t)Cout * Cin * taps;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int co = i % Cout;
         const size_t r = i / Cout;
         const int t = r % taps;
         const int ci = r / taps;
-        wt[i] = w[((size_t)co * taps + (taps - 1 - t)) * Cin + ci];
+        wt[i] = w[((size_t)co * taps + (taps - 1 - t)) * w_cin + w_coff + ci];
     }
 }
 
 // g[i] = sum_grp scale[grp] * P_grp[i],  dot[grp] += <P_grp, w>   with P_grp = sum of the group's slabs.
 constexpr int WG_MAX_GROUPS = 32;
+// Partial element i = (co, tap, ci) of a [Cout][taps][cs] slab lands at j = (co*taps + tap)*ct + coff + ci of g / w
+// (cs == ct, coff == 0: j == i).
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int groups, size_t numel,
                                     const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ g,
-                                    float* __restrict__ dot) {
+                                    float* __restrict__ dot, int taps, int cs, int ct, int coff) {
     __shared__ float red[WG_MAX_GROUPS][4];
     const int spg = nsplit / groups;
+    const size_t rowlen = (size_t)taps * cs;
     float d[WG_MAX_GROUPS];
 #pragma unroll
     for (int q = 0; q < WG_MAX_GROUPS; ++q) d[q] = 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
-        const float wi = w ? w[i] : 0.f;
+        size_t j = i;
+        if (cs != ct) {
+            const size_t co = i / rowlen, r = i - co * rowlen;
+            const size_t tap = r / cs, ci = r - tap * cs;
+            j = (co * taps + tap) * ct + coff + ci;
+        }
+        const float wi = w ? w[j] : 0.f;
         float tot = 0.f;
 #pragma unroll
         for (int q = 0; q < WG_MAX_GROUPS; ++q) {
@@ -429,7 +485,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
                 d[q] = fmaf(s, wi, d[q]);
             }
         }
-        g[i] = tot;
+        g[j] = tot;
     }
     if (dot) {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -483,10 +539,18 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     DGMR_CHECK_ARG((a->pre_a == nullptr) == (a->pre_b == nullptr), "dgmr_conv_fwd: pre_a/pre_b must come together");
     const int64_t M64 = (int64_t)a->N * a->D * a->H * a->W;
     DGMR_CHECK_ARG(M64 > 0 && M64 < (1ll << 31), "dgmr_conv_fwd: M=%lld out of range", (long long)M64);
+    DGMR_CHECK_ARG(a->epi_mode == DGMR_EPI_PLAIN || (a->pre_out && a->gru_h && (a->epi_mode != DGMR_EPI_GRU_BLEND || a->gru_pu)),
+                   "dgmr_conv_fwd: epi_mode %d needs pre_out / gru_h / gru_pu", a->epi_mode);
+    DGMR_CHECK_ARG(a->w_cin == 0 || (a->w_cin >= a->w_coff + a->Cin && a->w_coff >= 0 && a->w_coff % 4 == 0 && a->w_cin % 4 == 0),
+                   "dgmr_conv_fwd: weight slice [%d, %d) of %d channels is invalid", a->w_coff, a->w_coff + a->Cin, a->w_cin);
     dgmr_conv_args p = *a;
     if (p.scale_group < 1) p.scale_group = 1;
     if (p.pre_group < 1) p.pre_group = 1;
     if (p.mask_group < 1) p.mask_group = 1;
+    if (p.w_cin == 0) {
+        p.w_cin = p.Cin;
+        p.w_coff = 0;
+    }
     const int M = (int)M64, Ktot = a->KD * a->KH * a->KW * a->Cin;
     hipStream_t s = (hipStream_t)stream;
     const int C = a->Cout;
@@ -504,6 +568,23 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     else if (bn == 96) variant = V_F128x96;
     else if (bn == 64) variant = wgs128 >= 256 ? V_F128x64 : V_F64x64;
     else variant = V_F128x32;
+    // Split-K when the output grid cannot fill the 256 CUs (ConvGRU steps, latent stack, deep discriminator layers): the k
+    // loop is the only parallelism left.  Needs a workspace; chosen so that grid * ksplit ~ 512 workgroups, >= 4 k-tiles each.
+    p.ksplit = 1;
+    if (p.splitk_ws && p.splitk_ws_bytes > 0) {
+        const int bm = variant == V_F64x64 ? 64 : 128;
+        const int bnv = variant == V_F64x64 ? 64 : bn;
+        const int64_t wgs = ((M64 + bm - 1) / bm) * ((C + bnv - 1) / bnv);
+        const int nk = (Ktot + 31) / 32;
+        if (wgs < 192 && nk >= 8) {
+            int64_t S = 512 / wgs;
+            if (S > nk / 4) S = nk / 4;
+            const int64_t cap = p.splitk_ws_bytes / ((int64_t)M64 * C * 4);
+            if (S > cap) S = cap;
+            if (S > 64) S = 64;
+            if (S > 1) p.ksplit = (int)S;
+        }
+    }
     {
         ProfScope ps(variant, flops, s);
         switch (variant) {
@@ -518,12 +599,18 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     return 0;
 }
 
-extern "C" int dgmr_conv_flip_weights(const float* w, float* w_t, int Cout, int Cin, int KD, int KH, int KW, void* stream) {
+extern "C" int dgmr_conv_flip_weights(const float* w, float* w_t, int Cout, int Cin, int KD, int KH, int KW, int w_cin, int w_coff,
+                                      void* stream) {
     DGMR_CHECK_ARG(w && w_t, "dgmr_conv_flip_weights: null pointer");
+    if (w_cin == 0) {
+        w_cin = Cin;
+        w_coff = 0;
+    }
+    DGMR_CHECK_ARG(w_coff >= 0 && w_coff + Cin <= w_cin, "dgmr_conv_flip_weights: bad slice");
     const int taps = KD * KH * KW;
     const size_t total = (size_t)Cout * Cin * taps;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(flip_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, w_t, Cout, Cin, taps);
+    hipLaunchKernelGGL(flip_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, w_t, Cout, Cin, taps, w_cin, w_coff);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
@@ -584,7 +671,24 @@ extern "C" int dgmr_wgrad_reduce(const float* partial, int nsplit, int groups, i
     DGMR_CHECK_ARG(!dot || w, "dgmr_wgrad_reduce: dot needs w");
     const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 1024);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups, (size_t)numel,
-                       w, scale, g, dot);
+                       w, scale, g, dot, 1, 1, 1, 0);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_wgrad_reduce_slice(const float* partial, int nsplit, int groups, int Cout, int taps, int cin_slice, int cin_total,
+                                       int coff, const float* w, const float* scale, float* g, float* dot, void* stream) {
+    DGMR_CHECK_ARG(partial && g && Cout > 0 && taps > 0 && cin_slice > 0 && nsplit >= 1, "dgmr_wgrad_reduce_slice: bad args");
+    if (groups < 1) groups = 1;
+    DGMR_CHECK_ARG(groups <= WG_MAX_GROUPS && nsplit % groups == 0, "dgmr_wgrad_reduce_slice: groups=%d must divide nsplit=%d", groups,
+                   nsplit);
+    DGMR_CHECK_ARG(coff >= 0 && coff + cin_slice <= cin_total, "dgmr_wgrad_reduce_slice: bad slice");
+    DGMR_CHECK_ARG(!dot || w, "dgmr_wgrad_reduce_slice: dot needs w");
+    const int64_t numel = (int64_t)Cout * taps * cin_slice;
+    const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 1024);
+    // cs == ct would short-circuit the index map: force the mapped path whenever this is a true slice
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups, (size_t)numel,
+                       w, scale, g, dot, taps, cin_slice, cin_total, coff);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

@@ -41,24 +41,21 @@ class Sampler(torch.nn.Module, PyTorchModelHubMixin):
 
     def forward(self, conditioning_states: List[torch.Tensor], latent_dim: torch.Tensor) -> torch.Tensor:
         init_states = conditioning_states
-        latent_dim = ops.repeat_batch(latent_dim, init_states[0].shape[0])
-        hidden_states = [latent_dim] * self.forecast_steps
+        T = self.forecast_steps
+        # `[latent] * T` (generators.py:146-149): the first ConvGRU sees the same latent at every step
+        h = ops.repeat_batch(latent_dim, T * init_states[0].shape[0])
         levels = ((self.convGRU1, self.gru_conv_1x1, self.g1, self.up_g1),
                   (self.convGRU2, self.gru_conv_1x1_2, self.g2, self.up_g2),
                   (self.convGRU3, self.gru_conv_1x1_3, self.g3, self.up_g3),
                   (self.convGRU4, self.gru_conv_1x1_4, self.g4, self.up_g4))
-        T = self.forecast_steps
         for lvl, (gru, c11, g, upg) in enumerate(levels):
             # only the ConvGRU is a true recurrence; its T outputs then travel as ONE time-major batch [T*B, C, h, w] through
             # the 1x1 conv, the G-block and the upsampling G-block (one launch per conv instead of T), every forecast step
             # keeping its own spectral-norm sigma and BatchNorm batch statistics exactly as the reference's T calls do
-            hidden_states = gru.forward_list(hidden_states, init_states[3 - lvl])
-            h = ops.stack_batch(hidden_states)
+            h = gru.forward_batched(h, init_states[3 - lvl], T)
             h = c11(h, calls=T)
             h = g(h, calls=T)
             h = upg(h, calls=T)
-            if lvl < 3:
-                hidden_states = ops.unstack_batch(h, T)
         # relu(bn(h)) folded into the 1x1 conv's operand load; PixelShuffle + stack in one layout pass
         h = self.conv_1x1(h, bn=self.bn.prepare(h, T), calls=T)
         return ops.d2s_frames(h, T)

@@ -40,19 +40,18 @@ class ConvGRU(torch.nn.Module):
         super().__init__()
         self.cell = ConvGRUCell(input_channels, output_channels, kernel_size, sn_eps)
 
-    def forward_list(self, x, hidden_state=None) -> List[torch.Tensor]:
-        outputs = []
-        steps = len(x)
-        # the spectral-norm iterations of the cell's three convs do not depend on the data: all `steps` of them are drawn up front
-        # in one pass per conv (dgmr_spectral_sigma_seq), then step t uses record t
+    def forward_batched(self, x_all: torch.Tensor, hidden_state: torch.Tensor, steps: int) -> torch.Tensor:
+        """All `steps` inputs as one time-major batch [steps*B, C, h, w] -> all outputs [steps*B, C_out, h, w]."""
         cell = self.cell
-        seqs = [c._sigma(steps) for c in (cell.read_gate_conv, cell.update_gate_conv, cell.output_conv)]
-        for step in range(steps):
-            # groups == 1: a single step, or eval mode (no iteration: every step sees the same sigma)
-            sn = tuple(q.at(step) if q.groups > 1 else q for q in seqs)
-            output, hidden_state = cell(x[step], hidden_state, sn)
-            outputs.append(output)
-        return outputs
+        convs = (cell.read_gate_conv, cell.update_gate_conv, cell.output_conv)
+        # the spectral-norm iterations of the three convs do not depend on the data: all `steps` calls are drawn up front
+        seqs = tuple(c._sigma(steps) for c in convs)
+        params = tuple(p for c in convs for p in (c.weight_orig, c.bias))
+        return ops.conv_gru(x_all, hidden_state, params, seqs, steps)
+
+    def forward_list(self, x, hidden_state=None) -> List[torch.Tensor]:
+        steps = len(x)
+        return ops.unstack_batch(self.forward_batched(ops.stack_batch(list(x)), hidden_state, steps), steps)
 
     def forward(self, x, hidden_state=None) -> torch.Tensor:
         return torch.stack(self.forward_list(x, hidden_state), dim=0)

@@ -39,8 +39,24 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _p(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+def _p(t):
+    """Device pointer of a tensor (None -> NULL); raw integer addresses pass through (slices of step buffers)."""
+    if t is None or isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+_SPLITK_WS = {}
+SPLITK_WS_BYTES = 64 << 20
+
+
+def _splitk_ws(device) -> torch.Tensor:
+    """Per-device scratch for split-K partial sums (launches are stream-ordered, so one buffer serves every conv)."""
+    ws = _SPLITK_WS.get(device)
+    if ws is None:
+        ws = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
+        _SPLITK_WS[device] = ws
+    return ws
 
 
 def require_hip(t: torch.Tensor, what: str = "input"):
@@ -213,18 +229,20 @@ class ConvSpec:
 _flip_cache = {}
 
 
-def _flipped_weight(w: torch.Tensor) -> torch.Tensor:
-    """Weights of the transposed conv, cached until the parameter changes."""
-    key = id(w)
+def _flipped_weight(w: torch.Tensor, coff: int = 0, cin: Optional[int] = None) -> torch.Tensor:
+    """Weights of the transposed conv (optionally of the input-channel slice [coff, coff+cin)), cached until the parameter changes."""
+    cout, cin_total = w.shape[0], w.shape[1]
+    if cin is None:
+        cin = cin_total
+    key = (id(w), coff, cin)
     tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr())
     hit = _flip_cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
-    cout, cin = w.shape[0], w.shape[1]
     ks = list(w.shape[2:])
     kd, kh, kw = ([1] + ks) if len(ks) == 2 else ks
-    wt = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
-    call("dgmr_conv_flip_weights", _p(w), _p(wt), cout, cin, kd, kh, kw, _stream())
+    wt = torch.empty(cout * cin * kd * kh * kw, device=w.device, dtype=torch.float32)
+    call("dgmr_conv_flip_weights", _p(w), _p(wt), cout, cin, kd, kh, kw, cin_total, coff, _stream())
     _flip_cache[key] = (tag, wt)
     return wt
 
@@ -234,10 +252,18 @@ def _kdims(w: torch.Tensor):
     return tuple([1] + ks) if len(ks) == 2 else tuple(ks)
 
 
+EPI_PLAIN, EPI_GRU_GATE, EPI_GRU_BLEND = 0, 1, 2
+
+
 def _launch_conv(x, w_ptr, bias, scale, y, n, d, h, w_, cin, cout, kd, kh, kw, *, upsample=False, pre_relu=False, pre_a=None,
                  pre_b=None, pre_group=1, residual=None, addend=None, mask_src=None, mask_a=None, mask_b=None, mask_group=1,
-                 scale_group=None, act_relu=False):
+                 scale_group=None, act_relu=False, w_cin=0, w_coff=0, epi_mode=EPI_PLAIN, gru_h=None, gru_pu=None, pre_out=None,
+                 device=None):
     a = ConvArgs()
+    a.w_cin, a.w_coff, a.epi_mode = w_cin, w_coff, epi_mode
+    a.gru_h, a.gru_pu, a.pre_out = _p(gru_h), _p(gru_pu), _p(pre_out)
+    ws = _splitk_ws(device if device is not None else (x.device if isinstance(x, torch.Tensor) else y.device))
+    a.splitk_ws, a.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
     a.x, a.w, a.bias, a.scale = _p(x), w_ptr, _p(bias), _p(scale)
     a.pre_a, a.pre_b, a.addend, a.residual = _p(pre_a), _p(pre_b), _p(addend), _p(residual)
     a.mask_src, a.mask_a, a.mask_b, a.y = _p(mask_src), _p(mask_a), _p(mask_b), _p(y)
@@ -602,6 +628,155 @@ class GruBlendFn(Function):
 
 gru_gate = GruGateFn.apply
 gru_blend = GruBlendFn.apply
+
+
+class ConvGRUFn(Function):
+    """A whole ConvGRU layer over T steps (dgmr/layers/ConvGRU.py:57-85,102-111) with hand-written backward-through-time.
+
+    The reference convolves torch.cat([x_t, h]) three times per step.  Convolution is linear in its input channels, so each
+    conv splits into an x part and an h part.  The x parts of all T steps do not depend on the recurrence: they are three
+    batched launches up front (M = T*B*h*w rows).  Only the h parts (1/3 of K) stay on the sequential path, as three launches
+    per step whose epilogues carry the gating:  r*h = sigmoid(pre_r)*h  and  h' = u*h + (1-u)*relu(pre_c)  — no torch.cat, no
+    separate gate kernels.  Small-M steps are split over K inside the library to fill the chip.  The backward sweeps t = T-1..0
+    with three data-gradient convs per step; the x-part data gradients and all weight gradients (with the per-step
+    spectral-norm chain rule) are batched over T afterwards.
+    """
+
+    @staticmethod
+    def forward(ctx, x_all, h0, params, seqs, steps: int):
+        require_hip(x_all)
+        require_hip(h0, "initial state")
+        x_all, h0 = to_cl(x_all), to_cl(h0)
+        wr, br, wu, bu, wc, bc = params
+        T = steps
+        tb, cx, hh, ww = x_all.shape
+        b, ch = h0.shape[0], h0.shape[1]
+        if tb != T * b or wr.shape[1] != cx + ch or wr.shape[0] != ch:
+            raise RuntimeError(f"ConvGRU: x {tuple(x_all.shape)} / h0 {tuple(h0.shape)} / weight {tuple(wr.shape)} do not fit T={T}")
+        kh, kw = wr.shape[2], wr.shape[3]
+        dev = x_all.device
+        n_step = b * ch * hh * ww  # floats per step tensor
+        ct = cx + ch
+
+        def step_ptr(t_: torch.Tensor, t: int) -> int:
+            return t_.data_ptr() + 4 * n_step * t
+
+        def scale_ptr(sn: SNCall, t: int) -> int:
+            return sn.inv_sigma.data_ptr() + (4 * t if sn.groups > 1 else 0)
+
+        # x parts of the three convs for every step: raw sums (scale and bias are applied with the h part)
+        xparts = []
+        for w in (wr, wu, wc):
+            xp = empty_cl((tb, ch, hh, ww), x_all)
+            _launch_conv(x_all, _p(w), None, None, xp, tb, 1, hh, ww, cx, ch, 1, kh, kw, w_cin=ct, w_coff=0)
+            xparts.append(xp)
+        xr, xu, xc = xparts
+        buf = empty_cl(((T + 1) * b, ch, hh, ww), x_all)  # h_{-1} = h0, h_0, ..., h_{T-1}
+        _copy(_p(h0), _p(buf), n_step)
+        pr, pu, pc, rh = (empty_cl((tb, ch, hh, ww), x_all) for _ in range(4))
+        sr, su, sc = seqs
+        for t in range(T):
+            hp, out = step_ptr(buf, t), step_ptr(buf, t + 1)
+            _launch_conv(hp, _p(wr), br, scale_ptr(sr, t), step_ptr(rh, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
+                         addend=step_ptr(xr, t), epi_mode=EPI_GRU_GATE, gru_h=hp, pre_out=step_ptr(pr, t), device=dev)
+            _launch_conv(hp, _p(wu), bu, scale_ptr(su, t), step_ptr(pu, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
+                         addend=step_ptr(xu, t), device=dev)
+            _launch_conv(step_ptr(rh, t), _p(wc), bc, scale_ptr(sc, t), out, b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
+                         addend=step_ptr(xc, t), epi_mode=EPI_GRU_BLEND, gru_h=hp, gru_pu=step_ptr(pu, t), pre_out=step_ptr(pc, t),
+                         device=dev)
+        ctx.params = params
+        ctx.geom = (T, b, cx, ch, hh, ww, kh, kw)
+        ctx.groups = tuple(q.groups for q in seqs)
+        ctx.save_for_backward(x_all, buf, pr, pu, pc, rh, sr.inv_sigma, sr.u, sr.v, su.inv_sigma, su.u, su.v, sc.inv_sigma, sc.u, sc.v)
+        return buf[b:]
+
+    @staticmethod
+    def backward(ctx, dout_all):
+        (x_all, buf, pr, pu, pc, rh, isr, ur, vr, isu, uu, vu, isc, uc, vc) = ctx.saved_tensors
+        wr, br, wu, bu, wc, bc = ctx.params
+        T, b, cx, ch, hh, ww, kh, kw = ctx.geom
+        gr, gu, gc = ctx.groups
+        dout_all = to_cl(dout_all)
+        dev = dout_all.device
+        st = _stream()
+        tb = T * b
+        n_step = b * ch * hh * ww
+        ct = cx + ch
+        taps = kh * kw
+
+        def step_ptr(t_: torch.Tensor, t: int) -> int:
+            return t_.data_ptr() + 4 * n_step * t
+
+        def scale_ptr(inv_sigma: torch.Tensor, groups: int, t: int) -> int:
+            return inv_sigma.data_ptr() + (4 * t if groups > 1 else 0)
+
+        dpr, dpu, dpc = (empty_cl((tb, ch, hh, ww), dout_all) for _ in range(3))
+        # scratch of one step each
+        d_tot, dh_a, dh_b, d_rh, c1, c2 = (torch.empty(n_step, device=dev, dtype=torch.float32) for _ in range(6))
+        dh_next = torch.empty(n_step, device=dev, dtype=torch.float32)
+        wt_rh, wt_uh, wt_ch = (_flipped_weight(w, cx, ch) for w in (wr, wu, wc))
+        have_next = False
+        for t in reversed(range(T)):
+            hp = step_ptr(buf, t)
+            if have_next:
+                call("dgmr_axpby", step_ptr(dout_all, t), _p(dh_next), _p(d_tot), 1.0, 1.0, n_step, st)
+                d = _p(d_tot)
+            else:
+                d = step_ptr(dout_all, t)
+            call("dgmr_gru_blend_bwd", d, step_ptr(pu, t), hp, step_ptr(pc, t), step_ptr(dpu, t), _p(dh_a), step_ptr(dpc, t), n_step, st)
+            # through the candidate conv to r*h, then through the read gate
+            _launch_conv(step_ptr(dpc, t), _p(wt_ch), None, scale_ptr(isc, gc, t), d_rh, b, 1, hh, ww, ch, ch, 1, kh, kw, device=dev)
+            call("dgmr_gru_gate_bwd", _p(d_rh), step_ptr(pr, t), hp, step_ptr(dpr, t), _p(dh_b), n_step, st)
+            # dh = dh_a + dh_b + convT(dpr / sigma_r, W_rh) + convT(dpu / sigma_u, W_uh)
+            _launch_conv(step_ptr(dpr, t), _p(wt_rh), None, scale_ptr(isr, gr, t), c1, b, 1, hh, ww, ch, ch, 1, kh, kw, residual=dh_a,
+                         device=dev)
+            _launch_conv(step_ptr(dpu, t), _p(wt_uh), None, scale_ptr(isu, gu, t), c2, b, 1, hh, ww, ch, ch, 1, kh, kw, residual=c1,
+                         device=dev)
+            call("dgmr_axpby", _p(c2), _p(dh_b), _p(dh_next), 1.0, 1.0, n_step, st)
+            have_next = True
+        dh0 = None
+        if ctx.needs_input_grad[1]:
+            dh0 = empty_cl((b, ch, hh, ww), dout_all)
+            _copy(_p(dh_next), _p(dh0), n_step)
+        # ---- x-part data gradient, batched over the T steps (each step with its own 1/sigma) ----
+        dx_all = None
+        if ctx.needs_input_grad[0]:
+            dx_all = empty_cl((tb, cx, hh, ww), dout_all)
+            tmp = empty_cl((tb, cx, hh, ww), dout_all)
+            chain = ((dpr, wr, isr, gr, None, tmp), (dpu, wu, isu, gu, tmp, dx_all), (dpc, wc, isc, gc, dx_all, tmp))
+            for dp, w, inv_s, g_, res, dst in chain:
+                _launch_conv(dp, _p(_flipped_weight(w, 0, cx)), None, inv_s, dst, tb, 1, hh, ww, ch, cx, 1, kh, kw, residual=res,
+                             scale_group=tb // g_)
+            dx_all = tmp
+        # ---- weight / bias gradients, batched over T ----
+        hprev_all = buf  # rows [0, T*B) are h_{-1} .. h_{T-2}
+        for w, bias, dp, inv_s, u_, v_, g_, hsrc in ((wr, br, dpr, isr, ur, vr, gr, hprev_all), (wu, bu, dpu, isu, uu, vu, gu, hprev_all),
+                                                     (wc, bc, dpc, isc, uc, vc, gc, rh)):
+            m = tb * hh * ww
+            if bias is not None and bias.requires_grad:
+                tmpd = torch.empty(2 * ch, device=dev, dtype=torch.float64)
+                call("dgmr_colsum", _p(dp), _p(grad_buffer(bias)), _p(tmpd), m, ch, 1, st)
+            if not w.requires_grad:
+                continue
+            g = torch.empty(ch * taps * ct, device=dev, dtype=torch.float32)
+            dot = torch.zeros(g_, device=dev, dtype=torch.float32)
+            for src, cin, coff in ((x_all, cx, 0), (hsrc, ch, cx)):
+                k = taps * cin
+                ns = call_nsplit(m, ch, k, g_)
+                partial = torch.empty(ns * ch * k, device=dev, dtype=torch.float32)
+                wa = WgradArgs()
+                wa.x, wa.dy, wa.partial = _p(src), _p(dp), _p(partial)
+                wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = tb, 1, hh, ww, cin, ch
+                wa.KD, wa.KH, wa.KW = 1, kh, kw
+                wa.upsample, wa.pre_relu, wa.pre_group, wa.nsplit, wa.groups = 0, 0, 1, ns, g_
+                call("dgmr_conv_wgrad", ctypes.byref(wa), st)
+                call("dgmr_wgrad_reduce_slice", _p(partial), ns, g_, ch, taps, cin, ct, coff, _p(w), _p(inv_s), _p(g), _p(dot), st)
+            call("dgmr_sn_wgrad_finalize", _p(g), _p(grad_buffer(w)), _p(dot), _p(inv_s), _p(u_), _p(v_), ch, ct, taps, g_, 1, st)
+        return dx_all, dh0, None, None, None
+
+
+def conv_gru(x_all, h0, params, seqs, steps: int):
+    return ConvGRUFn.apply(x_all, h0, params, seqs, steps)
 
 
 # ---------------------------------------------------------------------------------------------------
