@@ -150,6 +150,27 @@ int dgmr_spectral_sigma_seq(const float* w, const float* gram, float* u, float* 
                             float* inv_sigma, float* scratch, float* tmp, int Cout, int Cin, int taps, float eps, int T,
                             void* stream);
 
+/* The same for many modules at once: every spectral-norm call sequence of one generator / discriminator forward in three
+ * launches (the iterations do not depend on activations; the chains of all modules run concurrently, one workgroup each).
+ * descs: DEVICE array of n descriptors.  Outputs live in one caller-allocated float arena (offsets in floats):
+ * inv_sigma[T], u_hist[T][Cout], v_hist[T][K], tmp[Cout + T].  row_block0 / col_block0: exclusive prefix sums of Cout and of
+ * ceil(K/64) over the descriptors; the totals are passed alongside.  max_cout: largest Cout (sizes the chain kernel's LDS). */
+typedef struct dgmr_sn_desc {
+    const float* w;
+    const float* gram;
+    float* u;
+    float* v;
+    int64_t inv_sigma_off;
+    int64_t u_hist_off;
+    int64_t v_hist_off;
+    int64_t tmp_off;
+    int32_t Cout, Cin, taps, T;
+    float eps;
+    int32_t row_block0, col_block0, reserved;
+} dgmr_sn_desc;
+int dgmr_spectral_sigma_seq_multi(const dgmr_sn_desc* descs_dev, int n, int total_row_blocks, int total_col_blocks, int max_cout,
+                                  float* arena, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Per-channel reductions / BatchNorm — torch.nn.BatchNorm2d (common.py:38-39,108-109; generators.py:113)
  * and BatchNorm1d (discriminators.py:102,194) in train and eval mode.

@@ -41,6 +41,17 @@ class WgradArgs(Structure):
     ]
 
 
+class SNDesc(Structure):
+    """Mirror of ``dgmr_sn_desc``."""
+
+    _fields_ = [
+        ("w", P), ("gram", P), ("u", P), ("v", P),
+        ("inv_sigma_off", c_int64), ("u_hist_off", c_int64), ("v_hist_off", c_int64), ("tmp_off", c_int64),
+        ("Cout", c_int32), ("Cin", c_int32), ("taps", c_int32), ("T", c_int32), ("eps", c_float),
+        ("row_block0", c_int32), ("col_block0", c_int32), ("reserved", c_int32),
+    ]
+
+
 i, f, L = c_int, c_float, c_int64
 # name -> argtypes (every function returns int except the two noted below); must match include/dgmr_hip.h
 SIGNATURES = {
@@ -53,6 +64,7 @@ SIGNATURES = {
     "dgmr_sn_wgrad_finalize": [P, P, P, P, P, P, i, i, i, i, i, P],
     "dgmr_spectral_sigma": [P, P, P, P, P, P, P, P, i, i, i, f, i, P],
     "dgmr_spectral_sigma_seq": [P, P, P, P, P, P, P, P, P, i, i, i, f, i, P],
+    "dgmr_spectral_sigma_seq_multi": [P, i, i, i, i, P, P],
     "dgmr_bn_stats": [P, P, i, L, i, P],
     "dgmr_bn_finalize": [P, P, P, P, P, P, P, P, P, P, i, L, i, f, f, P],
     "dgmr_bn_bwd_reduce": [P, P, P, P, P, i, L, i, P],

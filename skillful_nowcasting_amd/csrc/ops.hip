@@ -213,6 +213,141 @@ __global__ void sn_cols_seq_kernel(const float* __restrict__ w, const float* __r
     }
 }
 
+// ---- the same for MANY modules in three launches (all spectral-norm work of one generator / discriminator forward) ----
+// Power iterations do not depend on activations, so a forward draws every module's call sequence up front: block -> module
+// through the descriptors' block prefix sums; the chains of all modules run concurrently, one workgroup each.
+__device__ __forceinline__ int sn_find(const dgmr_sn_desc* __restrict__ d, int n, int blk, bool rows) {
+    int m = 0;
+    while (m + 1 < n && blk >= (rows ? d[m + 1].row_block0 : d[m + 1].col_block0)) ++m;
+    return m;
+}
+
+__global__ void sn_rows_multi_kernel(const dgmr_sn_desc* __restrict__ descs, int n, float* __restrict__ arena) {
+    __shared__ float red[32];
+    const int m = sn_find(descs, n, blockIdx.x, true);
+    const dgmr_sn_desc d = descs[m];
+    const int i = blockIdx.x - d.row_block0;
+    const int K = d.Cin * d.taps;
+    const float* wr = d.w + (size_t)i * K;
+    float s = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += blockDim.x * 4) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+        const int tp = k / d.Cin, ci = k - tp * d.Cin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = fmaf(wv[j], d.v[(size_t)(ci + j) * d.taps + tp], s);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) arena[d.tmp_off + i] = s;
+}
+
+__global__ __launch_bounds__(1024) void sn_chain_multi_kernel(const dgmr_sn_desc* __restrict__ descs, float* __restrict__ arena) {
+    extern __shared__ float sh[];  // ucur[Cmax] | y[Cmax] | red[64]
+    const dgmr_sn_desc d = descs[blockIdx.x];
+    const int Cout = d.Cout, T = d.T;
+    const float eps = d.eps;
+    const float* __restrict__ A = d.gram;
+    const float* t0 = arena + d.tmp_off;
+    float* dnorm = arena + d.tmp_off + Cout;
+    float* u_hist = arena + d.u_hist_off;
+    float* inv_sigma = arena + d.inv_sigma_off;
+    float* ucur = sh;
+    float* y = sh + Cout;
+    float* red = sh + 2 * Cout;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    {
+        float q = 0.f;
+        for (int i = threadIdx.x; i < Cout; i += blockDim.x) q = fmaf(t0[i], t0[i], q);
+        q = block_sum(q, red);
+        const float inv = 1.f / fmaxf(sqrtf(q), eps);
+        for (int i = threadIdx.x; i < Cout; i += blockDim.x) ucur[i] = t0[i] * inv;
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        float part = 0.f, part2 = 0.f;
+        // each wave takes rows wid, wid+nw, ...; four rows in flight per wave to cover the L2 latency
+        for (int i0 = wid; i0 < Cout; i0 += 4 * nw) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int j = lane; j < Cout; j += 64) {
+                const float uj = ucur[j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + r * nw;
+                    if (i < Cout) s[r] = fmaf(A[(size_t)i * Cout + j], uj, s[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + r * nw;
+                const float v = wave_sum(s[r]);
+                if (lane == 0 && i < Cout) {
+                    y[i] = v;
+                    part = fmaf(ucur[i], v, part);
+                    part2 = fmaf(v, v, part2);
+                }
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            red[wid] = part;
+            red[16 + wid] = part2;
+        }
+        __syncthreads();
+        float n2 = 0.f, y2 = 0.f;
+        for (int k = 0; k < nw; ++k) {
+            n2 += red[k];
+            y2 += red[16 + k];
+        }
+        const float dd = fmaxf(sqrtf(fmaxf(n2, 0.f)), eps);
+        for (int i = threadIdx.x; i < Cout; i += blockDim.x) u_hist[(size_t)t * Cout + i] = ucur[i];
+        if (threadIdx.x == 0) {
+            dnorm[t] = dd;
+            inv_sigma[t] = dd / n2;
+        }
+        __syncthreads();
+        if (t + 1 < T) {
+            const float invd = 1.f / dd;
+            const float inv = invd / fmaxf(sqrtf(y2) * invd, eps);
+            for (int i = threadIdx.x; i < Cout; i += blockDim.x) ucur[i] = y[i] * inv;
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) d.u[i] = ucur[i];
+}
+
+__global__ void sn_cols_multi_kernel(const dgmr_sn_desc* __restrict__ descs, int n, float* __restrict__ arena) {
+    __shared__ float part[4][SN_TMAX][64];
+    const int m = sn_find(descs, n, blockIdx.x, false);
+    const dgmr_sn_desc d = descs[m];
+    const int Cout = d.Cout, T = d.T, K = d.Cin * d.taps;
+    const float* __restrict__ u_hist = arena + d.u_hist_off;
+    const float* __restrict__ dnorm = arena + d.tmp_off + Cout;
+    float* v_hist = arena + d.v_hist_off;
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int k = (blockIdx.x - d.col_block0) * 64 + c;
+    float acc[SN_TMAX];
+#pragma unroll
+    for (int t = 0; t < SN_TMAX; ++t) acc[t] = 0.f;
+    if (k < K)
+        for (int i = rg; i < Cout; i += 4) {
+            const float wv = d.w[(size_t)i * K + k];
+#pragma unroll
+            for (int t = 0; t < SN_TMAX; ++t)
+                if (t < T) acc[t] = fmaf(wv, u_hist[(size_t)t * Cout + i], acc[t]);
+        }
+#pragma unroll
+    for (int t = 0; t < SN_TMAX; ++t) part[rg][t][c] = acc[t];
+    __syncthreads();
+    if (k < K) {
+        const int tp = k / d.Cin, ci = k - tp * d.Cin;
+        const size_t j = (size_t)ci * d.taps + tp;
+        for (int t = rg; t < T; t += 4) {
+            const float s = (part[0][t][c] + part[1][t][c] + part[2][t][c] + part[3][t][c]) / dnorm[t];
+            v_hist[(size_t)t * K + j] = s;
+            if (t == T - 1) d.v[j] = s;
+        }
+    }
+}
+
 __global__ void zero_kernel(float* p, int n) {
     if (threadIdx.x < n) p[threadIdx.x] = 0.f;
 }
@@ -867,6 +1002,17 @@ extern "C" int dgmr_spectral_sigma_seq(const float* w, const float* gram, float*
                        u_hist, dnorm, inv_sigma, Cout, T, eps);
     hipLaunchKernelGGL(sn_cols_seq_kernel, dim3((K + 63) / 64), dim3(256), 0, ST, w, u_hist, dnorm, v, v_hist, Cout, K, Cin, taps, T);
     hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ST, scratch, 4);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_spectral_sigma_seq_multi(const dgmr_sn_desc* descs_dev, int n, int total_row_blocks, int total_col_blocks,
+                                             int max_cout, float* arena, void* stream) {
+    DGMR_CHECK_ARG(descs_dev && arena && n > 0 && total_row_blocks > 0 && total_col_blocks > 0, "dgmr_spectral_sigma_seq_multi: bad args");
+    DGMR_CHECK_ARG(max_cout > 0 && max_cout <= 8192, "dgmr_spectral_sigma_seq_multi: max_cout=%d", max_cout);
+    hipLaunchKernelGGL(sn_rows_multi_kernel, dim3(total_row_blocks), dim3(256), 0, ST, descs_dev, n, arena);
+    hipLaunchKernelGGL(sn_chain_multi_kernel, dim3(n), dim3(1024), (2 * max_cout + 64) * sizeof(float), ST, descs_dev, arena);
+    hipLaunchKernelGGL(sn_cols_multi_kernel, dim3(total_col_blocks), dim3(256), 0, ST, descs_dev, n, arena);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

@@ -4,7 +4,7 @@ from huggingface_hub import PyTorchModelHubMixin
 
 from . import ops
 from .common import DBlock
-from .nn import BatchNorm1d, SNLinear1
+from .nn import BatchNorm1d, SNLinear1, SNScope
 
 
 class Discriminator(torch.nn.Module, PyTorchModelHubMixin):
@@ -17,8 +17,9 @@ class Discriminator(torch.nn.Module, PyTorchModelHubMixin):
         self.temporal_discriminator = TemporalDiscriminator(input_channels=input_channels, conv_type=conv_type)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        spatial_loss = self.spatial_discriminator(x)
-        temporal_loss = self.temporal_discriminator(x)
+        with SNScope(self, tuple(x.shape)):  # all spectral-norm iterations of both discriminators up front
+            spatial_loss = self.spatial_discriminator(x)
+            temporal_loss = self.temporal_discriminator(x)
         return torch.cat([spatial_loss, temporal_loss], dim=1)
 
 

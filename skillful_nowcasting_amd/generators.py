@@ -7,7 +7,7 @@ from huggingface_hub import PyTorchModelHubMixin
 from . import ops
 from .common import GBlock, UpsampleGBlock
 from .layers import ConvGRU
-from .nn import BatchNorm, SNConv
+from .nn import BatchNorm, SNConv, SNScope
 
 
 class Sampler(torch.nn.Module, PyTorchModelHubMixin):
@@ -71,6 +71,9 @@ class Generator(torch.nn.Module, PyTorchModelHubMixin):
         self.sampler = sampler
 
     def forward(self, x: torch.Tensor):
-        conditioning_states = self.conditioning_stack(x)
-        latent_dim = self.latent_stack(x)
-        return self.sampler(conditioning_states, latent_dim)
+        # every spectral-norm power iteration of this forward is data-independent: after the first (traced) call they are all
+        # drawn up front in three launches
+        with SNScope(self, (tuple(x.shape), getattr(self.sampler, "forecast_steps", 0))):
+            conditioning_states = self.conditioning_stack(x)
+            latent_dim = self.latent_stack(x)
+            return self.sampler(conditioning_states, latent_dim)

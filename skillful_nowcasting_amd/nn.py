@@ -20,6 +20,131 @@ from . import ops
 from .ops import BNState, ConvSpec
 
 
+class SNPlan:
+    """Every spectral-norm call sequence of one forward, drawn in three launches (dgmr_spectral_sigma_seq_multi).
+
+    `entries`: [(module, calls)] in first-use order, each module at most once.  The descriptor table (static pointers to
+    W, W W^T, u, v and offsets into a per-run output arena) is uploaded once; `run()` refreshes stale Gram matrices, allocates
+    the arena and returns {id(module): SNCall} whose tensors are views into it.
+    """
+
+    def __init__(self, entries):
+        import ctypes
+
+        from ._lib import SNDesc
+
+        self.entries = list(entries)
+        n = len(self.entries)
+        descs = (SNDesc * n)()
+        off = row0 = col0 = 0
+        self.layout = []
+        self.max_cout = 1
+        self.ptrs = []
+        dev = None
+        for i, (m, calls) in enumerate(self.entries):
+            w = m.weight_orig
+            dev = w.device
+            vec = getattr(m.parametrizations.weight, "0")
+            cout, cin = w.shape[0], w.shape[1]
+            taps = w.numel() // (cout * cin)
+            k = cin * taps
+            gram = m._gram_buffer()
+            d = descs[i]
+            d.w, d.gram, d.u, d.v = w.data_ptr(), gram.data_ptr(), vec._u.data_ptr(), vec._v.data_ptr()
+            d.inv_sigma_off = off
+            d.u_hist_off = off + calls
+            d.v_hist_off = d.u_hist_off + calls * cout
+            d.tmp_off = d.v_hist_off + calls * k
+            self.layout.append((off, calls, cout, k))
+            off = d.tmp_off + cout + calls
+            off = (off + 3) // 4 * 4
+            d.Cout, d.Cin, d.taps, d.T, d.eps = cout, cin, taps, calls, float(m.eps)
+            d.row_block0, d.col_block0 = row0, col0
+            row0 += cout
+            col0 += (k + 63) // 64
+            self.max_cout = max(self.max_cout, cout)
+            self.ptrs.append((w.data_ptr(), vec._u.data_ptr(), vec._v.data_ptr(), gram.data_ptr()))
+        self.total, self.rows, self.cols = off, row0, col0
+        raw = bytes(ctypes.string_at(ctypes.addressof(descs), ctypes.sizeof(descs)))
+        self.descs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.device = dev
+
+    def valid(self) -> bool:
+        for (m, _), ptrs in zip(self.entries, self.ptrs):
+            vec = getattr(m.parametrizations.weight, "0")
+            if (m.weight_orig.data_ptr(), vec._u.data_ptr(), vec._v.data_ptr(), m._gram_buffer().data_ptr()) != ptrs:
+                return False
+        return True
+
+    def run(self):
+        for m, _ in self.entries:
+            m._gram()  # refresh W W^T in place if the optimiser moved W
+        arena = torch.empty(self.total, device=self.device, dtype=torch.float32)
+        ops.call("dgmr_spectral_sigma_seq_multi", self.descs_dev.data_ptr(), len(self.entries), self.rows, self.cols, self.max_cout,
+                 arena.data_ptr(), ops._stream())
+        out = {}
+        for (m, calls), (off, _, cout, k) in zip(self.entries, self.layout):
+            inv_sigma = arena[off:off + calls]
+            u = arena[off + calls:off + calls + calls * cout].view(calls, cout)
+            v = arena[off + calls + calls * cout:off + calls + calls * cout + calls * k].view(calls, k)
+            out[id(m)] = ops.SNCall(inv_sigma, u, v, calls)
+        return out
+
+
+class SNScope:
+    """`with SNScope(owner, key):` around a forward whose spectral-norm calls are data-independent (every DGMR forward is).
+
+    First time for (owner, key): the forward runs with per-module launches while the (module, calls) requests are traced.
+    Afterwards the traced plan is executed up front and each `_sigma()` request is served from it.  Eval mode: no-op.
+    """
+
+    _active = None
+    _plans = {}
+
+    def __init__(self, owner: nn.Module, key=()):
+        self.owner, self.key = owner, (id(owner), key)
+        self.records = None
+        self.trace = None
+
+    def __enter__(self):
+        self.prev = SNScope._active
+        if not self.owner.training or self.prev is not None:
+            self.noop = True
+            return self
+        self.noop = False
+        hit = SNScope._plans.get(self.key)
+        plan = None
+        if hit is not None and hit[0]() is self.owner and hit[1].valid():  # same live owner, pointers unchanged
+            plan = hit[1]
+        if plan is not None:
+            self.records = plan.run()
+        else:
+            self.trace = []
+        SNScope._active = self
+        return self
+
+    def __exit__(self, *exc):
+        if self.noop:
+            return False
+        SNScope._active = self.prev
+        if self.trace is not None and exc[0] is None:
+            seen = {id(m) for m, _ in self.trace}
+            if self.trace and len(seen) == len(self.trace):  # a module requested twice cannot be planned (dependent sequences)
+                import weakref
+
+                SNScope._plans[self.key] = (weakref.ref(self.owner), SNPlan(self.trace))
+        return False
+
+    def take(self, module, calls):
+        if self.records is None:
+            return None
+        rec = self.records.get(id(module))
+        if rec is not None and rec.groups == calls:
+            del self.records[id(module)]
+            return rec
+        return None
+
+
 def _mf(ndim: int):
     return torch.channels_last if ndim == 4 else (torch.channels_last_3d if ndim == 5 else torch.contiguous_format)
 
@@ -77,19 +202,35 @@ class _SpectralNormBase(nn.Module):
     def weight_orig(self) -> torch.Tensor:
         return self.parametrizations.weight.original
 
-    def _gram(self) -> torch.Tensor:
-        """W W^T, recomputed only when the optimiser (or a load_state_dict) has changed W."""
+    def _gram_buffer(self) -> torch.Tensor:
         w = self.weight_orig
+        buf = getattr(self, "_gram_buf", None)
+        if buf is None or buf.device != w.device:
+            buf = torch.empty(w.shape[0], w.shape[0], device=w.device, dtype=torch.float32)
+            self._gram_buf = buf
+            self._gram_tag = None
+        return buf
+
+    def _gram(self) -> torch.Tensor:
+        """W W^T (in a persistent buffer), recomputed only when the optimiser (or a load_state_dict) has changed W."""
+        w = self.weight_orig
+        buf = self._gram_buffer()
         tag = (w._version, ops.weights_epoch(), w.data_ptr())
-        hit = getattr(self, "_gram_cache", None)
-        if hit is None or hit[0] != tag:
-            hit = (tag, ops.weight_gram(w))
-            self._gram_cache = hit
-        return hit[1]
+        if self._gram_tag != tag:
+            ops.weight_gram(w, out=buf)
+            self._gram_tag = tag
+        return buf
 
     def _sigma(self, calls: int = 1) -> ops.SNCall:
         """Spectral-norm record of `calls` consecutive calls of this module (train: one power iteration per call)."""
         vec = getattr(self.parametrizations.weight, "0")
+        scope = SNScope._active
+        if scope is not None and self.training:
+            rec = scope.take(self, calls)
+            if rec is not None:
+                return rec
+            if scope.trace is not None:
+                scope.trace.append((self, calls))
         if calls > 1 and self.training:
             return ops.spectral_sigma_seq(self.weight_orig, self._gram(), vec._u, vec._v, self._scratch, self.eps, calls)
         # one call, or eval mode (no iteration: every call sees the same sigma)

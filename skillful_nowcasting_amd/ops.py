@@ -132,13 +132,13 @@ def spectral_sigma(w: torch.Tensor, u: torch.Tensor, v: torch.Tensor, scratch: t
     return SNCall(inv_sigma, u_save.view(1, -1), v_save.view(1, -1), 1)
 
 
-def weight_gram(w: torch.Tensor) -> torch.Tensor:
+def weight_gram(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """A = W W^T ([Cout, Cout]) of a conv / linear weight seen as the [Cout, K] matrix, on the MFMA conv kernel:
     the weight tensor is handed in both as the 'image' (Cout pixels of K channels) and as the 1x1 filter bank."""
     require_hip(w, "spectral-norm weight")
     cout = w.shape[0]
     k = w.numel() // cout
-    a = torch.empty(cout, cout, device=w.device, dtype=torch.float32)
+    a = out if out is not None else torch.empty(cout, cout, device=w.device, dtype=torch.float32)
     _launch_conv(w, _p(w), None, None, a, 1, 1, cout, 1, k, cout, 1, 1, 1)
     return a
 

@@ -57,7 +57,7 @@ def test_struct_layouts_match_header():
 
     src = open(HEADER).read()
     for cname, pyt in (("dgmr_conv_args", _lib.ConvArgs), ("dgmr_wgrad_args", _lib.WgradArgs),
-                       ("dgmr_seq_desc", getattr(_lib, "SeqDesc", None))):
+                       ("dgmr_sn_desc", _lib.SNDesc)):
         m = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S)
         if m is None and pyt is None:
             continue
