@@ -34,6 +34,8 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
   # keep only the summaries (the raw per-dispatch trace / sqlite db can be hundreds of MB; gpurun_out is capped at 64 MiB)
   mkdir -p "$OUT/prof_keep"
   find "$OUT/prof" -name '*stats*.csv' -exec cp {} "$OUT/prof_keep/" \;
+  KT=$(find "$OUT/prof" -name '*kernel_trace.csv' | head -1)
+  [ -n "$KT" ] && python tools/trace_by_grid.py "$KT" "$OUT/prof_keep/kernel_by_grid.csv" && head -3 "$KT" > "$OUT/prof_keep/kernel_trace_head.csv"
   rm -rf "$OUT/prof"
   ls -la "$OUT/prof_keep"
 fi
