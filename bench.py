@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak
 
 
 def parse():
@@ -34,6 +35,8 @@ def parse():
     ap.add_argument("--fast", action="store_true", help="strict_reference_semantics=False (skip discarded work)")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "off"])
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--precision", default=os.environ.get("DGMR_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the conv forward/data-gradient contractions (tensors stay fp32 in HBM)")
     return ap.parse_args()
 
 
@@ -112,6 +115,7 @@ def main():
 
     kw, hw, T = WORKLOADS[args.workload]
     B = args.batch
+    S.set_precision(args.precision)
     torch.manual_seed(0)
     model = S.DGMR(strict_reference_semantics=not args.fast, **kw).to(dev)
     if world > 1:
@@ -159,12 +163,22 @@ def main():
         rows = [dict(kernel=lib.dgmr_profile_variant_name(i).decode(), launches=int(cnt[i]), total_ms=ms[i],
                      avg_us=(1e3 * ms[i] / cnt[i]) if cnt[i] else 0.0, tflops=(fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] > 0 else 0.0,
                      flops_per_launch=(fl[i] / cnt[i]) if cnt[i] else 0.0) for i in range(nv)]
+        # forward / data-gradient variants run in the selected precision; the weight-gradient kernels are fp32 MFMA in every mode
+        mult = {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
+        for r in rows:
+            fwd = r["kernel"].startswith("conv_fwd_dgrad")
+            r["peak_tflops"] = PEAK_BF16_MFMA_TFLOPS if (fwd and args.precision != "f32") else PEAK_F32_MFMA_TFLOPS
+            r["mfma_executed_tflops"] = r["tflops"] * (mult if fwd else 1)
+            r["frac"] = r["tflops"] / r["peak_tflops"]
         dom = max(rows, key=lambda r: r["total_ms"])
         tot_ms = sum(r["total_ms"] for r in rows)
         tot_fl = sum(fl[i] for i in range(nv))
         roofline = {
-            "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": dom["kernel"],
+            "bound": "mfma", "achieved": dom["tflops"], "peak": dom["peak_tflops"], "unit": "TFLOP/s",
+            "frac": dom["tflops"] / dom["peak_tflops"], "traffic": None, "kernel": dom["kernel"],
+            "mfma_executed_tflops": dom["mfma_executed_tflops"], "mfma_executed_frac": dom["mfma_executed_tflops"] / dom["peak_tflops"],
+            "note": "achieved = algorithmic 2*M*K*Cout per launch / HIP-event time of that launch, summed over the step; in bf16x3 "
+                    "every product costs three bf16 MFMAs (mfma_executed_*), peak is the dense bf16 MFMA rate",
             "launches_per_step": dom["launches"], "avg_launch_us": dom["avg_us"], "flops_per_launch": dom["flops_per_launch"],
             "all_conv_kernels": {"tflops": tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0, "ms_per_step": tot_ms,
                                  "frac_of_step": tot_ms / ms_per_step},
@@ -175,7 +189,8 @@ def main():
         out = {
             "metric": "radar frames/sec (G+D step) 4->18 @256^2" if args.workload == "paper" else f"radar frames/sec (G+D step) [{args.workload}]",
             "value": value, "unit": "radar frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 tensors, split-bf16 MFMA operands, fp32 accumulate)", "bf16": "bf16"}[args.precision],
             "data": "synthetic torch.rand frames, random-init weights",
             "config": {"workload": f"DGMR.training_step {args.workload}: {kw}, H=W={hw}", "per_gpu_batch": B, "global_batch": world * B,
                        "frames_per_sample": 4 + T, "parallelism": f"dp{world}",

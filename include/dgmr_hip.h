@@ -84,6 +84,17 @@ typedef struct dgmr_conv_args {
 #define DGMR_EPI_GRU_GATE 1  /* pre_out = v ; y = sigmoid(v) * gru_h                              (ConvGRU.py:69-71,78) */
 #define DGMR_EPI_GRU_BLEND 2 /* pre_out = v ; y = s*gru_h + (1-s)*relu(v), s = sigmoid(gru_pu)     (ConvGRU.py:80-84) */
 
+/* Arithmetic of the forward / data-gradient contraction (process-wide; tensors in HBM stay fp32, accumulation is fp32):
+ *   DGMR_PREC_F32     exact fp32 on v_mfma_f32_32x32x2_f32 (157 TF peak) -- the parity mode
+ *   DGMR_PREC_BF16X3  each operand split into two bf16 terms, 3 x v_mfma_f32_32x32x16_bf16 per product: ~2^-16 relative error
+ *                     per product (fp32-class), 833 TF effective peak
+ *   DGMR_PREC_BF16    operands rounded to bf16 (BASELINE.json configs[1]): 2.5 PF peak, ~3 significant digits */
+#define DGMR_PREC_F32 0
+#define DGMR_PREC_BF16X3 1
+#define DGMR_PREC_BF16 2
+int dgmr_set_precision(int mode);
+int dgmr_get_precision(void);
+
 /* y = act(conv(pre(x), w) (+addend) *scale + bias) (+residual), masked.  Forward AND data-gradient (the
  * latter with dgmr_conv_flip_weights()'ed weights and dy as x). */
 int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream);

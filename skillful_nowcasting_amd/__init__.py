@@ -8,6 +8,7 @@ from .common import ContextConditioningStack, LatentConditioningStack
 from .dgmr import DGMR
 from .discriminators import Discriminator, SpatialDiscriminator, TemporalDiscriminator
 from .generators import Generator, Sampler
+from .ops import get_precision, set_precision
 
 __all__ = ["DGMR", "Generator", "Sampler", "Discriminator", "SpatialDiscriminator", "TemporalDiscriminator",
-           "ContextConditioningStack", "LatentConditioningStack"]
+           "ContextConditioningStack", "LatentConditioningStack", "set_precision", "get_precision"]

@@ -96,6 +96,8 @@ SIGNATURES = {
     "dgmr_hinge_disc": [P, P, P, P, P, i, i, P],
     "dgmr_grid_cell_loss": [P, i, L, P, f, P, P, f, P, L, P],
     "dgmr_adam": [P, P, P, P, L, f, f, f, f, i, P],
+    "dgmr_set_precision": [i],
+    "dgmr_get_precision": [],
     "dgmr_profile_enable": [i],
     "dgmr_profile_variants": [],
     "dgmr_profile_collect": [P, P, P, i],

@@ -14,113 +14,10 @@
 #include <mutex>
 #include <vector>
 
-#include "common.h"
+#include "conv_bf16.h"
+#include "conv_device.h"
 
 namespace {
-
-struct RowCoord {
-    int n, d, h, w;
-};
-
-__device__ __forceinline__ RowCoord decode_row(int m, int D, int H, int W) {
-    RowCoord r;
-    r.w = m % W;
-    int t = m / W;
-    r.h = t % H;
-    t /= H;
-    r.d = t % D;
-    r.n = t / D;
-    return r;
-}
-
-// Decoded position of a thread's 4-channel group inside the flattened K axis.
-struct KPos {
-    int ci, dz, dy, dx;  // channel, tap offsets relative to the output pixel (already minus padding)
-    bool ok;
-};
-
-__device__ __forceinline__ KPos decode_k(int k, int Ktot, int Cin, int KW, int KHW, int pd, int ph, int pw) {
-    KPos p;
-    p.ok = k < Ktot;
-    const int tap = k / Cin;
-    p.ci = k - tap * Cin;
-    const int kz = tap / KHW;
-    const int r2 = tap - kz * KHW;
-    const int ky = r2 / KW;
-    p.dz = kz - pd;
-    p.dy = ky - ph;
-    p.dx = r2 - ky * KW - pw;
-    return p;
-}
-
-// Issue the 16-byte load of 4 consecutive input channels of im2col element (pixel rc, position kp).  The value is
-// returned RAW (no relu / affine): the fused prologue is applied later, at LDS-store time (finish_a), so that the
-// load stays in flight under the MFMAs of the current tile instead of being waited for right here.
-__device__ __forceinline__ f32x4 issue_a(const float* __restrict__ x, const RowCoord& rc, bool row_ok, const KPos& kp, int D,
-                                         int H, int W, int Cin, int upsample, bool& valid) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    int id = rc.d + kp.dz, ih = rc.h + kp.dy, iw = rc.w + kp.dx;
-    valid = row_ok && kp.ok && (unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-    if (valid) {
-        int Hin = H, Win = W;
-        if (upsample) {
-            ih >>= 1;
-            iw >>= 1;
-            Hin >>= 1;
-            Win >>= 1;
-        }
-        const size_t off = ((((size_t)rc.n * D + id) * Hin + ih) * Win + iw) * (size_t)Cin + kp.ci;
-        v = *reinterpret_cast<const f32x4*>(x + off);
-    }
-    return v;
-}
-
-__device__ __forceinline__ f32x4 finish_a(f32x4 v, bool valid, const float* __restrict__ pre_a, const float* __restrict__ pre_b,
-                                          int n, int ci, int Cin, int pre_relu, int pre_group) {
-    if (pre_a) {
-        if (valid) {
-            const size_t g = (size_t)(n / pre_group) * Cin + ci;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(pre_a + g);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(pre_b + g);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.f);
-        }
-    } else if (pre_relu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-    }
-    return v;
-}
-
-__device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + __expf(-x)); }
-
-// One output element: (acc + addend) * scale + bias, then the fused tail selected by epi_mode.  Shared by the in-kernel
-// epilogue and the split-K reduce kernel.
-__device__ __forceinline__ void epilogue_store(const dgmr_conv_args& p, float v, int n, int col, size_t idx) {
-    if (p.addend) v += p.addend[idx];
-    if (p.scale) v *= p.scale[n / p.scale_group];
-    if (p.bias) v += p.bias[col];
-    if (p.epi_mode == DGMR_EPI_GRU_GATE) {  // r * h with r = sigmoid(pre)   (ConvGRU.py:69-71,78)
-        p.pre_out[idx] = v;
-        v = sigmoid_(v) * p.gru_h[idx];
-    } else if (p.epi_mode == DGMR_EPI_GRU_BLEND) {  // u*h + (1-u)*relu(pre_c)   (ConvGRU.py:80-84)
-        p.pre_out[idx] = v;
-        const float s = sigmoid_(p.gru_pu[idx]);
-        v = s * p.gru_h[idx] + (1.f - s) * fmaxf(v, 0.f);
-    } else {
-        if (p.act_relu) v = fmaxf(v, 0.f);
-        if (p.residual) v += p.residual[idx];
-        if (p.mask_src) {
-            float ms = p.mask_src[idx];
-            if (p.mask_a) {
-                const size_t g = (size_t)(n / p.mask_group) * p.Cout + col;
-                ms = fmaf(ms, p.mask_a[g], p.mask_b[g]);
-            }
-            v = ms > 0.f ? v : 0.f;
-        }
-    }
-    p.y[idx] = v;
-}
 
 template <int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_conv_args p, const int M, const int Ktot,
@@ -306,18 +203,27 @@ struct ProfScope {
 
 enum { V_F128x128 = 0, V_F64x64, V_F128x96, V_F128x64, V_F128x32, V_W128, V_W64, V_W32, V_COUNT };
 const char* const kVariantNames[V_COUNT] = {
-    "conv_igemm_kernel<128,128,32,2,2>", "conv_igemm_kernel<64,64,32,2,2>", "conv_igemm_kernel<128,96,32,4,1>",
-    "conv_igemm_kernel<128,64,32,4,1>",  "conv_igemm_kernel<128,32,32,4,1>", "conv_wgrad_kernel<128,128,2,2>",
-    "conv_wgrad_kernel<64,128,2,2>",     "conv_wgrad_kernel<32,128,1,4>"};
+    "conv_fwd_dgrad<128,128>", "conv_fwd_dgrad<64,64>", "conv_fwd_dgrad<128,96>", "conv_fwd_dgrad<128,64>",
+    "conv_fwd_dgrad<128,32>",  "conv_wgrad_kernel<128,128,2,2>", "conv_wgrad_kernel<64,128,2,2>", "conv_wgrad_kernel<32,128,1,4>"};
 
-template <int BM, int BN, int BK, int WM, int WN>
+// 0: exact fp32 (v_mfma_f32_32x32x2_f32)   1: bf16x3 split (fp32-class accuracy on the bf16 matrix cores)   2: plain bf16
+int g_precision = 0;
+
+// WM x WN: wave grid of the f32 kernel; WMB x WNB: of the bf16 kernels (two register stages: 128x128 needs 8 waves to fit)
+template <int BM, int BN, int WM, int WN, int WMB = WM, int WNB = WN>
 int launch_conv(const dgmr_conv_args& a, int M, int Ktot, hipStream_t s) {
+    const int BK = 32;
     const int nk = (Ktot + BK - 1) / BK;
     const int S = a.ksplit > 1 ? a.ksplit : 1;
     const int per = (nk + S - 1) / S;
     const int Seff = (nk + per - 1) / per;  // no empty splits
     dim3 grid((M + BM - 1) / BM, (a.Cout + BN - 1) / BN, Seff);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(64 * WM * WN), 0, s, a, M, Ktot, per);
+    if (g_precision == 1)
+        hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, 32, WMB, WNB, 3>), grid, dim3(64 * WMB * WNB), 0, s, a, M, Ktot, per);
+    else if (g_precision == 2)
+        hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, 32, WMB, WNB, 1>), grid, dim3(64 * WMB * WNB), 0, s, a, M, Ktot, per);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, WM, WN>), grid, dim3(64 * WM * WN), 0, s, a, M, Ktot, per);
     if (Seff > 1) {
         const size_t total = (size_t)M * a.Cout;
         const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
@@ -575,7 +481,8 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         const int bm = variant == V_F64x64 ? 64 : 128;
         const int bnv = variant == V_F64x64 ? 64 : bn;
         const int64_t wgs = ((M64 + bm - 1) / bm) * ((C + bnv - 1) / bnv);
-        const int nk = (Ktot + 31) / 32;
+        const int bk = 32;
+        const int nk = (Ktot + bk - 1) / bk;
         if (wgs < 192 && nk >= 8) {
             int64_t S = 512 / wgs;
             if (S > nk / 4) S = nk / 4;
@@ -588,11 +495,11 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     {
         ProfScope ps(variant, flops, s);
         switch (variant) {
-            case V_F128x128: launch_conv<128, 128, 32, 2, 2>(p, M, Ktot, s); break;
-            case V_F64x64: launch_conv<64, 64, 32, 2, 2>(p, M, Ktot, s); break;
-            case V_F128x96: launch_conv<128, 96, 32, 4, 1>(p, M, Ktot, s); break;
-            case V_F128x64: launch_conv<128, 64, 32, 4, 1>(p, M, Ktot, s); break;
-            default: launch_conv<128, 32, 32, 4, 1>(p, M, Ktot, s); break;
+            case V_F128x128: launch_conv<128, 128, 2, 2, 2, 4>(p, M, Ktot, s); break;
+            case V_F64x64: launch_conv<64, 64, 2, 2>(p, M, Ktot, s); break;
+            case V_F128x96: launch_conv<128, 96, 4, 1>(p, M, Ktot, s); break;
+            case V_F128x64: launch_conv<128, 64, 4, 1>(p, M, Ktot, s); break;
+            default: launch_conv<128, 32, 4, 1>(p, M, Ktot, s); break;
         }
     }
     DGMR_CHECK_LAUNCH();
@@ -707,6 +614,13 @@ extern "C" int dgmr_sn_wgrad_finalize(const float* g, float* gw, float* dot, con
     DGMR_CHECK_LAUNCH();
     return 0;
 }
+
+extern "C" int dgmr_set_precision(int mode) {
+    DGMR_CHECK_ARG(mode >= 0 && mode <= 2, "dgmr_set_precision: mode %d (0 f32, 1 bf16x3, 2 bf16)", mode);
+    g_precision = mode;
+    return 0;
+}
+extern "C" int dgmr_get_precision(void) { return g_precision; }
 
 extern "C" int dgmr_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -35,6 +35,24 @@ def weights_epoch() -> int:
     return _WEIGHTS_EPOCH
 
 
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+
+def set_precision(mode: str):
+    """Arithmetic of the forward / data-gradient contractions (tensors stay fp32 in HBM, accumulation is fp32):
+    "f32" exact fp32 MFMA (parity mode, default) | "bf16x3" split-bf16, fp32-class accuracy at 5x the ceiling | "bf16"."""
+    if mode not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {mode!r}")
+    call("dgmr_set_precision", PRECISIONS[mode])
+
+
+def get_precision() -> str:
+    from ._lib import load
+
+    code = int(load().dgmr_get_precision())
+    return next(k for k, v in PRECISIONS.items() if v == code)
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

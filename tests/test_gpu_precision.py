@@ -1,0 +1,101 @@
+"""The three arithmetic modes of the convolution kernels against a float64 reference of the same op, and against the goldens.
+
+  f32     exact fp32 MFMA                       -> fp32 round-off only
+  bf16x3  split-bf16 (3 MFMAs per product)      -> ~2^-16 per product: held to 5e-5 of the output scale here, 1e-4 on goldens
+  bf16    plain bf16 operands, fp32 accumulate  -> ~2^-8 per product: held to 2e-2
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, split_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 2e-6, "bf16x3": 5e-5, "bf16": 2e-2}
+
+
+@pytest.fixture
+def precision():
+    import skillful_nowcasting_amd as S
+
+    yield S.set_precision
+    S.set_precision("f32")
+
+
+def _conv_ref(x, w, b, up=False, relu_in=False):
+    x = x.double()
+    if relu_in:
+        x = x.relu()
+    if up:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    pad = w.shape[-1] // 2
+    return F.conv2d(x, w.double(), b.double(), padding=pad)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("n,cin,cout,hw,k,up,relu", [
+    (2, 96, 96, 32, 3, False, True),     # K = 864, 128x96 tile
+    (3, 48, 128, 16, 3, True, False),    # upsample-on-load, 128x128 tile
+    (1, 384, 384, 8, 3, False, False),   # small M, long K: split-K path
+    (4, 64, 24, 24, 1, False, False),    # 1x1, narrow N tile
+    (2, 20, 52, 17, 3, False, True),     # ragged M / N / K
+])
+def test_conv_modes_vs_float64(precision, mode, n, cin, cout, hw, k, up, relu):
+    from skillful_nowcasting_amd import ops
+
+    precision(mode)
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout)
+    x = torch.randn(n, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = _conv_ref(x, w, b, up, relu)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = torch.nn.Parameter(w.cuda().contiguous(memory_format=torch.channels_last))
+    bd = torch.nn.Parameter(b.cuda())
+    y = ops.conv(xd, wd, bd, None, None, ops.ConvSpec(upsample=up, pre_relu=relu))
+    err = (y.detach().cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= TOL[mode], f"{mode}: forward rel err {err:.3e}"
+    # data gradient (the same kernel with flipped weights) and weight gradient (fp32 kernel in every mode)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    cot = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    xin = xr.relu() if relu else xr
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    (F.conv2d(xin, wr, b.double(), padding=k // 2) * cot).sum().backward()
+    (y * cot.float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    ex = (xd.grad.cpu().double() - xr.grad).abs().max().item() / xr.grad.abs().max().item()
+    ew = (wd.grad.cpu().double() - wr.grad).abs().max().item() / wr.grad.abs().max().item()
+    assert ex <= TOL[mode], f"{mode}: dgrad rel err {ex:.3e}"
+    assert ew <= 5e-6, f"{mode}: wgrad rel err {ew:.3e}"
+
+
+@pytest.mark.parametrize("mode,tol,ptol", [("bf16x3", 1e-4, 3e-4), ("bf16", 5e-2, None)])
+@pytest.mark.parametrize("name", ["gblock_8_8", "upgblock_8_4", "dblock_4_12", "convgru_8_4_T3", "sampler_64_32_T2"])
+def test_goldens_in_reduced_modes(precision, mode, tol, ptol, name):
+    """The reference's own outputs (goldens) reproduced by the split-bf16 / bf16 kernels.
+
+    bf16x3: outputs AND gradients (the whole sampler at 1e-3 / 1e-2: its 2- and 4-channel BatchNorms over 2x2 ... 16x16 maps
+    amplify rounding; measured 2.4e-3 ... 1.2e-2 on the worst input gradient, run to run).  bf16: forward only (gradients through these tiny
+    random-weight BatchNorm stacks are dominated by the ~2^-8 operand rounding and are not a meaningful parity target)."""
+    from test_gpu_parity import _run_golden
+    from skillful_nowcasting_amd import Sampler, common
+    from skillful_nowcasting_amd.layers import ConvGRU
+
+    precision(mode)
+    if name == "sampler_64_32_T2":
+        tol, ptol = (1e-3, 3e-2) if mode == "bf16x3" else (1e-1, None)
+    if ptol is None:
+        ptol = 1e9  # forward-only check
+    builders = {
+        "gblock_8_8": (lambda: common.GBlock(8, 8), lambda m, x: m(x)),
+        "upgblock_8_4": (lambda: common.UpsampleGBlock(8, 4), lambda m, x: m(x)),
+        "dblock_4_12": (lambda: common.DBlock(4, 12), lambda m, x: m(x)),
+        "convgru_8_4_T3": (lambda: ConvGRU(12, 4, 3), lambda m, xs, h: m(list(xs.unbind(0)), h)),
+        "sampler_64_32_T2": (lambda: Sampler(forecast_steps=2, latent_channels=64, context_channels=32),
+                             lambda m, c0, c1, c2, c3, l: m([c0, c1, c2, c3], l)),
+    }
+    build, call = builders[name]
+    _run_golden(name, build, call, tol=tol, ptol=ptol)

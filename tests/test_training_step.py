@@ -141,7 +141,20 @@ def test_oracle_training_step_matches_reference():
 
 
 @pytest.mark.gpu
-def test_hip_training_step_matches_reference():
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_hip_training_step_matches_reference(precision):
+    """f32: exact-fp32 MFMA kernels.  bf16x3: forward / data-gradient contractions on the bf16 matrix cores with split operands
+    (fp32-class products) -- the same tolerances hold."""
+    import skillful_nowcasting_amd as S
+
+    S.set_precision(precision)
+    try:
+        _hip_training_step()
+    finally:
+        S.set_precision("f32")
+
+
+def _hip_training_step():
     import skillful_nowcasting_amd as S
 
     rec, keys, kw = _golden()

@@ -27,6 +27,12 @@ SHAPES = [
     ("tempD.d1.first 3d", 32, 22, 64, 64, 4, 48, (3, 3, 3), False, False),
     ("spatD.d2.first f8", 256, 1, 32, 32, 48, 96, (1, 3, 3), False, False),
     ("spatD.d5 f8", 256, 1, 4, 4, 384, 768, (1, 3, 3), False, False),
+    ("gru1.h-step B4", 4, 1, 8, 8, 384, 384, (1, 3, 3), False, False),
+    ("gru2.h-step B4", 4, 1, 16, 16, 192, 192, (1, 3, 3), False, False),
+    ("gru3.h-step B4", 4, 1, 32, 32, 96, 96, (1, 3, 3), False, False),
+    ("gru4.h-step B4", 4, 1, 64, 64, 48, 48, (1, 3, 3), False, False),
+    ("gru3.h-step B16", 16, 1, 32, 32, 96, 96, (1, 3, 3), False, False),
+    ("gru2.x-part T18B4", 72, 1, 16, 16, 384, 192, (1, 3, 3), False, False),
 ]
 
 
@@ -45,6 +51,10 @@ def bench(fn, iters=10):
 def main():
     load()
     dev = "cuda"
+    for a in sys.argv[1:]:
+        if a.startswith("--prec="):
+            ops.set_precision(a.split("=")[1])
+    print("precision:", ops.get_precision(), flush=True)
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     for name, n, d, h, w, cin, cout, ks, up, bn in SHAPES:
         if only and not any(o in name for o in only):
