@@ -116,6 +116,7 @@ typedef struct dgmr_wgrad_args {
     int32_t nsplit;      /* >= 1: the M = N*D*H*W reduction is cut into nsplit contiguous slabs */
     int32_t groups;      /* >= 1, divides N and nsplit: consecutive N/groups samples form a group (one spectral-norm call:
                             forecast step / frame); a slab never straddles two groups */
+    float* bias_grad;    /* NULL, or [Cout]: += column sums of dy (the conv's bias gradient) in the same pass */
 } dgmr_wgrad_args;
 
 /* Weight-gradient partial sums: partial[s] = dy[slab s]^T * im2col(pre(x))[slab s]. */

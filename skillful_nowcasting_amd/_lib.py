@@ -37,7 +37,7 @@ class WgradArgs(Structure):
         ("x", P), ("dy", P), ("pre_a", P), ("pre_b", P), ("partial", P),
         ("N", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
         ("KD", c_int32), ("KH", c_int32), ("KW", c_int32), ("upsample", c_int32), ("pre_relu", c_int32),
-        ("pre_group", c_int32), ("nsplit", c_int32), ("groups", c_int32),
+        ("pre_group", c_int32), ("nsplit", c_int32), ("groups", c_int32), ("bias_grad", P),
     ]
 
 

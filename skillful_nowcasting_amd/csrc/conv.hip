@@ -270,6 +270,9 @@ __global__ __launch_bounds__(64 * WI * WJ) void conv_wgrad_kernel(const dgmr_wgr
     for (int i = 0; i < XP; ++i) kps[i] = decode_k(k0 + (lq + i * TPR) * 4, Ktot, p.Cin, p.KW, KHW, pd, ph, pw);
 
     f32x4 ry[YP], rx[XP];
+    f32x4 bsum[YP];
+#pragma unroll
+    for (int i = 0; i < YP; ++i) bsum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bool vx[XP];
     int cur_n = 0;
     auto load_tiles = [&](int r0) {
@@ -283,6 +286,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void conv_wgrad_kernel(const dgmr_wgr
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok && co < p.Cout) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co);
             ry[i] = v;
+            bsum[i] += v;
         }
 #pragma unroll
         for (int i = 0; i < XP; ++i) rx[i] = issue_a(p.x, rc, ok, kps[i], p.D, p.H, p.W, p.Cin, p.upsample, vx[i]);
@@ -345,6 +349,16 @@ __global__ __launch_bounds__(64 * WI * WJ) void conv_wgrad_kernel(const dgmr_wgr
                 if (k < Ktot) out[(size_t)co * Ktot + k] = acc[i][j][r];
             }
         }
+    // bias gradient (column sums of dY over this slab): thread (lr, lq) summed rows lr, lr+.. of its channels
+    if (p.bias_grad && blockIdx.x == 0 && nr > 0) {
+#pragma unroll
+        for (int i = 0; i < YP; ++i) {
+            const int co = co0 + (lq + i * TPR) * 4;
+            if (co < p.Cout)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) atomicAdd(p.bias_grad + co + c, bsum[i][c]);
+        }
+    }
 }
 
 __global__ void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int taps, int w_cin,
@@ -555,7 +569,22 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int kt = (Ktot + 127) / 128;
     ProfScope ps(a->Cout <= 32 ? V_W32 : (a->Cout <= 64 ? V_W64 : V_W128), 2.0 * (double)M64 * (double)Ktot * (double)a->Cout, s);
-    if (a->Cout <= 32) {
+    if (g_precision != 0) {
+        const dim3 blk(256);
+        if (a->Cout <= 32) {
+            const dim3 grid(kt, (a->Cout + 31) / 32, a->nsplit);
+            if (g_precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<32, 1, 4, 3>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
+            else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<32, 1, 4, 1>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
+        } else if (a->Cout <= 64) {
+            const dim3 grid(kt, (a->Cout + 63) / 64, a->nsplit);
+            if (g_precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<64, 2, 2, 3>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
+            else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<64, 2, 2, 1>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
+        } else {
+            const dim3 grid(kt, (a->Cout + 127) / 128, a->nsplit);
+            if (g_precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<128, 2, 2, 3>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
+            else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<128, 2, 2, 1>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
+        }
+    } else if (a->Cout <= 32) {
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), dim3(kt, (a->Cout + 31) / 32, a->nsplit), dim3(256), 0, s, p, M,
                            Ktot, rows, spg, rows_per_group);
     } else if (a->Cout <= 64) {

@@ -260,4 +260,194 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix cores:  G[co][k] = sum_m dY[m][co] * A[m][k]  over one slab of pixels m.
+// Both MFMA operands need 8 consecutive *pixels* per lane (the reduction index), while HBM has channels contiguous: every
+// thread therefore loads a 4-pixel x 4-channel block (four 16-byte loads), transposes it in registers and writes, per
+// channel, 4 consecutive pixels as one 8-byte bf16 group -> LDS images [co][m] and [k][m] with the padded row stride of the
+// forward kernel.  bias_grad (optional): column sums of dY ride along (the workgroups of the first k tile add them up).
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void advance_row(RowCoord& r, int delta, int D, int H, int W) {
+    r.w += delta;
+    while (r.w >= W) {
+        r.w -= W;
+        if (++r.h == H) {
+            r.h = 0;
+            if (++r.d == D) {
+                r.d = 0;
+                ++r.n;
+            }
+        }
+    }
+}
+
+template <int BI, int WI, int WJ, int NS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const dgmr_wgrad_args p, const int M, const int Ktot,
+                                                                 const int rows_per_split, const int splits_per_group,
+                                                                 const int rows_per_group) {
+    constexpr int BJ = 128, BR = 32;
+    constexpr int LDW = BR / 2 + 4;  // dwords per LDS row: 32 bf16 pixels + 16 bytes of padding
+    constexpr int NP = NS == 3 ? 2 : 1;
+    constexpr bool SPLIT = NS == 3;
+    constexpr int TM = BI / WI / 32, TN = BJ / WJ / 32;
+    static_assert(WI * WJ == 4 && TM >= 1 && TN >= 1, "bad tile");
+
+    __shared__ __attribute__((aligned(16))) uint32_t smem[2 * NP * (BI + BJ) * LDW];
+    uint32_t* Ys = smem;
+    uint32_t* Xs = smem + 2 * NP * BI * LDW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wi = wid / WJ, wj = wid % WJ;
+    const int k0 = blockIdx.x * BJ, co0 = blockIdx.y * BI;
+    const int grp = blockIdx.z / splits_per_group;
+    const int r_begin = grp * rows_per_group + (blockIdx.z - grp * splits_per_group) * rows_per_split;
+    const int r_end = min(min(M, (grp + 1) * rows_per_group), r_begin + rows_per_split);
+    const int mg = tid & 7, cg = tid >> 3;  // this thread's 4-pixel group (0..7) and 4-channel group (0..31)
+
+    const int KHW = p.KH * p.KW;
+    const int pd = p.KD >> 1, ph = p.KH >> 1, pw = p.KW >> 1;
+    const KPos kp = decode_k(k0 + cg * 4, Ktot, p.Cin, p.KW, KHW, pd, ph, pw);  // fixed for the whole kernel
+    const int co = co0 + cg * 4;
+    const bool y_on = cg * 4 < BI && co < p.Cout;
+
+    RowCoord rc = decode_row(min(r_begin + mg * 4, M - 1), p.D, p.H, p.W);  // first pixel of this thread's group
+    int m_first = r_begin + mg * 4;
+
+    f32x4 ry[4], rx[4];
+    unsigned xmask = 0;
+    int nrow[4];
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&]() {
+        RowCoord r = rc;
+        xmask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m_first + j;
+            const bool ok = m < r_end;
+            f32x4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+            if (ok && y_on) vy = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co);
+            const int id = r.d + kp.dz, ih = r.h + kp.dy, iw = r.w + kp.dx;
+            const bool valid = ok && kp.ok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            if (valid) {
+                uint32_t off;
+                if (p.upsample) off = ((((uint32_t)r.n * p.D + id) * (p.H >> 1) + (ih >> 1)) * (p.W >> 1) + (iw >> 1)) * p.Cin + kp.ci;
+                else off = ((((uint32_t)r.n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + kp.ci;
+                vx = *reinterpret_cast<const f32x4*>(p.x + off);
+                xmask |= 1u << j;
+            }
+            ry[j] = vy;
+            rx[j] = vx;
+            nrow[j] = r.n;
+            advance_row(r, 1, p.D, p.H, p.W);
+        }
+        m_first += BR;
+        advance_row(rc, BR, p.D, p.H, p.W);
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bsum += ry[j];
+            if (p.pre_a) {
+                if ((xmask >> j) & 1u) {
+                    const uint32_t g = (uint32_t)(nrow[j] / p.pre_group) * p.Cin + kp.ci;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(p.pre_a + g);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.pre_b + g);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) rx[j][c] = fmaxf(fmaf(rx[j][c], a[c], b[c]), 0.f);
+                }
+            } else if (p.pre_relu) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rx[j][c] = fmaxf(rx[j][c], 0.f);
+            }
+        }
+        // transpose: channel c of the 4 pixels -> one 8-byte group of 4 consecutive pixels
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            u32x2 hi, lo;
+            if (cg * 4 < BI) {
+                split4<SPLIT>((f32x4){ry[0][c], ry[1][c], ry[2][c], ry[3][c]}, hi, lo);
+                uint32_t* dst = Ys + ((buf * NP) * BI + cg * 4 + c) * LDW + mg * 2;
+                *reinterpret_cast<u32x2*>(dst) = hi;
+                if (SPLIT) *reinterpret_cast<u32x2*>(dst + BI * LDW) = lo;
+            }
+            split4<SPLIT>((f32x4){rx[0][c], rx[1][c], rx[2][c], rx[3][c]}, hi, lo);
+            uint32_t* dst = Xs + ((buf * NP) * BJ + cg * 4 + c) * LDW + mg * 2;
+            *reinterpret_cast<u32x2*>(dst) = hi;
+            if (SPLIT) *reinterpret_cast<u32x2*>(dst + BJ * LDW) = lo;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nr = (r_end - r_begin + BR - 1) / BR;
+    if (nr > 0) {
+        load();
+        store(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nr; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nr) load();
+        const uint32_t* Yb = Ys + ((cur * NP) * BI + wi * TM * 32 + (lane & 31)) * LDW + (lane >> 5) * 4;
+        const uint32_t* Xb = Xs + ((cur * NP) * BJ + wj * TN * 32 + (lane & 31)) * LDW + (lane >> 5) * 4;
+#pragma unroll
+        for (int kk = 0; kk < BR / 16; ++kk) {
+            bf16x8_t yh[TM], xh[TN], yl[TM], xl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                yh[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Yb + i * 32 * LDW + kk * 8));
+                if (SPLIT) yl[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Yb + (BI + i * 32) * LDW + kk * 8));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                xh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Xb + j * 32 * LDW + kk * 8));
+                if (SPLIT) xl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Xb + (BJ + j * 32) * LDW + kk * 8));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[i], xh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[i], xl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[i], xh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (it + 1 < nr) store(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* out = p.partial + (size_t)blockIdx.z * p.Cout * Ktot;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c_o = co0 + wi * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (c_o >= p.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int k = k0 + wj * TN * 32 + j * 32 + (lane & 31);
+                if (k < Ktot) out[(size_t)c_o * Ktot + k] = acc[i][j][r];
+            }
+        }
+    // bias gradient: the 8 threads of a channel group (consecutive lanes) hold the partial column sums of this slab
+    if (p.bias_grad && blockIdx.x == 0 && nr > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = bsum[c];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            if (mg == 0 && y_on) atomicAdd(p.bias_grad + co + c, v);
+        }
+    }
+}
+
 }  // namespace

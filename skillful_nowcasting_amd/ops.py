@@ -350,8 +350,9 @@ class ConvFn(Function):
         k = kd * kh * kw * cin
         bn = spec.bn
         st = _stream()
-        # ---- bias ----
-        if bias is not None and bias.requires_grad:
+        # ---- bias: column sums of dy ride along in the weight-gradient kernel; standalone only when W is frozen ----
+        want_bias = bias is not None and bias.requires_grad
+        if want_bias and not w.requires_grad:
             tmp = torch.empty(2 * cout, device=dev, dtype=torch.float64)
             call("dgmr_colsum", _p(dy), _p(grad_buffer(bias)), _p(tmp), m, cout, 1, st)
         # ---- weight (and scale) ----
@@ -367,6 +368,7 @@ class ConvFn(Function):
             wa.KD, wa.KH, wa.KW = kd, kh, kw
             wa.upsample, wa.pre_relu, wa.pre_group, wa.nsplit = int(spec.upsample), int(spec.pre_relu), (bn.group_size if bn else 1), ns
             wa.groups = groups
+            wa.bias_grad = _p(grad_buffer(bias)) if want_bias else None
             call("dgmr_conv_wgrad", ctypes.byref(wa), st)
             gw = grad_buffer(w)
             g = torch.empty(cout * k, device=dev, dtype=torch.float32)
@@ -771,10 +773,11 @@ class ConvGRUFn(Function):
         for w, bias, dp, inv_s, u_, v_, g_, hsrc in ((wr, br, dpr, isr, ur, vr, gr, hprev_all), (wu, bu, dpu, isu, uu, vu, gu, hprev_all),
                                                      (wc, bc, dpc, isc, uc, vc, gc, rh)):
             m = tb * hh * ww
-            if bias is not None and bias.requires_grad:
-                tmpd = torch.empty(2 * ch, device=dev, dtype=torch.float64)
-                call("dgmr_colsum", _p(dp), _p(grad_buffer(bias)), _p(tmpd), m, ch, 1, st)
+            want_bias = bias is not None and bias.requires_grad
             if not w.requires_grad:
+                if want_bias:
+                    tmpd = torch.empty(2 * ch, device=dev, dtype=torch.float64)
+                    call("dgmr_colsum", _p(dp), _p(grad_buffer(bias)), _p(tmpd), m, ch, 1, st)
                 continue
             g = torch.empty(ch * taps * ct, device=dev, dtype=torch.float32)
             dot = torch.zeros(g_, device=dev, dtype=torch.float32)
@@ -787,6 +790,7 @@ class ConvGRUFn(Function):
                 wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = tb, 1, hh, ww, cin, ch
                 wa.KD, wa.KH, wa.KW = 1, kh, kw
                 wa.upsample, wa.pre_relu, wa.pre_group, wa.nsplit, wa.groups = 0, 0, 1, ns, g_
+                wa.bias_grad = _p(grad_buffer(bias)) if (want_bias and coff == 0) else None  # bias gradient once, with the x half
                 call("dgmr_conv_wgrad", ctypes.byref(wa), st)
                 call("dgmr_wgrad_reduce_slice", _p(partial), ns, g_, ch, taps, cin, ct, coff, _p(w), _p(inv_s), _p(g), _p(dot), st)
             call("dgmr_sn_wgrad_finalize", _p(g), _p(grad_buffer(w)), _p(dot), _p(inv_s), _p(u_), _p(v_), ch, ct, taps, g_, 1, st)
