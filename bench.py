@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DGMR_BENCH_BATCH", "4")), help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DGMR_BENCH_BATCH", "16")), help="per-GPU batch")
     ap.add_argument("--workload", default="paper", choices=["paper", "cfg2", "smoke"])
     ap.add_argument("--fast", action="store_true", help="strict_reference_semantics=False (skip discarded work)")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "off"])

@@ -411,6 +411,15 @@ __global__ void colsum_kernel(const float* __restrict__ x, double* __restrict__ 
     chan_reduce2([&](int64_t i, int, int, float& s0, float&) { s0 += x[i]; }, R, C, sums);
 }
 
+// out[c] (+)= sum_r x[r][c] for FEW rows and MANY columns (one thread per 4 columns; colsum_kernel is for the opposite shape)
+__global__ void sum_rows_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ out, int R, int64_t C4, int accumulate) {
+    GRID_STRIDE(c, C4) {
+        f32x4 s = accumulate ? out[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < R; ++r) s += x[(int64_t)r * C4 + c];
+        out[c] = s;
+    }
+}
+
 __global__ void colsum_finish_kernel(const double* __restrict__ sums, float* __restrict__ out, int C, int accumulate) {
     GRID_STRIDE(c, C) out[c] = (accumulate ? out[c] : 0.f) + (float)sums[c];
 }
@@ -1064,6 +1073,12 @@ extern "C" int dgmr_bn_bwd_apply(const float* gy, const float* x, const float* m
 
 extern "C" int dgmr_colsum(const float* x, float* out, double* tmp, int64_t R, int C, int accumulate, void* stream) {
     DGMR_CHECK_ARG(x && out && tmp, "dgmr_colsum: null pointer");
+    if (R <= 256 && C >= 4096 && C % 4 == 0) {  // few rows, many columns: parallel over columns, no atomics
+        hipLaunchKernelGGL(sum_rows_kernel, dim3(ew_blocks(C / 4)), dim3(EW_THREADS), 0, ST, (const f32x4*)x, (f32x4*)out, (int)R,
+                           (int64_t)(C / 4), accumulate);
+        DGMR_CHECK_LAUNCH();
+        return 0;
+    }
     (void)hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C, ST);
     hipLaunchKernelGGL(colsum_kernel, reduce_grid(1, R), dim3(256), 0, ST, x, tmp, R, C);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, tmp, out, C, accumulate);
