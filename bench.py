@@ -194,8 +194,9 @@ def main():
             "data": "synthetic torch.rand frames, random-init weights",
             "config": {"workload": f"DGMR.training_step {args.workload}: {kw}, H=W={hw}", "per_gpu_batch": B, "global_batch": world * B,
                        "frames_per_sample": 4 + T, "parallelism": f"dp{world}",
-                       "semantics": "fast (discarded work skipped)" if args.fast else "strict reference semantics (checkpoint recompute, "
-                                    "un-detached D pass, extra logging forward)"},
+                       "semantics": "fast (state-only forwards skipped too)" if args.fast else
+                                    "strict: every observable effect of the reference step (losses, both Adam updates, u/v / BN / RNG "
+                                    "state incl. checkpoint-recompute and logging forwards); never-read gradients are not computed"},
         }
         if roofline:
             out["roofline"] = roofline

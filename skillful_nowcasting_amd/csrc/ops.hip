@@ -1073,7 +1073,7 @@ extern "C" int dgmr_bn_bwd_apply(const float* gy, const float* x, const float* m
 
 extern "C" int dgmr_colsum(const float* x, float* out, double* tmp, int64_t R, int C, int accumulate, void* stream) {
     DGMR_CHECK_ARG(x && out && tmp, "dgmr_colsum: null pointer");
-    if (R <= 256 && C >= 4096 && C % 4 == 0) {  // few rows, many columns: parallel over columns, no atomics
+    if (R <= 4096 && C >= 4096 && C % 4 == 0) {  // few rows, many columns: parallel over columns, no atomics
         hipLaunchKernelGGL(sum_rows_kernel, dim3(ew_blocks(C / 4)), dim3(EW_THREADS), 0, ST, (const f32x4*)x, (f32x4*)out, (int)R,
                            (int64_t)(C / 4), accumulate);
         DGMR_CHECK_LAUNCH();

@@ -1,11 +1,14 @@
 """DGMR LightningModule (mirror of dgmr/dgmr.py) driving the HIP operators.
 
 ``training_step`` keeps the reference's manual-optimisation order (2 discriminator passes, then the
-generator pass over ``generation_steps`` draws).  With ``strict_reference_semantics=True`` (default) it
-replays the reference literally — activation checkpointing of the generator, the un-detached predictions in
-the D pass and the extra logging forward — so buffers (u/v, BN running statistics)
-advance exactly as the reference's do.  ``strict_reference_semantics=False`` skips work whose results are
-discarded (G recompute, cross-network gradients, the extra forward).
+generator pass over ``generation_steps`` draws).  With ``strict_reference_semantics=True`` (default) every
+OBSERVABLE effect of the reference's step is reproduced — losses, both optimiser updates, and the state that
+forwards mutate (spectral-norm u/v, BatchNorm running statistics, the CPU RNG stream), including the second
+advance caused by activation checkpointing's recompute and the extra logging forward.
+What is NOT executed is gradient work whose result nothing reads: the D-pass back-propagation into the
+generator (zeroed by ``g_opt.zero_grad()``) and the G-pass weight gradients of the discriminator (zeroed by
+the next ``d_opt.zero_grad()``).  ``strict_reference_semantics=False`` additionally drops the state-only
+forwards (checkpoint recompute, logging forward), so buffers advance fewer times than the reference's.
 """
 import torch
 from huggingface_hub import PyTorchModelHubMixin
@@ -146,7 +149,17 @@ class DGMR(
         for _ in range(2):
             d_opt.zero_grad()
             if strict:
-                predictions = self._generate(images)
+                # reference: predictions = checkpoint(self.forward, images), NOT detached (dgmr.py:150-157).  Its D-loss
+                # backward therefore (a) re-runs the generator forward once (checkpoint recompute, same RNG state -> same z),
+                # which advances u/v and the BatchNorm running statistics a second time, and (b) back-propagates into generator
+                # gradients that g_opt.zero_grad() (dgmr.py:199) discards.  (a) is replayed for its side effects, (b) is dead.
+                rng0 = torch.get_rng_state()
+                with torch.no_grad():
+                    predictions = self.forward(images)
+                    rng1 = torch.get_rng_state()
+                    torch.set_rng_state(rng0)
+                    self.forward(images)
+                    torch.set_rng_state(rng1)
             else:
                 with torch.no_grad():
                     predictions = self.forward(images)
@@ -159,22 +172,22 @@ class DGMR(
         # Optimize Generator #
         ######################
         predictions = [self._generate(images) for _ in range(self.generation_steps)]
-        if not strict:  # D's parameter gradients from this pass are discarded by the next d_opt.zero_grad()
-            for p in self.discriminator.parameters():
-                p.requires_grad_(False)
+        # D's parameter gradients from this pass are never read (the next d_opt.zero_grad() clears them): not computed
+        for p in self.discriminator.parameters():
+            p.requires_grad_(False)
         generator_loss, grid_cell_reg = self._gen_losses(images, future_images, predictions)
         g_opt.zero_grad()
         self.manual_backward(generator_loss)
         if self.grad_sync is not None:
             self.grad_sync.sync("g")
         g_opt.step()
-        if not strict:
-            for p in self.discriminator.parameters():
-                p.requires_grad_(True)
+        for p in self.discriminator.parameters():
+            p.requires_grad_(True)
         self.log_dict({"train/d_loss": discriminator_loss, "train/g_loss": generator_loss, "train/grid_loss": grid_cell_reg},
                       prog_bar=True)
         if strict or self.visualize:
-            generated_images = self(images)
+            with torch.no_grad():  # the logging forward (dgmr.py:213): only its side effects on buffers / RNG matter
+                generated_images = self(images)
             if self.visualize:
                 self.visualize_step(images, future_images, generated_images, self.global_iteration, step="train")
         return {"d_loss": discriminator_loss.detach(), "g_loss": generator_loss.detach(), "grid_loss": grid_cell_reg.detach()}
