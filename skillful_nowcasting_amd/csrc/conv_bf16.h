@@ -96,9 +96,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
 
     struct Stage {
         f32x4 a[AP], b[BP], pa, pb;
-        unsigned vmask;
+        unsigned vmask, bmask;
         int ci;
     };
+    // Every load below is UNCONDITIONAL (invalid elements read a clamped, always-mapped address and are zeroed at store time):
+    // a load inside a divergent `if` makes hipcc wait vmcnt(0) right behind it, which serialises the whole operand fetch.
+    const int us = p.upsample ? 1 : 0;
+    const int Hs = p.H >> us, Ws = p.W >> us;
+    const float* pa_base = p.pre_a ? p.pre_a : p.x;
+    const float* pb_base = p.pre_a ? p.pre_b : p.x;
     auto load = [&](Stage& s) {
         const bool kok = k < Ktot;
         const int dz = kz - pd, dy = ky - ph, dx = kx - pw;
@@ -108,30 +114,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
         for (int i = 0; i < AP; ++i) {
             const int id = rd[i] + dz, ih = rh[i] + dy, iw = rw[i] + dx;
             const bool valid = rok[i] && kok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (valid) {
-                uint32_t off;
-                if (p.upsample) off = ((((uint32_t)rn[i] * p.D + id) * (p.H >> 1) + (ih >> 1)) * (p.W >> 1) + (iw >> 1)) * p.Cin + ci;
-                else off = ((((uint32_t)rn[i] * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + ci;
-                v = *reinterpret_cast<const f32x4*>(p.x + off);
-                vm |= 1u << i;
-            }
-            s.a[i] = v;
+            const uint32_t off = ((((uint32_t)rn[i] * p.D + id) * Hs + (ih >> us)) * Ws + (iw >> us)) * p.Cin + ci;
+            s.a[i] = *reinterpret_cast<const f32x4*>(p.x + (valid ? off : 0u));
+            vm |= (valid ? 1u : 0u) << i;
         }
         s.vmask = vm;
-        if (grp_uniform && kok) {
-            const uint32_t g = (uint32_t)grp0 * p.Cin + ci;
-            s.pa = *reinterpret_cast<const f32x4*>(p.pre_a + g);
-            s.pb = *reinterpret_cast<const f32x4*>(p.pre_b + g);
+        {
+            const uint32_t g = (grp_uniform && kok) ? (uint32_t)grp0 * p.Cin + ci : 0u;
+            s.pa = *reinterpret_cast<const f32x4*>(pa_base + g);
+            s.pb = *reinterpret_cast<const f32x4*>(pb_base + g);
         }
-        const uint32_t wk = (uint32_t)tap * p.w_cin + p.w_coff + ci;
+        const uint32_t wk = kok ? (uint32_t)tap * p.w_cin + p.w_coff + ci : 0u;
+        unsigned bm = 0;
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             const int co = n0 + i * RPP + lrow;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (co < p.Cout && kok) v = *reinterpret_cast<const f32x4*>(p.w + (uint32_t)co * wrow + wk);
-            s.b[i] = v;
+            const bool ok = co < p.Cout && kok;
+            s.b[i] = *reinterpret_cast<const f32x4*>(p.w + (uint32_t)min(co, p.Cout - 1) * wrow + wk);
+            bm |= (ok ? 1u : 0u) << i;
         }
+        s.bmask = bm;
         // advance to the next k tile
         k += BK;
         ci += BK;
@@ -148,25 +150,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
         }
     };
     auto store = [&](const Stage& s, int buf) {
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             f32x4 v = s.a[i];
-            const bool valid = (s.vmask >> i) & 1u;
             if (p.pre_a) {
-                if (valid) {
-                    f32x4 a = s.pa, b = s.pb;
-                    if (!grp_uniform) {
-                        const uint32_t g = (uint32_t)(rn[i] / p.pre_group) * p.Cin + s.ci;
-                        a = *reinterpret_cast<const f32x4*>(p.pre_a + g);
-                        b = *reinterpret_cast<const f32x4*>(p.pre_b + g);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.f);
+                f32x4 a = s.pa, b = s.pb;
+                if (!grp_uniform) {  // tile straddles two statistics groups (never at the model's shapes): per-row lookup
+                    const uint32_t g = (uint32_t)(rn[i] / p.pre_group) * p.Cin + s.ci;
+                    a = *reinterpret_cast<const f32x4*>(p.pre_a + g);
+                    b = *reinterpret_cast<const f32x4*>(p.pre_b + g);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.f);
             } else if (p.pre_relu) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
+            v = ((s.vmask >> i) & 1u) ? v : zero4;
             u32x2 hi, lo;
             split4<SPLIT>(v, hi, lo);
             uint32_t* dst = As + ((buf * NP) * BM + i * RPP + lrow) * LDW + kq * 2;
@@ -175,8 +176,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
+            const f32x4 v = ((s.bmask >> i) & 1u) ? s.b[i] : zero4;
             u32x2 hi, lo;
-            split4<SPLIT>(s.b[i], hi, lo);
+            split4<SPLIT>(v, hi, lo);
             uint32_t* dst = Bs + ((buf * NP) * BN + i * RPP + lrow) * LDW + kq * 2;
             *reinterpret_cast<u32x2*>(dst) = hi;
             if (SPLIT) *reinterpret_cast<u32x2*>(dst + BN * LDW) = lo;
@@ -225,18 +227,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
     // load has a whole iteration (and the other resident workgroup's MFMAs) to land before it is split and stored.
     Stage st0, st1;
     load(st0);
-    if (kt0 + 1 < nk) load(st1);
+    load(st1);  // beyond the last tile k >= Ktot: harmless clamped loads, zero tiles
     store(st0, 0);
     __syncthreads();
     for (int kt = kt0; kt < nk; kt += 2) {
-        if (kt + 2 < nk) load(st0);
+        load(st0);
         mma(0);
-        if (kt + 1 < nk) store(st1, 1);
+        store(st1, 1);
         __syncthreads();
         if (kt + 1 >= nk) break;
-        if (kt + 3 < nk) load(st1);
+        load(st1);
         mma(1);
-        if (kt + 2 < nk) store(st0, 0);
+        store(st0, 0);
         __syncthreads();
     }
 
