@@ -78,11 +78,18 @@ typedef struct dgmr_conv_args {
     float* pre_out;        /* [M][Cout] receives the pre-activation (scale+bias applied) in the GRU modes (needed by the backward) */
     float* splitk_ws;      /* NULL, or scratch for split-K partial sums */
     int64_t splitk_ws_bytes;
+    const uint16_t* w_split; /* NULL, or the SAME weights pre-split into bf16 planes [2][Cout][KH*KW][Cin] by dgmr_split_weights
+                                (dense: w_cin == Cin): lets the bf16 modes run 3x3 convs of the big feature maps through the
+                                LDS-window kernel */
 } dgmr_conv_args;
 
 #define DGMR_EPI_PLAIN 0
 #define DGMR_EPI_GRU_GATE 1  /* pre_out = v ; y = sigmoid(v) * gru_h                              (ConvGRU.py:69-71,78) */
 #define DGMR_EPI_GRU_BLEND 2 /* pre_out = v ; y = s*gru_h + (1-s)*relu(v), s = sigmoid(gru_pu)     (ConvGRU.py:80-84) */
+
+/* out[0][i] = bf16(w_i), out[1][i] = bf16(w_i - out[0][i]) for the [rows][Cin] slice [w_coff, w_coff+Cin) of a [rows][w_cin]
+ * weight matrix (rows = Cout * taps; w_cin == 0: dense).  Cin must be even.  Valid until the weights change. */
+int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, int w_cin, int w_coff, void* stream);
 
 /* Arithmetic of the forward / data-gradient contraction (process-wide; tensors in HBM stay fp32, accumulation is fp32):
  *   DGMR_PREC_F32     exact fp32 on v_mfma_f32_32x32x2_f32 (157 TF peak) -- the parity mode

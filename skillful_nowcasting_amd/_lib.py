@@ -26,7 +26,7 @@ class ConvArgs(Structure):
         ("KD", c_int32), ("KH", c_int32), ("KW", c_int32), ("upsample", c_int32), ("pre_relu", c_int32),
         ("scale_group", c_int32), ("pre_group", c_int32), ("mask_group", c_int32), ("act_relu", c_int32),
         ("w_cin", c_int32), ("w_coff", c_int32), ("epi_mode", c_int32), ("ksplit", c_int32),
-        ("gru_h", P), ("gru_pu", P), ("pre_out", P), ("splitk_ws", P), ("splitk_ws_bytes", c_int64),
+        ("gru_h", P), ("gru_pu", P), ("pre_out", P), ("splitk_ws", P), ("splitk_ws_bytes", c_int64), ("w_split", P),
     ]
 
 
@@ -96,6 +96,7 @@ SIGNATURES = {
     "dgmr_hinge_disc": [P, P, P, P, P, i, i, P],
     "dgmr_grid_cell_loss": [P, i, L, P, f, P, P, f, P, L, P],
     "dgmr_adam": [P, P, P, P, L, f, f, f, f, i, P],
+    "dgmr_split_weights": [P, P, L, i, i, i, P],
     "dgmr_set_precision": [i],
     "dgmr_get_precision": [],
     "dgmr_profile_enable": [i],

@@ -488,6 +488,32 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     else if (bn == 96) variant = V_F128x96;
     else if (bn == 64) variant = wgs128 >= 256 ? V_F128x64 : V_F64x64;
     else variant = V_F128x32;
+    // 3x3 convs of the big feature maps in the bf16 modes: LDS-window kernel (needs pre-split weights)
+    if (g_precision != 0 && p.w_split && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.D == 1 && p.w_cin == p.Cin && p.w_coff == 0 &&
+        p.Cin % 8 == 0 && p.epi_mode == DGMR_EPI_PLAIN && (p.W == 16 || p.W % 32 == 0) && M64 >= 128 * 192) {
+        const int tw_shift = p.W == 16 ? 4 : 5;
+        const int TWv = 1 << tw_shift, THv = 128 >> tw_shift;
+        if (p.H % THv == 0) {
+            const int tiles_w = p.W / TWv, tiles_hw = tiles_w * (p.H / THv);
+            const int bnw = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
+            const dim3 grid((unsigned)(p.N * tiles_hw), (unsigned)((C + bnw - 1) / bnw));
+            const int v = bnw == 128 ? V_F128x128 : (bnw == 96 ? V_F128x96 : V_F128x64);
+            ProfScope ps(v, flops, s);
+#define DGMR_WIN(BN_, WM_, WN_)                                                                                              \
+    do {                                                                                                                     \
+        if (g_precision == 1)                                                                                                \
+            hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw); \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw); \
+    } while (0)
+            if (bnw == 128) DGMR_WIN(128, 2, 2);
+            else if (bnw == 96) DGMR_WIN(96, 4, 1);
+            else DGMR_WIN(64, 4, 1);
+#undef DGMR_WIN
+            DGMR_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     // Split-K when the output grid cannot fill the 256 CUs (ConvGRU steps, latent stack, deep discriminator layers): the k
     // loop is the only parallelism left.  Needs a workspace; chosen so that grid * ksplit ~ 512 workgroups, >= 4 k-tiles each.
     p.ksplit = 1;
@@ -640,6 +666,20 @@ extern "C" int dgmr_sn_wgrad_finalize(const float* g, float* gw, float* dot, con
     hipLaunchKernelGGL(sn_wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, s, g, gw, dot, inv_sigma, u, v, Cout, Cin, taps, groups,
                        accumulate);
     if (dot) hipLaunchKernelGGL(zero_n_kernel, dim3(1), dim3(64), 0, s, dot, groups);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, int w_cin, int w_coff, void* stream) {
+    DGMR_CHECK_ARG(w && out && rows > 0 && Cin > 0 && Cin % 2 == 0, "dgmr_split_weights: bad args (Cin=%d must be even)", Cin);
+    if (w_cin == 0) {
+        w_cin = Cin;
+        w_coff = 0;
+    }
+    DGMR_CHECK_ARG(w_coff >= 0 && w_coff + Cin <= w_cin, "dgmr_split_weights: bad slice");
+    const int64_t total = rows * Cin;
+    const int blocks = (int)std::min<int64_t>((total / 2 + 255) / 256, 2048);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, total, Cin, w_cin, w_coff);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

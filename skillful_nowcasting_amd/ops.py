@@ -15,6 +15,7 @@ epilogue fuse the spectral-norm chain rule and skips autograd's separate accumul
 from __future__ import annotations
 
 import ctypes
+import weakref
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -41,9 +42,11 @@ PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
 def set_precision(mode: str):
     """Arithmetic of the forward / data-gradient contractions (tensors stay fp32 in HBM, accumulation is fp32):
     "f32" exact fp32 MFMA (parity mode, default) | "bf16x3" split-bf16, fp32-class accuracy at 5x the ceiling | "bf16"."""
+    global _PRECISION_CODE
     if mode not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {mode!r}")
     call("dgmr_set_precision", PRECISIONS[mode])
+    _PRECISION_CODE = PRECISIONS[mode]
 
 
 def get_precision() -> str:
@@ -253,16 +256,41 @@ def _flipped_weight(w: torch.Tensor, coff: int = 0, cin: Optional[int] = None) -
     if cin is None:
         cin = cin_total
     key = (id(w), coff, cin)
-    tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr())
+    tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
     hit = _flip_cache.get(key)
-    if hit is not None and hit[0] == tag:
+    if hit is not None and hit[0] == tag and hit[2]() is w:  # the weakref guards against id() reuse after a parameter is freed
         return hit[1]
     ks = list(w.shape[2:])
     kd, kh, kw = ([1] + ks) if len(ks) == 2 else ks
     wt = torch.empty(cout * cin * kd * kh * kw, device=w.device, dtype=torch.float32)
     call("dgmr_conv_flip_weights", _p(w), _p(wt), cout, cin, kd, kh, kw, cin_total, coff, _stream())
-    _flip_cache[key] = (tag, wt)
+    _flip_cache[key] = (tag, wt, weakref.ref(w))
     return wt
+
+
+_split_cache = {}
+_PRECISION_CODE = 0  # mirror of the library's mode (set_precision keeps it in sync): 0 means no pre-split weights are needed
+
+
+def _split_planes(w: torch.Tensor, flipped: bool) -> Optional[torch.Tensor]:
+    """bf16 (hi, lo) planes of a 2-D 3x3 conv weight (or of its flipped / transposed version for the data gradient), cached until
+    the parameter changes.  None when the LDS-window kernel cannot take this conv (mode f32, not 3x3, channel count % 8)."""
+    if _PRECISION_CODE == 0 or w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
+        return None
+    cout, cin = w.shape[0], w.shape[1]
+    rows_c, k_c = (cin, cout) if flipped else (cout, cin)  # rows of the matrix the kernel sees, and its input channels
+    if k_c % 8:
+        return None
+    key = (id(w), flipped)
+    tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    hit = _split_cache.get(key)
+    if hit is not None and hit[0] == tag and hit[2]() is w:
+        return hit[1]
+    src = _flipped_weight(w) if flipped else w
+    out = torch.empty(2 * w.numel(), device=w.device, dtype=torch.int16)
+    call("dgmr_split_weights", _p(src), _p(out), rows_c * 9, k_c, 0, 0, _stream())
+    _split_cache[key] = (tag, out, weakref.ref(w))
+    return out
 
 
 def _kdims(w: torch.Tensor):
@@ -276,8 +304,9 @@ EPI_PLAIN, EPI_GRU_GATE, EPI_GRU_BLEND = 0, 1, 2
 def _launch_conv(x, w_ptr, bias, scale, y, n, d, h, w_, cin, cout, kd, kh, kw, *, upsample=False, pre_relu=False, pre_a=None,
                  pre_b=None, pre_group=1, residual=None, addend=None, mask_src=None, mask_a=None, mask_b=None, mask_group=1,
                  scale_group=None, act_relu=False, w_cin=0, w_coff=0, epi_mode=EPI_PLAIN, gru_h=None, gru_pu=None, pre_out=None,
-                 device=None):
+                 device=None, w_split=None):
     a = ConvArgs()
+    a.w_split = _p(w_split)
     a.w_cin, a.w_coff, a.epi_mode = w_cin, w_coff, epi_mode
     a.gru_h, a.gru_pu, a.pre_out = _p(gru_h), _p(gru_pu), _p(pre_out)
     ws = _splitk_ws(device if device is not None else (x.device if isinstance(x, torch.Tensor) else y.device))
@@ -319,7 +348,7 @@ class ConvFn(Function):
         _launch_conv(x, _p(w), bias, scale, y, n, d, h, wd, cin, cout, kd, kh, kw, upsample=spec.upsample,
                      pre_relu=spec.pre_relu, pre_a=bn.a if bn else None, pre_b=bn.b if bn else None,
                      pre_group=bn.group_size if bn else 1, residual=residual, act_relu=spec.act_relu,
-                     scale_group=n // groups)
+                     scale_group=n // groups, w_split=_split_planes(w, False) if d == 1 else None)
         ctx.spec = spec  # flags only are read from it in backward; its tensors are re-read from saved_tensors
         ctx.has_residual = residual is not None
         # parameters are kept as-is (checkpointing hands back DETACHED copies of saved tensors: .grad must land on the real ones)
@@ -392,7 +421,8 @@ class ConvFn(Function):
             wt = _flipped_weight(w)
             if spec.upsample:
                 hi = empty_cl((n, cin, h, wd) if x.dim() == 4 else (n, cin, d, h, wd), dy)
-                _launch_conv(dy, _p(wt), None, scale, hi, n, d, h, wd, cout, cin, kd, kh, kw, scale_group=n // groups)
+                _launch_conv(dy, _p(wt), None, scale, hi, n, d, h, wd, cout, cin, kd, kh, kw, scale_group=n // groups,
+                             w_split=_split_planes(w, True) if d == 1 else None)
                 g = empty_cl(x.shape, dy)
                 call("dgmr_pool_fwd", _p(hi), None, _p(g), n, d, h, wd, cin, 1, 1.0, _p(x) if (bn or spec.pre_relu) else None,
                      _p(bn_a) if bn else None, _p(bn_b) if bn else None, bn.group_size if bn else 1, st)
@@ -400,7 +430,8 @@ class ConvFn(Function):
                 g = empty_cl(x.shape, dy)
                 _launch_conv(dy, _p(wt), None, scale, g, n, d, h, wd, cout, cin, kd, kh, kw,
                              mask_src=x if (bn or spec.pre_relu) else None, mask_a=bn_a if bn else None,
-                             mask_b=bn_b if bn else None, mask_group=bn.group_size if bn else 1, scale_group=n // groups)
+                             mask_b=bn_b if bn else None, mask_group=bn.group_size if bn else 1, scale_group=n // groups,
+                             w_split=_split_planes(w, True) if d == 1 else None)
             if bn is None:
                 dx = g
             else:

@@ -40,6 +40,10 @@ def _conv_ref(x, w, b, up=False, relu_in=False):
     (1, 384, 384, 8, 3, False, False),   # small M, long K: split-K path
     (4, 64, 24, 24, 1, False, False),    # 1x1, narrow N tile
     (2, 20, 52, 17, 3, False, True),     # ragged M / N / K
+    (24, 96, 96, 32, 3, False, True),    # big map: LDS-window kernel in the bf16 modes (TW = 32, BN = 96)
+    (8, 48, 128, 32, 3, True, False),    # window kernel with nearest-2x upsample-on-load (64x64 out), Cin = 1.5 chunks
+    (96, 64, 48, 16, 3, False, False),   # window kernel, 16-wide maps (TW = 16), Cout = 48 on the 64-wide tile
+    (6, 40, 256, 64, 3, False, True),    # window kernel, Cin = 40 (ragged chunk), two N tiles of 128
 ])
 def test_conv_modes_vs_float64(precision, mode, n, cin, cout, hw, k, up, relu):
     from skillful_nowcasting_amd import ops
@@ -101,3 +105,37 @@ def test_goldens_in_reduced_modes(precision, mode, tol, ptol, name):
     }
     build, call = builders[name]
     _run_golden(name, build, call, tol=tol, ptol=ptol)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("up", [False, True])
+def test_bn_prologue_grouped_vs_float64(precision, mode, up):
+    """BatchNorm(train)+ReLU(+nearest-2x) folded into the conv's operand load, 3 call groups with their own statistics and their own
+    1/sigma epilogue scale: the T-batched G-block path, at a size that takes the LDS-window kernel in the bf16 modes."""
+    from skillful_nowcasting_amd import ops
+
+    precision(mode)
+    g = torch.Generator().manual_seed(7)
+    groups, b, cin, cout, hw = 3, 8, 64, 96, 32
+    n = groups * b
+    x = torch.randn(n, cin, hw, hw, generator=g) * 2 + 0.5
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.2
+    scale = torch.rand(groups, generator=g) + 0.5
+    xd = x.double().view(groups, b, cin, hw, hw)
+    mean = xd.mean(dim=(1, 3, 4), keepdim=True)
+    var = xd.var(dim=(1, 3, 4), keepdim=True, unbiased=False)
+    xn = ((xd - mean) / (var + 1e-5).sqrt() * gamma.double().view(1, 1, -1, 1, 1) + beta.double().view(1, 1, -1, 1, 1)).relu()
+    xn = xn.view(n, cin, hw, hw)
+    if up:
+        xn = F.interpolate(xn, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xn, w.double(), None, padding=1) * scale.double().repeat_interleave(b).view(n, 1, 1, 1)
+    dev = "cuda"
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    rm, rv, nbt = torch.zeros(cin, device=dev), torch.ones(cin, device=dev), torch.zeros((), device=dev, dtype=torch.int64)
+    bn = ops.bn_prepare(xg, gamma.to(dev), beta.to(dev), rm, rv, nbt, 1e-5, 0.1, True, groups)
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last)
+    sn = ops.SNCall(scale.to(dev), torch.zeros(groups, cout, device=dev), torch.zeros(groups, cin * 9, device=dev), groups)
+    y = ops.conv(xg, wd, None, sn.inv_sigma, None, ops.ConvSpec(upsample=up, bn=bn, sn=sn))
+    err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= TOL[mode], f"{mode}: rel err {err:.3e}"

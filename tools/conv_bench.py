@@ -70,9 +70,14 @@ def main():
         b = torch.randn(cin, device=dev) * 0.1
         flops = 2.0 * n * d * h * w * cout * cin * kd * kh * kw
 
+        wsp = None
+        if ops.get_precision() != "f32" and ks == (1, 3, 3) and cin % 8 == 0 and "--nowin" not in sys.argv:
+            wsp = torch.empty(2 * wt.numel(), device=dev, dtype=torch.int16)
+            call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, ops._stream())
+
         def fwd():
             ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, d, h, w, cin, cout, kd, kh, kw, upsample=up,
-                             pre_a=a if bn else None, pre_b=b if bn else None, pre_group=n)
+                             pre_a=a if bn else None, pre_b=b if bn else None, pre_group=n, w_split=wsp)
 
         ms = bench(fwd)
         line = f"{name:22s} M={n*d*h*w:8d} K={cin*kd*kh*kw:6d} N={cout:4d}  fwd {ms*1e3:9.1f} us {flops/ms/1e9:7.1f} TF"
