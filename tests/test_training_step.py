@@ -72,7 +72,7 @@ def _check_post(sd1, rec, keys):
 WELL_CONDITIONED = ("grad.discriminator.", "grad.generator.sampler.bn.", "grad.generator.sampler.conv_1x1.")
 
 
-def _check_grads(grads, rec, well_tol=2e-4):
+def _check_grads(grads, rec, well_tol=2e-4, ill_tol=5e-2):
     n = 0
     for k, ref in rec.items():
         if not k.startswith("grad."):
@@ -81,7 +81,7 @@ def _check_grads(grads, rec, well_tol=2e-4):
         got = grads[k[5:]].detach().cpu().float().reshape(ref.shape)
         scale = ref.abs().max().item()
         err = (got - ref).abs().max().item()
-        tol = well_tol if k.startswith(WELL_CONDITIONED) else 5e-2  # see the module docstring
+        tol = well_tol if k.startswith(WELL_CONDITIONED) else ill_tol  # see the module docstring
         if k.endswith("att_block.gamma"):
             # a single scalar, i.e. ONE heavily cancelling sum: the CPU oracle alone moves it by 1.2e-2 against the reference's
             # golden; the HIP path (split-K, slab and atomic reductions reorder the sum run to run) lands at 2.6e-2 ... 5.9e-2
@@ -149,12 +149,14 @@ def test_hip_training_step_matches_reference(precision):
 
     S.set_precision(precision)
     try:
-        _hip_training_step(2e-4 if precision == "f32" else 1e-3)  # bf16x3: measured 3.4e-4 on the worst D gradient
+        # bf16x3 perturbs every product by ~2^-16 instead of 2^-24: more ReLU-mask flips in the cancelling generator gradient
+        # (measured up to 5.1e-2 on conditioning_stack.d1, 3.4e-4 on the worst D gradient)
+        _hip_training_step(*((2e-4, 5e-2) if precision == "f32" else (1e-3, 1.5e-1)))
     finally:
         S.set_precision("f32")
 
 
-def _hip_training_step(well_tol):
+def _hip_training_step(well_tol, ill_tol):
     import skillful_nowcasting_amd as S
 
     rec, keys, kw = _golden()
@@ -171,7 +173,7 @@ def _hip_training_step(well_tol):
     torch.manual_seed(44)
     out = model.training_step((rec["images"].cuda(), rec["future"].cuda()), 0)
     torch.cuda.synchronize()
-    _check_grads(grads, rec, well_tol)
+    _check_grads(grads, rec, well_tol, ill_tol)
     ref_bw = rec["backward_losses"].tolist()
     got_bw = [float(x) for x in bw]
     for g, r in zip(got_bw, ref_bw):
