@@ -78,9 +78,9 @@ typedef struct dgmr_conv_args {
     float* pre_out;        /* [M][Cout] receives the pre-activation (scale+bias applied) in the GRU modes (needed by the backward) */
     float* splitk_ws;      /* NULL, or scratch for split-K partial sums */
     int64_t splitk_ws_bytes;
-    const uint16_t* w_split; /* NULL, or the SAME weights pre-split into bf16 planes [2][Cout][KH*KW][Cin] by dgmr_split_weights
-                                (dense: w_cin == Cin): lets the bf16 modes run 3x3 convs of the big feature maps through the
-                                LDS-window kernel */
+    const uint16_t* w_split; /* NULL, or the SAME weights (of the slice, if w_cin/w_coff select one) pre-split into dense bf16
+                                planes [2][Cout][KH*KW][Cin] by dgmr_split_weights: lets the bf16 modes run 3x3 convs of the big
+                                feature maps through the LDS-window kernel */
 } dgmr_conv_args;
 
 #define DGMR_EPI_PLAIN 0

@@ -489,8 +489,8 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     else if (bn == 64) variant = wgs128 >= 256 ? V_F128x64 : V_F64x64;
     else variant = V_F128x32;
     // 3x3 convs of the big feature maps in the bf16 modes: LDS-window kernel (needs pre-split weights)
-    if (g_precision != 0 && p.w_split && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.D == 1 && p.w_cin == p.Cin && p.w_coff == 0 &&
-        p.Cin % 8 == 0 && p.epi_mode == DGMR_EPI_PLAIN && (p.W == 16 || p.W % 32 == 0) && M64 >= 128 * 192) {
+    if (g_precision != 0 && p.w_split && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.D == 1 && p.Cin % 8 == 0 &&
+        (p.W == 16 || p.W % 32 == 0) && M64 >= 128 * 192) {
         const int tw_shift = p.W == 16 ? 4 : 5;
         const int TWv = 1 << tw_shift, THv = 128 >> tw_shift;
         if (p.H % THv == 0) {

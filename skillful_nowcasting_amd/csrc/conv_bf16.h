@@ -316,51 +316,55 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const dgmr_wgra
     int m_first = r_begin + mg * 4;
 
     f32x4 ry[4], rx[4];
-    unsigned xmask = 0;
-    int nrow[4];
+    unsigned xmask = 0, ymask = 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    // BatchNorm-on-load parameters: this thread's 4 channels never change and a slab lies inside one statistics group
+    const int DHW = p.D * p.H * p.W;
+    f32x4 bn_a = {1.f, 1.f, 1.f, 1.f}, bn_b = {0.f, 0.f, 0.f, 0.f};
+    if (p.pre_a && kp.ok) {
+        const uint32_t g = (uint32_t)((min(r_begin, M - 1) / DHW) / p.pre_group) * p.Cin + kp.ci;
+        bn_a = *reinterpret_cast<const f32x4*>(p.pre_a + g);
+        bn_b = *reinterpret_cast<const f32x4*>(p.pre_b + g);
+    }
+    const int us = p.upsample ? 1 : 0;
+    const int Hs = p.H >> us, Ws = p.W >> us;
+    const int co_c = min(co, p.Cout - 4);  // clamped (Cout % 4 == 0): invalid lanes read a mapped address and are zeroed
+    // every load is unconditional (see conv_bf16_kernel): out-of-range elements read a clamped address, masks zero them later
     auto load = [&]() {
         RowCoord r = rc;
         xmask = 0;
+        ymask = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m_first + j;
             const bool ok = m < r_end;
-            f32x4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
-            if (ok && y_on) vy = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co);
+            ry[j] = *reinterpret_cast<const f32x4*>(p.dy + (size_t)(ok ? m : 0) * p.Cout + co_c);
+            ymask |= ((ok && y_on) ? 1u : 0u) << j;
             const int id = r.d + kp.dz, ih = r.h + kp.dy, iw = r.w + kp.dx;
             const bool valid = ok && kp.ok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            if (valid) {
-                uint32_t off;
-                if (p.upsample) off = ((((uint32_t)r.n * p.D + id) * (p.H >> 1) + (ih >> 1)) * (p.W >> 1) + (iw >> 1)) * p.Cin + kp.ci;
-                else off = ((((uint32_t)r.n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + kp.ci;
-                vx = *reinterpret_cast<const f32x4*>(p.x + off);
-                xmask |= 1u << j;
-            }
-            ry[j] = vy;
-            rx[j] = vx;
-            nrow[j] = r.n;
+            const uint32_t off = ((((uint32_t)r.n * p.D + id) * Hs + (ih >> us)) * Ws + (iw >> us)) * p.Cin + kp.ci;
+            rx[j] = *reinterpret_cast<const f32x4*>(p.x + (valid ? off : 0u));
+            xmask |= (valid ? 1u : 0u) << j;
             advance_row(r, 1, p.D, p.H, p.W);
         }
         m_first += BR;
         advance_row(rc, BR, p.D, p.H, p.W);
     };
     auto store = [&](int buf) {
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            ry[j] = ((ymask >> j) & 1u) ? ry[j] : zero4;
             bsum += ry[j];
+            f32x4 v = rx[j];
             if (p.pre_a) {
-                if ((xmask >> j) & 1u) {
-                    const uint32_t g = (uint32_t)(nrow[j] / p.pre_group) * p.Cin + kp.ci;
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(p.pre_a + g);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.pre_b + g);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) rx[j][c] = fmaxf(fmaf(rx[j][c], a[c], b[c]), 0.f);
-                }
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(fmaf(v[c], bn_a[c], bn_b[c]), 0.f);
             } else if (p.pre_relu) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) rx[j][c] = fmaxf(rx[j][c], 0.f);
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
             }
+            rx[j] = ((xmask >> j) & 1u) ? v : zero4;
         }
         // transpose: channel c of the 4 pixels -> one 8-byte group of 4 consecutive pixels
 #pragma unroll
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const dgmr_wgra
     __syncthreads();
     for (int it = 0; it < nr; ++it) {
         const int cur = it & 1;
-        if (it + 1 < nr) load();
+        load();  // past the slab's end every element is masked
         const uint32_t* Yb = Ys + ((cur * NP) * BI + wi * TM * 32 + (lane & 31)) * LDW + (lane >> 5) * 4;
         const uint32_t* Xb = Xs + ((cur * NP) * BJ + wj * TN * 32 + (lane & 31)) * LDW + (lane >> 5) * 4;
 #pragma unroll

@@ -272,23 +272,28 @@ _split_cache = {}
 _PRECISION_CODE = 0  # mirror of the library's mode (set_precision keeps it in sync): 0 means no pre-split weights are needed
 
 
-def _split_planes(w: torch.Tensor, flipped: bool) -> Optional[torch.Tensor]:
-    """bf16 (hi, lo) planes of a 2-D 3x3 conv weight (or of its flipped / transposed version for the data gradient), cached until
-    the parameter changes.  None when the LDS-window kernel cannot take this conv (mode f32, not 3x3, channel count % 8)."""
+def _split_planes(w: torch.Tensor, flipped: bool, coff: int = 0, cin: Optional[int] = None) -> Optional[torch.Tensor]:
+    """bf16 (hi, lo) planes of a 2-D 3x3 conv weight — optionally of its input-channel slice [coff, coff+cin) — or of the flipped /
+    transposed version used by the data gradient; cached until the parameter changes.  None when the LDS-window kernel cannot take
+    this conv (mode f32, not 3x3, channel count % 8)."""
     if _PRECISION_CODE == 0 or w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
         return None
-    cout, cin = w.shape[0], w.shape[1]
+    cout, cin_total = w.shape[0], w.shape[1]
+    if cin is None:
+        cin = cin_total
     rows_c, k_c = (cin, cout) if flipped else (cout, cin)  # rows of the matrix the kernel sees, and its input channels
     if k_c % 8:
         return None
-    key = (id(w), flipped)
+    key = (id(w), flipped, coff, cin)
     tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
     hit = _split_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
-    src = _flipped_weight(w) if flipped else w
-    out = torch.empty(2 * w.numel(), device=w.device, dtype=torch.int16)
-    call("dgmr_split_weights", _p(src), _p(out), rows_c * 9, k_c, 0, 0, _stream())
+    out = torch.empty(2 * cout * 9 * cin, device=w.device, dtype=torch.int16)
+    if flipped:  # the flipped slice is already dense
+        call("dgmr_split_weights", _p(_flipped_weight(w, coff, cin)), _p(out), rows_c * 9, k_c, 0, 0, _stream())
+    else:
+        call("dgmr_split_weights", _p(w), _p(out), rows_c * 9, k_c, cin_total, coff, _stream())
     _split_cache[key] = (tag, out, weakref.ref(w))
     return out
 
@@ -719,22 +724,24 @@ class ConvGRUFn(Function):
         xparts = []
         for w in (wr, wu, wc):
             xp = empty_cl((tb, ch, hh, ww), x_all)
-            _launch_conv(x_all, _p(w), None, None, xp, tb, 1, hh, ww, cx, ch, 1, kh, kw, w_cin=ct, w_coff=0)
+            _launch_conv(x_all, _p(w), None, None, xp, tb, 1, hh, ww, cx, ch, 1, kh, kw, w_cin=ct, w_coff=0,
+                         w_split=_split_planes(w, False, 0, cx))
             xparts.append(xp)
         xr, xu, xc = xparts
         buf = empty_cl(((T + 1) * b, ch, hh, ww), x_all)  # h_{-1} = h0, h_0, ..., h_{T-1}
         _copy(_p(h0), _p(buf), n_step)
         pr, pu, pc, rh = (empty_cl((tb, ch, hh, ww), x_all) for _ in range(4))
         sr, su, sc = seqs
+        spr, spu, spc = (_split_planes(w, False, cx, ch) for w in (wr, wu, wc))  # h halves as bf16 planes (bf16 modes, big maps)
         for t in range(T):
             hp, out = step_ptr(buf, t), step_ptr(buf, t + 1)
             _launch_conv(hp, _p(wr), br, scale_ptr(sr, t), step_ptr(rh, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
-                         addend=step_ptr(xr, t), epi_mode=EPI_GRU_GATE, gru_h=hp, pre_out=step_ptr(pr, t), device=dev)
+                         addend=step_ptr(xr, t), epi_mode=EPI_GRU_GATE, gru_h=hp, pre_out=step_ptr(pr, t), device=dev, w_split=spr)
             _launch_conv(hp, _p(wu), bu, scale_ptr(su, t), step_ptr(pu, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
-                         addend=step_ptr(xu, t), device=dev)
+                         addend=step_ptr(xu, t), device=dev, w_split=spu)
             _launch_conv(step_ptr(rh, t), _p(wc), bc, scale_ptr(sc, t), out, b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
                          addend=step_ptr(xc, t), epi_mode=EPI_GRU_BLEND, gru_h=hp, gru_pu=step_ptr(pu, t), pre_out=step_ptr(pc, t),
-                         device=dev)
+                         device=dev, w_split=spc)
         ctx.params = params
         ctx.geom = (T, b, cx, ch, hh, ww, kh, kw)
         ctx.groups = tuple(q.groups for q in seqs)
@@ -766,6 +773,7 @@ class ConvGRUFn(Function):
         d_tot, dh_a, dh_b, d_rh, c1, c2 = (torch.empty(n_step, device=dev, dtype=torch.float32) for _ in range(6))
         dh_next = torch.empty(n_step, device=dev, dtype=torch.float32)
         wt_rh, wt_uh, wt_ch = (_flipped_weight(w, cx, ch) for w in (wr, wu, wc))
+        sp_rh, sp_uh, sp_ch = (_split_planes(w, True, cx, ch) for w in (wr, wu, wc))
         have_next = False
         for t in reversed(range(T)):
             hp = step_ptr(buf, t)
@@ -776,13 +784,14 @@ class ConvGRUFn(Function):
                 d = step_ptr(dout_all, t)
             call("dgmr_gru_blend_bwd", d, step_ptr(pu, t), hp, step_ptr(pc, t), step_ptr(dpu, t), _p(dh_a), step_ptr(dpc, t), n_step, st)
             # through the candidate conv to r*h, then through the read gate
-            _launch_conv(step_ptr(dpc, t), _p(wt_ch), None, scale_ptr(isc, gc, t), d_rh, b, 1, hh, ww, ch, ch, 1, kh, kw, device=dev)
+            _launch_conv(step_ptr(dpc, t), _p(wt_ch), None, scale_ptr(isc, gc, t), d_rh, b, 1, hh, ww, ch, ch, 1, kh, kw, device=dev,
+                         w_split=sp_ch)
             call("dgmr_gru_gate_bwd", _p(d_rh), step_ptr(pr, t), hp, step_ptr(dpr, t), _p(dh_b), n_step, st)
             # dh = dh_a + dh_b + convT(dpr / sigma_r, W_rh) + convT(dpu / sigma_u, W_uh)
             _launch_conv(step_ptr(dpr, t), _p(wt_rh), None, scale_ptr(isr, gr, t), c1, b, 1, hh, ww, ch, ch, 1, kh, kw, residual=dh_a,
-                         device=dev)
+                         device=dev, w_split=sp_rh)
             _launch_conv(step_ptr(dpu, t), _p(wt_uh), None, scale_ptr(isu, gu, t), c2, b, 1, hh, ww, ch, ch, 1, kh, kw, residual=c1,
-                         device=dev)
+                         device=dev, w_split=sp_uh)
             call("dgmr_axpby", _p(c2), _p(dh_b), _p(dh_next), 1.0, 1.0, n_step, st)
             have_next = True
         dh0 = None
@@ -797,7 +806,7 @@ class ConvGRUFn(Function):
             chain = ((dpr, wr, isr, gr, None, tmp), (dpu, wu, isu, gu, tmp, dx_all), (dpc, wc, isc, gc, dx_all, tmp))
             for dp, w, inv_s, g_, res, dst in chain:
                 _launch_conv(dp, _p(_flipped_weight(w, 0, cx)), None, inv_s, dst, tb, 1, hh, ww, ch, cx, 1, kh, kw, residual=res,
-                             scale_group=tb // g_)
+                             scale_group=tb // g_, w_split=_split_planes(w, True, 0, cx))
             dx_all = tmp
         # ---- weight / bias gradients, batched over T ----
         hprev_all = buf  # rows [0, T*B) are h_{-1} .. h_{T-2}
