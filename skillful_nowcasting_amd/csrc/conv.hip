@@ -201,10 +201,11 @@ struct ProfScope {
     }
 };
 
-enum { V_F128x128 = 0, V_F64x64, V_F128x96, V_F128x64, V_F128x32, V_W128, V_W64, V_W32, V_COUNT };
+enum { V_F128x128 = 0, V_F64x64, V_F128x96, V_F128x64, V_F128x32, V_W128, V_W64, V_W32, V_WIN128, V_WIN96, V_WIN64, V_COUNT };
 const char* const kVariantNames[V_COUNT] = {
     "conv_fwd_dgrad<128,128>", "conv_fwd_dgrad<64,64>", "conv_fwd_dgrad<128,96>", "conv_fwd_dgrad<128,64>",
-    "conv_fwd_dgrad<128,32>",  "conv_wgrad_kernel<128,128,2,2>", "conv_wgrad_kernel<64,128,2,2>", "conv_wgrad_kernel<32,128,1,4>"};
+    "conv_fwd_dgrad<128,32>",  "conv_wgrad_kernel<128,128,2,2>", "conv_wgrad_kernel<64,128,2,2>", "conv_wgrad_kernel<32,128,1,4>",
+    "conv_fwd_dgrad_win3x3<128px,128>", "conv_fwd_dgrad_win3x3<128px,96>", "conv_fwd_dgrad_win3x3<128px,64>"};
 
 // 0: exact fp32 (v_mfma_f32_32x32x2_f32)   1: bf16x3 split (fp32-class accuracy on the bf16 matrix cores)   2: plain bf16
 int g_precision = 0;
@@ -497,7 +498,7 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
             const int tiles_w = p.W / TWv, tiles_hw = tiles_w * (p.H / THv);
             const int bnw = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
             const dim3 grid((unsigned)(p.N * tiles_hw), (unsigned)((C + bnw - 1) / bnw));
-            const int v = bnw == 128 ? V_F128x128 : (bnw == 96 ? V_F128x96 : V_F128x64);
+            const int v = bnw == 128 ? V_WIN128 : (bnw == 96 ? V_WIN96 : V_WIN64);
             ProfScope ps(v, flops, s);
 #define DGMR_WIN(BN_, WM_, WN_)                                                                                              \
     do {                                                                                                                     \

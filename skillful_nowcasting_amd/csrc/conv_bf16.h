@@ -210,16 +210,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
                 bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDW + kk * 8));
                 if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BN + j * 32) * LDW + kk * 8));
             }
+            // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); small terms first
+            if (SPLIT) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (SPLIT) {  // small terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -415,16 +420,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const dgmr_wgra
                 xh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Xb + j * 32 * LDW + kk * 8));
                 if (SPLIT) xl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Xb + (BJ + j * 32) * LDW + kk * 8));
             }
+            // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); small terms first
+            if (SPLIT) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[i], xh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[i], xl[j], acc[i][j], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (SPLIT) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[i], xh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[i], xl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[i], xh[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[i], xh[j], acc[i][j], 0, 0, 0);
         }
         if (it + 1 < nr) store(cur ^ 1);
         __syncthreads();
@@ -635,16 +645,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const dgmr_conv_arg
                 bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDW + kk * 8));
                 if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BN + j * 32) * LDW + kk * 8));
             }
+            // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); small terms first
+            if (SPLIT) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (SPLIT) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     };
 
