@@ -684,18 +684,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const dgmr_conv_arg
         }
     }
 
-    // epilogue: lane = output channel, 16 pixels per MFMA block
+    // epilogue: lane = output channel, 16 pixels per MFMA block.  The whole tile lies in image n: scale and bias are hoisted, and
+    // the common case (scale, bias, optional relu - no addend / residual / mask / gating) is a straight fma + store.
+    const float sc = p.scale ? p.scale[n / p.scale_group] : 1.f;
+    float bj[TN];
+    int colj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        colj[j] = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        bj[j] = (p.bias && colj[j] < p.Cout) ? p.bias[colj[j]] : 0.f;
+    }
+    const bool simple = !p.addend && !p.residual && !p.mask_src && p.epi_mode == DGMR_EPI_PLAIN;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int m = (n * p.H + h0 + (q >> tw_shift)) * p.W + w0 + (q & (TW - 1));
+            float* yrow = p.y + (size_t)m * p.Cout;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-                if (col >= p.Cout) continue;
-                epilogue_store(p, acc[i][j][r], n, col, (size_t)m * p.Cout + col);
+                if (colj[j] >= p.Cout) continue;
+                if (simple) {
+                    float v = fmaf(acc[i][j][r], sc, bj[j]);
+                    if (p.act_relu) v = fmaxf(v, 0.f);
+                    yrow[colj[j]] = v;
+                } else {
+                    epilogue_store(p, acc[i][j][r], n, colj[j], (size_t)m * p.Cout + colj[j]);
+                }
             }
         }
     }
