@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--fast", action="store_true", help="strict_reference_semantics=False (skip discarded work)")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "off"])
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("DGMR_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default=os.environ.get("DGMR_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the conv forward/data-gradient contractions (tensors stay fp32 in HBM)")
     return ap.parse_args()
 
@@ -106,11 +106,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    backend = os.environ.get("DGMR_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for smoke-testing N ranks on one GPU
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     kw, hw, T = WORKLOADS[args.workload]
@@ -184,6 +190,16 @@ def main():
                                  "frac_of_step": tot_ms / ms_per_step},
             "per_kernel": rows,
         }
+        # HBM traffic of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs, FETCH_SIZE doubled per
+        # MI355X_MICROARCH.md): measured on one representative launch of that kernel (tools/pmc_conv.sh), not inside this process
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_dominant.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("precision") == args.precision and dom["kernel"] in pmc.get("kernel", ""):
+                roofline["traffic"] = pmc["traffic_bytes"]
+                roofline["traffic_detail"] = {k: pmc[k] for k in ("shape", "launch_us", "algorithmic_bytes", "traffic_over_algorithmic",
+                                                                  "hbm_gbps", "mfma_util", "valu_per_mfma", "traffic_note")}
+                roofline["traffic_detail"]["source"] = "profiles/r01_pmc_dominant.json (+ raw counters in profiles/r01_pmc_*.csv)"
 
     if rank == 0:
         out = {
