@@ -121,23 +121,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const dgmr_con
         __syncthreads();
     }
 
-    // Epilogue.  Lane = output channel, 16 rows per MFMA block.
     const int DHW = p.D * p.H * p.W;
+    // Epilogue.  Lane = output channel, 16 rows per MFMA block; row quantities (sample, 1/sigma, mask group) once per row, bias
+    // once per column.
     float* ws = gridDim.z > 1 ? p.splitk_ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
+    float bj[TN];
+    int colj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        colj[j] = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        bj[j] = (p.bias && colj[j] < p.Cout) ? p.bias[colj[j]] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row >= M) continue;
-            const int n = row / DHW;
+            const size_t rbase = (size_t)row * p.Cout;
+            if (ws) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-                if (col >= p.Cout) continue;
-                const size_t idx = (size_t)row * p.Cout + col;
-                if (ws) ws[idx] = acc[i][j][r];
-                else epilogue_store(p, acc[i][j][r], n, col, idx);
+                for (int j = 0; j < TN; ++j)
+                    if (colj[j] < p.Cout) ws[rbase + colj[j]] = acc[i][j][r];
+            } else {
+                const RowEpi e = row_epi(p, row, DHW);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (colj[j] < p.Cout) epilogue_store_row(p, acc[i][j][r], e, bj[j], colj[j], rbase + colj[j]);
             }
         }
     }

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
                 if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BN + j * 32) * LDW + kk * 8));
             }
             // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); small terms first
+            __builtin_amdgcn_s_setprio(1);  // the co-resident workgroup is usually in its load / store phase: matrix pipe first
             if (SPLIT) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
     };
 
@@ -248,20 +250,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
     }
 
     float* ws = gridDim.z > 1 ? p.splitk_ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
+    float bj[TN];
+    int colj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        colj[j] = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        bj[j] = (p.bias && colj[j] < p.Cout) ? p.bias[colj[j]] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row >= M) continue;
-            const int n = row / DHW;
+            const size_t rbase = (size_t)row * p.Cout;
+            if (ws) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-                if (col >= p.Cout) continue;
-                const size_t idx = (size_t)row * p.Cout + col;
-                if (ws) ws[idx] = acc[i][j][r];
-                else epilogue_store(p, acc[i][j][r], n, col, idx);
+                for (int j = 0; j < TN; ++j)
+                    if (colj[j] < p.Cout) ws[rbase + colj[j]] = acc[i][j][r];
+            } else {
+                const RowEpi e = row_epi(p, row, DHW);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (colj[j] < p.Cout) epilogue_store_row(p, acc[i][j][r], e, bj[j], colj[j], rbase + colj[j]);
             }
         }
     }
@@ -421,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const dgmr_wgra
                 if (SPLIT) xl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Xb + (BJ + j * 32) * LDW + kk * 8));
             }
             // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); small terms first
+            __builtin_amdgcn_s_setprio(1);  // the co-resident workgroup is usually in its load / store phase: matrix pipe first
             if (SPLIT) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -435,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const dgmr_wgra
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[i], xh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
         if (it + 1 < nr) store(cur ^ 1);
         __syncthreads();
@@ -646,6 +659,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const dgmr_conv_arg
                 if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BN + j * 32) * LDW + kk * 8));
             }
             // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); small terms first
+            __builtin_amdgcn_s_setprio(1);  // the co-resident workgroup is usually in its load / store phase: matrix pipe first
             if (SPLIT) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -660,6 +674,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const dgmr_conv_arg
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
     };
 

@@ -82,6 +82,47 @@ __device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + __expf(
 
 // One output element: (acc + addend) * scale + bias, then the fused tail selected by epi_mode.  Shared by the in-kernel
 // epilogue and the split-K reduce kernel.
+// Per-row quantities of the epilogue, computed once per output row instead of once per element (the integer divisions are
+// ~35 VALU instructions each): sample index, 1/sigma of its call group, index of its mask (BatchNorm) group.
+struct RowEpi {
+    int n;
+    float sc;
+    int mg;
+};
+__device__ __forceinline__ RowEpi row_epi(const dgmr_conv_args& p, int row, int DHW) {
+    RowEpi e;
+    e.n = row / DHW;
+    e.sc = p.scale ? p.scale[e.n / p.scale_group] : 1.f;
+    e.mg = p.mask_a ? e.n / p.mask_group : 0;
+    return e;
+}
+
+// One output element with the row quantities and the bias value hoisted by the caller.
+__device__ __forceinline__ void epilogue_store_row(const dgmr_conv_args& p, float v, const RowEpi& e, float bias_v, int col, size_t idx) {
+    if (p.addend) v += p.addend[idx];
+    v = fmaf(v, e.sc, bias_v);
+    if (p.epi_mode == DGMR_EPI_GRU_GATE) {
+        p.pre_out[idx] = v;
+        v = sigmoid_(v) * p.gru_h[idx];
+    } else if (p.epi_mode == DGMR_EPI_GRU_BLEND) {
+        p.pre_out[idx] = v;
+        const float s = sigmoid_(p.gru_pu[idx]);
+        v = s * p.gru_h[idx] + (1.f - s) * fmaxf(v, 0.f);
+    } else {
+        if (p.act_relu) v = fmaxf(v, 0.f);
+        if (p.residual) v += p.residual[idx];
+        if (p.mask_src) {
+            float ms = p.mask_src[idx];
+            if (p.mask_a) {
+                const size_t g = (size_t)e.mg * p.Cout + col;
+                ms = fmaf(ms, p.mask_a[g], p.mask_b[g]);
+            }
+            v = ms > 0.f ? v : 0.f;
+        }
+    }
+    p.y[idx] = v;
+}
+
 __device__ __forceinline__ void epilogue_store(const dgmr_conv_args& p, float v, int n, int col, size_t idx) {
     if (p.addend) v += p.addend[idx];
     if (p.scale) v *= p.scale[n / p.scale_group];
