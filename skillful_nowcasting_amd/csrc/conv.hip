@@ -616,6 +616,10 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
             const dim3 grid(kt, (a->Cout + 63) / 64, a->nsplit);
             if (g_precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<64, 2, 2, 3>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
             else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<64, 2, 2, 1>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
+        } else if (a->Cout % 96 == 0 && a->Cout % 128 != 0) {  // 96 / 192 / 288 output channels: no idle MFMA rows
+            const dim3 grid(kt, a->Cout / 96, a->nsplit);
+            if (g_precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<96, 1, 4, 3>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
+            else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<96, 1, 4, 1>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
         } else {
             const dim3 grid(kt, (a->Cout + 127) / 128, a->nsplit);
             if (g_precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<128, 2, 2, 3>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);

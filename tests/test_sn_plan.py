@@ -1,0 +1,69 @@
+"""Host logic of the spectral-norm plan (nn.SNPlan): descriptor table and arena layout.  CPU only, no kernel runs."""
+import ctypes
+
+import torch
+
+
+def _modules():
+    from skillful_nowcasting_amd.nn import SNConv, SNLinear1
+
+    torch.manual_seed(0)
+    return [(SNConv(8, 16, 3), 4), (SNConv(16, 8, 1), 1), (SNLinear1(32), 3), (SNConv(4, 12, 3, ndim=3), 2)]
+
+
+def test_plan_layout_is_disjoint_and_complete():
+    from skillful_nowcasting_amd._lib import SNDesc
+    from skillful_nowcasting_amd.nn import SNPlan
+
+    entries = _modules()
+    plan = SNPlan(entries)
+    raw = bytes(plan.descs_dev.cpu().numpy().tobytes())
+    descs = (SNDesc * len(entries)).from_buffer_copy(raw)
+    used = []
+    rows = cols = 0
+    for d, (m, calls) in zip(descs, entries):
+        w = m.weight_orig
+        cout, cin = w.shape[0], w.shape[1]
+        taps = w.numel() // (cout * cin)
+        k = cin * taps
+        assert (d.Cout, d.Cin, d.taps, d.T) == (cout, cin, taps, calls)
+        assert d.w == w.data_ptr() and d.gram == m._gram_buffer().data_ptr()
+        assert abs(d.eps - m.eps) <= 1e-12 * max(1.0, m.eps) or d.eps == ctypes.c_float(m.eps).value
+        assert d.row_block0 == rows and d.col_block0 == cols
+        rows += cout
+        cols += (k + 63) // 64
+        # arena regions: inv_sigma[T] | u_hist[T*Cout] | v_hist[T*K] | tmp[Cout + T]
+        regions = [(d.inv_sigma_off, calls), (d.u_hist_off, calls * cout), (d.v_hist_off, calls * k), (d.tmp_off, cout + calls)]
+        for off, n in regions:
+            assert off >= 0 and off + n <= plan.total
+            used.append((off, off + n))
+    assert (rows, cols) == (plan.rows, plan.cols)
+    used.sort()
+    for (a0, a1), (b0, b1) in zip(used, used[1:]):
+        assert a1 <= b0, "arena regions overlap"
+    assert plan.max_cout == 16
+
+
+def test_plan_valid_tracks_pointers():
+    from skillful_nowcasting_amd.nn import SNPlan
+
+    entries = _modules()
+    plan = SNPlan(entries)
+    assert plan.valid()
+    m = entries[0][0]
+    vec = getattr(m.parametrizations.weight, "0")
+    vec._u = vec._u.clone()  # a buffer moved (e.g. module.to(device)): the plan must notice
+    assert not plan.valid()
+
+
+def test_scope_is_noop_in_eval_and_traces_in_train():
+    from skillful_nowcasting_amd.nn import SNScope
+
+    owner = torch.nn.Module()
+    owner.eval()
+    with SNScope(owner, "k") as sc:
+        assert sc.noop and SNScope._active is None
+    owner.train()
+    with SNScope(owner, "k") as sc:
+        assert not sc.noop and SNScope._active is sc and sc.trace == []
+    assert SNScope._active is None
