@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DGMR_BENCH_BATCH", "16")), help="per-GPU batch")
-    ap.add_argument("--workload", default="paper", choices=["paper", "cfg2", "smoke"])
+    ap.add_argument("--workload", default="paper", choices=["paper", "cfg2", "cfg5", "smoke"])
     ap.add_argument("--fast", action="store_true", help="strict_reference_semantics=False (skip discarded work)")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "off"])
     ap.add_argument("--no-roofline", action="store_true")
@@ -44,6 +44,7 @@ WORKLOADS = {
     # name: (DGMR kwargs, H=W, T)
     "paper": (dict(forecast_steps=18, output_shape=256, latent_channels=768, context_channels=384, generation_steps=6), 256, 18),
     "cfg2": (dict(forecast_steps=4, output_shape=256, latent_channels=384, context_channels=192, generation_steps=6), 256, 4),
+    "cfg5": (dict(forecast_steps=18, output_shape=512, latent_channels=768, context_channels=384, generation_steps=6), 512, 18),
     "smoke": (dict(forecast_steps=2, output_shape=128, latent_channels=384, context_channels=192, generation_steps=2), 128, 2),
 }
 
