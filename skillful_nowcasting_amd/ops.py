@@ -264,7 +264,7 @@ def _flipped_weight(w: torch.Tensor, coff: int = 0, cin: Optional[int] = None) -
     kd, kh, kw = ([1] + ks) if len(ks) == 2 else ks
     wt = torch.empty(cout * cin * kd * kh * kw, device=w.device, dtype=torch.float32)
     call("dgmr_conv_flip_weights", _p(w), _p(wt), cout, cin, kd, kh, kw, cin_total, coff, _stream())
-    _flip_cache[key] = (tag, wt, weakref.ref(w))
+    _flip_cache[key] = (tag, wt, weakref.ref(w, lambda _r, k=key: _flip_cache.pop(k, None)))  # freed with the parameter
     return wt
 
 
@@ -294,7 +294,7 @@ def _split_planes(w: torch.Tensor, flipped: bool, coff: int = 0, cin: Optional[i
         call("dgmr_split_weights", _p(_flipped_weight(w, coff, cin)), _p(out), rows_c * 9, k_c, 0, 0, _stream())
     else:
         call("dgmr_split_weights", _p(w), _p(out), rows_c * 9, k_c, cin_total, coff, _stream())
-    _split_cache[key] = (tag, out, weakref.ref(w))
+    _split_cache[key] = (tag, out, weakref.ref(w, lambda _r, k=key: _split_cache.pop(k, None)))
     return out
 
 
