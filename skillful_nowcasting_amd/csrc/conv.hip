@@ -518,7 +518,14 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
             hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw); \
     } while (0)
             if (bnw == 128) DGMR_WIN(128, 2, 2);
-            else if (bnw == 96) DGMR_WIN(96, 4, 1);
+            else if (bnw == 96) {
+                // bf16x3 at 96 channels: ONE weight stage (48 KB of LDS instead of 63) lets three workgroups share a CU, which is
+                // worth more than the saved barrier (measured 261 -> 284 TF); plain bf16 already fits three with two stages
+                if (g_precision == 1)
+                    hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 3, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw);
+                else
+                    hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 1, 2>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw);
+            }
             else DGMR_WIN(64, 4, 1);
 #undef DGMR_WIN
             DGMR_CHECK_LAUNCH();

@@ -495,9 +495,9 @@ namespace {
 //     tap by tap through a two-stage LDS ring with no arithmetic at all;
 //   * nearest-2x upsampling stages the half-resolution halo and folds the >>1 into the window address.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const dgmr_conv_args p, const int tw_shift, const int tiles_w,
-                                                             const int tiles_hw) {
+template <int BN, int WM, int WN, int NS, int NSTAGE = 2>
+__global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(const dgmr_conv_args p, const int tw_shift,
+                                                                               const int tiles_w, const int tiles_hw) {
     constexpr int BM = 128, CK = 32;
     constexpr int LDW = CK / 2 + 4;  // 80-byte rows
     constexpr int NP = NS == 3 ? 2 : 1;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const dgmr_conv_arg
     constexpr int BPASS = (BITEMS + 255) / 256;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "bad tile");
 
-    __shared__ __attribute__((aligned(16))) uint32_t smem[NP * AMAX * LDW + 2 * NP * BN * LDW];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[NP * AMAX * LDW + NSTAGE * NP * BN * LDW];
     uint32_t* As = smem;                     // [plane][pixel][LDW]
     uint32_t* Bs = smem + NP * AMAX * LDW;   // [stage][plane][co][LDW]
 
@@ -689,13 +689,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const dgmr_conv_arg
         for (int tap = 0; tap < 9; ++tap) {
             const int s = chunk * 9 + tap;
             issue_b(s + 1);
-            mma(tap, s & 1);
-            store_b((s + 1) & 1);
-            if (tap == 8) {
-                __syncthreads();  // every wave is done with this chunk's halo
-                store_a();
+            if (NSTAGE == 2) {
+                mma(tap, s & 1);
+                store_b((s + 1) & 1);
+                if (tap == 8) {
+                    __syncthreads();  // every wave is done with this chunk's halo
+                    store_a();
+                }
+                __syncthreads();
+            } else {  // one weight stage (smaller LDS footprint, three workgroups per CU): publish only after everyone has read
+                mma(tap, 0);
+                __syncthreads();
+                store_b(0);
+                if (tap == 8) store_a();
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
 
