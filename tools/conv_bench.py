@@ -15,6 +15,9 @@ SHAPES = [
     ("up_g4.first T18", 288, 1, 128, 128, 96, 96, (1, 3, 3), True, True),
     ("up_g4.last T18", 288, 1, 128, 128, 96, 48, (1, 3, 3), False, True),
     ("up_g3.first t1", 16, 1, 64, 64, 192, 192, (1, 3, 3), True, True),
+    ("up_g3.first T18", 288, 1, 64, 64, 192, 192, (1, 3, 3), True, True),
+    ("up_g3.last T18", 288, 1, 64, 64, 192, 96, (1, 3, 3), False, True),
+    ("g3.first T18", 288, 1, 32, 32, 192, 192, (1, 3, 3), False, True),
     ("up_g2.first t1", 16, 1, 32, 32, 384, 384, (1, 3, 3), True, True),
     ("up_g2.first T18", 288, 1, 32, 32, 384, 384, (1, 3, 3), True, True),
     ("g1.first t1", 16, 1, 8, 8, 768, 768, (1, 3, 3), False, True),
