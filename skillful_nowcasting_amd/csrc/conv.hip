@@ -517,12 +517,19 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         else                                                                                                                 \
             hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw); \
     } while (0)
-            if (bnw == 128) DGMR_WIN(128, 2, 2);
-            else if (bnw == 96) {
-                // bf16x3 at 96 channels: ONE weight stage (48 KB of LDS instead of 63) lets three workgroups share a CU, which is
-                // worth more than the saved barrier (measured 261 -> 284 TF); plain bf16 already fits three with two stages
+            if (bnw == 128) {
+                // bf16x3: one weight stage + halo fetched at the chunk boundary = 53 KB of LDS and <= 168 VGPRs -> three workgroups per CU
+                // (measured 320 -> 350 TF); plain bf16 keeps the two-stage pipeline
                 if (g_precision == 1)
-                    hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 3, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw);
+                    hipLaunchKernelGGL((conv3x3_win_kernel<128, 2, 2, 3, 1, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw);
+                else DGMR_WIN(128, 2, 2);
+            }
+            else if (bnw == 96) {
+                // bf16x3 at 96 channels: ONE weight stage and the halo fetched at the chunk boundary (48 KB of LDS instead of 63, no
+                // spill at 168 VGPRs) let three workgroups share a CU, which is worth more than the saved barrier (measured
+                // 261 -> 286 TF); plain bf16 already fits three with two stages
+                if (g_precision == 1)
+                    hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 3, 1, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw);
                 else
                     hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 1, 2>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw);
             }

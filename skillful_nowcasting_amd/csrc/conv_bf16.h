@@ -495,7 +495,9 @@ namespace {
 //     tap by tap through a two-stage LDS ring with no arithmetic at all;
 //   * nearest-2x upsampling stages the half-resolution halo and folds the >>1 into the window address.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int BN, int WM, int WN, int NS, int NSTAGE = 2>
+// NSTAGE: weight stages in LDS (2: one barrier per tap; 1: two barriers, smaller footprint -> three workgroups per CU).
+// LAZYA: fetch the next halo at the chunk boundary instead of holding it in registers under the nine taps (fewer live VGPRs).
+template <int BN, int WM, int WN, int NS, int NSTAGE = 2, bool LAZYA = false>
 __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(const dgmr_conv_args p, const int tw_shift,
                                                                                const int tiles_w, const int tiles_hw) {
     constexpr int BM = 128, CK = 32;
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
     store_b(0);
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        issue_a(chunk + 1);  // next halo: in flight under the nine taps (clamped, zero beyond the last chunk)
+        if (!LAZYA) issue_a(chunk + 1);  // next halo: in flight under the nine taps (clamped, zero beyond the last chunk)
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int s = chunk * 9 + tap;
@@ -701,7 +703,10 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
                 mma(tap, 0);
                 __syncthreads();
                 store_b(0);
-                if (tap == 8) store_a();
+                if (tap == 8) {
+                    if (LAZYA) issue_a(chunk + 1);
+                    store_a();
+                }
                 __syncthreads();
             }
         }
