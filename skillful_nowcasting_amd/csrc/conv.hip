@@ -500,28 +500,33 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     else if (bn == 64) variant = wgs128 >= 256 ? V_F128x64 : V_F64x64;
     else variant = V_F128x32;
     // 3x3 convs of the big feature maps in the bf16 modes: LDS-window kernel (needs pre-split weights)
+    // 8x8 maps: a tile is two whole images; every per-sample group (1/sigma, BatchNorm statistics, relu mask) must then hold
+    // an even number of samples so that a tile never straddles two groups
+    const bool small8 = p.H == 8 && p.W == 8 && !p.upsample && p.N % 2 == 0 && (!p.scale || p.scale_group % 2 == 0) &&
+                        (!p.pre_a || p.pre_group % 2 == 0) && (!p.mask_a || p.mask_group % 2 == 0);
     if (g_precision != 0 && p.w_split && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.D == 1 && p.Cin % 8 == 0 &&
-        (p.W == 16 || p.W % 32 == 0) && M64 >= 128 * 192) {
-        const int tw_shift = p.W == 16 ? 4 : 5;
-        const int TWv = 1 << tw_shift, THv = 128 >> tw_shift;
+        (p.W == 16 || p.W % 32 == 0 || small8) && (M64 / 128) * ((C + 127) / 128) >= 192) {
+        const int tw_shift = small8 ? 3 : (p.W == 16 ? 4 : 5);
+        const int g_shift = small8 ? 1 : 0;
+        const int TWv = 1 << tw_shift, THv = (128 >> tw_shift) >> g_shift;
         if (p.H % THv == 0) {
             const int tiles_w = p.W / TWv, tiles_hw = tiles_w * (p.H / THv);
             const int bnw = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
-            const dim3 grid((unsigned)(p.N * tiles_hw), (unsigned)((C + bnw - 1) / bnw));
+            const dim3 grid((unsigned)(g_shift ? p.N >> g_shift : p.N * tiles_hw), (unsigned)((C + bnw - 1) / bnw));
             const int v = bnw == 128 ? V_WIN128 : (bnw == 96 ? V_WIN96 : V_WIN64);
             ProfScope ps(v, flops, s);
 #define DGMR_WIN(BN_, WM_, WN_)                                                                                              \
     do {                                                                                                                     \
         if (g_precision == 1)                                                                                                \
-            hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw); \
+            hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
         else                                                                                                                 \
-            hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw); \
+            hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
     } while (0)
             if (bnw == 128) {
                 // bf16x3: one weight stage + halo fetched at the chunk boundary = 53 KB of LDS and <= 168 VGPRs -> three workgroups per CU
                 // (measured 320 -> 350 TF); plain bf16 keeps the two-stage pipeline
                 if (g_precision == 1)
-                    hipLaunchKernelGGL((conv3x3_win_kernel<128, 2, 2, 3, 1, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw);
+                    hipLaunchKernelGGL((conv3x3_win_kernel<128, 2, 2, 3, 1, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
                 else DGMR_WIN(128, 2, 2);
             }
             else if (bnw == 96) {
@@ -529,9 +534,9 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
                 // spill at 168 VGPRs) let three workgroups share a CU, which is worth more than the saved barrier (measured
                 // 261 -> 286 TF); plain bf16 already fits three with two stages
                 if (g_precision == 1)
-                    hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 3, 1, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw);
+                    hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 3, 1, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
                 else
-                    hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 1, 2>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw);
+                    hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 1, 2>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
             }
             else DGMR_WIN(64, 4, 1);
 #undef DGMR_WIN

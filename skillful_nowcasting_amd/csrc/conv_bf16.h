@@ -499,7 +499,8 @@ namespace {
 // LAZYA: fetch the next halo at the chunk boundary instead of holding it in registers under the nine taps (fewer live VGPRs).
 template <int BN, int WM, int WN, int NS, int NSTAGE = 2, bool LAZYA = false>
 __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(const dgmr_conv_args p, const int tw_shift,
-                                                                               const int tiles_w, const int tiles_hw) {
+                                                                               const int tiles_w, const int tiles_hw,
+                                                                               const int g_shift) {
     constexpr int BM = 128, CK = 32;
     constexpr int LDW = CK / 2 + 4;  // 80-byte rows
     constexpr int NP = NS == 3 ? 2 : 1;
@@ -517,10 +518,13 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int TW = 1 << tw_shift, TH = BM >> tw_shift;
+    // A tile is 2^g_shift whole small images (8x8 maps: two images of 64 pixels, each with its own 10x10 halo) or, for g_shift
+    // == 0, TH x TW pixels of one image.  Groups (1/sigma, BatchNorm statistics, masks) never split the images of a tile (host).
+    const int TW = 1 << tw_shift, TH = (BM >> tw_shift) >> g_shift;  // rows per sub-tile
+    const int sub_shift = 7 - g_shift;                                // log2(pixels per sub-tile)
     const int tile = blockIdx.x;
-    const int n = tile / tiles_hw;
-    const int trem = tile - n * tiles_hw;
+    const int n = g_shift ? (tile << g_shift) : tile / tiles_hw;      // first image of the tile
+    const int trem = g_shift ? 0 : tile - n * tiles_hw;
     const int th = trem / tiles_w;
     const int h0 = th * TH, w0 = (trem - th * tiles_w) * TW;
     const int n0 = blockIdx.y * BN;
@@ -528,7 +532,8 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
     const int Hs = p.H >> us, Ws = p.W >> us;
     const int oh = (h0 - 1) >> us, ow = (w0 - 1) >> us;  // halo origin in input coordinates (arithmetic shift: -1 stays -1)
     const int HTw = (TW >> us) + 2;
-    const int npix = ((TH >> us) + 2) * HTw;
+    const int HP = ((TH >> us) + 2) * HTw;  // halo pixels per sub-tile
+    const int npix = HP << g_shift;
     const int nchunks = (p.Cin + CK - 1) / CK;
     const int S = nchunks * 9;
 
@@ -539,10 +544,11 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
         const int pix = (tid >> 3) + i * 32;
-        const int lr = pix / HTw, lc = pix - lr * HTw;
+        const int sub = pix / HP, prem = pix - sub * HP;
+        const int lr = prem / HTw, lc = prem - lr * HTw;
         const int ih = oh + lr, iw = ow + lc;
         const bool ok = pix < npix && (unsigned)ih < (unsigned)Hs && (unsigned)iw < (unsigned)Ws;
-        a_goff[i] = ok ? (((uint32_t)n * Hs + ih) * Ws + iw) * p.Cin + cq * 4 : 0u;
+        a_goff[i] = ok ? (((uint32_t)(n + sub) * Hs + ih) * Ws + iw) * p.Cin + cq * 4 : 0u;
         a_valid |= (ok ? 1u : 0u) << i;
     }
     const float* pa_base = p.pre_a ? p.pre_a : p.x;
@@ -630,12 +636,13 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // tile-local pixel of this lane in each of the wave's TM row blocks
-    int prow[TM], pcol[TM];
+    int prow[TM], pcol[TM], pbase[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int q = wm * TM * 32 + i * 32 + (lane & 31);
-        prow[i] = q >> tw_shift;
+        prow[i] = (q >> tw_shift) & (TH - 1);
         pcol[i] = q & (TW - 1);
+        pbase[i] = (q >> sub_shift) * HP;  // halo of the lane's image inside the tile
     }
     auto mma = [&](int tap, int stage) {
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
         for (int i = 0; i < TM; ++i) {
             const int lr = ((h0 + prow[i] + dy) >> us) - oh;
             const int lc = ((w0 + pcol[i] + dx) >> us) - ow;
-            Ab[i] = As + (lr * HTw + lc) * LDW + (lane >> 5) * 4;
+            Ab[i] = As + (pbase[i] + lr * HTw + lc) * LDW + (lane >> 5) * 4;
         }
         const uint32_t* Bb = Bs + ((stage * NP) * BN + wn * TN * 32 + (lane & 31)) * LDW + (lane >> 5) * 4;
 #pragma unroll
@@ -728,7 +735,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int m = (n * p.H + h0 + (q >> tw_shift)) * p.W + w0 + (q & (TW - 1));
+            const int m = ((n + (q >> sub_shift)) * p.H + h0 + ((q >> tw_shift) & (TH - 1))) * p.W + w0 + (q & (TW - 1));
             float* yrow = p.y + (size_t)m * p.Cout;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {

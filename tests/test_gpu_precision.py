@@ -44,6 +44,7 @@ def _conv_ref(x, w, b, up=False, relu_in=False):
     (8, 48, 128, 32, 3, True, False),    # window kernel with nearest-2x upsample-on-load (64x64 out), Cin = 1.5 chunks
     (96, 64, 48, 16, 3, False, False),   # window kernel, 16-wide maps (TW = 16), Cout = 48 on the 64-wide tile
     (6, 40, 256, 64, 3, False, True),    # window kernel, Cin = 40 (ragged chunk), two N tiles of 128
+    (64, 64, 768, 8, 3, False, True),    # window kernel on 8x8 maps: a tile is two whole images with their own halos
 ])
 def test_conv_modes_vs_float64(precision, mode, n, cin, cout, hw, k, up, relu):
     from skillful_nowcasting_amd import ops
