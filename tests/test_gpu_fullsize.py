@@ -69,3 +69,34 @@ def test_discriminator_forward_paper_config(setup):
     assert out.shape == (2, 2, 1)
     err = (out.cpu() - ref).abs().max().item() / ref.abs().max().item()
     assert err <= 1e-3, f"discriminator forward rel err {err:.3e}"
+
+
+def test_eval_forward_and_validation_step_small_config():
+    """inference (`forward` in eval mode: frozen spectral-norm sigma, BatchNorm running statistics) against
+    the oracle's eval path, and `validation_step` (dgmr/dgmr.py:220-290) end to end."""
+    import skillful_nowcasting_amd as S
+    from oracle import dgmr_oracle as O
+
+    kw = dict(forecast_steps=4, output_shape=128, latent_channels=384, context_channels=192, generation_steps=2)
+    torch.manual_seed(5)
+    model = S.DGMR(**kw)
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to("cuda").eval()
+    x = torch.rand(2, 4, 1, 128, 128)
+    y = torch.rand(2, 4, 1, 128, 128)
+    torch.manual_seed(6)
+    z = O.draw_latent((8, 4, 4))
+    ref = O.generator(sd_cpu, "", x, z, 4, False)
+    torch.manual_seed(6)
+    with torch.no_grad():
+        out = model(x.cuda())
+    err = (out.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 1e-3, f"eval-mode generator forward rel err {err:.3e}"
+    # eval mode must not move any state
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), sd_cpu[k]), f"{k} changed in eval mode"
+    with torch.no_grad():
+        model.validation_step((x.cuda(), y.cuda()), 0)
+    torch.cuda.synchronize()
+    logged = {k: float(v) for k, v in model.logged_metrics.items()} if hasattr(model, "logged_metrics") else {}
+    assert set(logged) == {"val/d_loss", "val/g_loss", "val/grid_loss"} and all(v == v for v in logged.values()), logged
