@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGMR_ABI_VERSION 3
+#define DGMR_ABI_VERSION 4
 
 int dgmr_abi_version(void);
 const char* dgmr_last_error(void);
@@ -81,6 +81,9 @@ typedef struct dgmr_conv_args {
     const uint16_t* w_split; /* NULL, or the SAME weights (of the slice, if w_cin/w_coff select one) pre-split into dense bf16
                                 planes [2][Cout][KH*KW][Cin] by dgmr_split_weights: lets the bf16 modes run 3x3 convs of the big
                                 feature maps through the LDS-window kernel */
+    int32_t residual_up;     /* 1: residual is [N][H/2][W/2][Cout], added with nearest-2x upsampling (the 1x1 shortcut of an upsampling
+                                G-block evaluated before the upsample: conv1x1(up(x)) == up(conv1x1(x)), common.py:142-143,154) */
+    int32_t reserved0;
 } dgmr_conv_args;
 
 #define DGMR_EPI_PLAIN 0

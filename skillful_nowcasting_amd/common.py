@@ -62,9 +62,11 @@ class UpsampleGBlock(torch.nn.Module):
         self.last_conv_3x3 = conv2d(input_channels, output_channels, 3, eps=spectral_normalized_eps)
 
     def forward(self, x: torch.Tensor, calls: int = 1) -> torch.Tensor:
-        sc = self.conv_1x1(x, upsample=True, calls=calls)
+        # shortcut: conv1x1(upsample(x)) == upsample(conv1x1(x)) exactly (a 1x1 conv acts per pixel), so it is evaluated on the
+        # low-resolution map (4x fewer FLOPs and bytes) and upsampled inside the last conv's residual add
+        sc = self.conv_1x1(x, calls=calls)
         x2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x, calls), upsample=True, calls=calls)
-        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls), residual=sc, calls=calls)
+        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls), residual=sc, residual_up=True, calls=calls)
 
 
 class DBlock(torch.nn.Module):

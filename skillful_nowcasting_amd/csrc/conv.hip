@@ -161,7 +161,9 @@ __global__ void splitk_reduce_kernel(const dgmr_conv_args p, const int M, const 
         float v = 0.f;
         for (int z = 0; z < S; ++z) v += p.splitk_ws[(size_t)z * total + idx];
         const int row = idx / p.Cout, col = idx - (size_t)row * p.Cout;
-        epilogue_store(p, v, row / DHW, col, idx);
+        const int n = row / DHW;
+        const size_t ridx = (p.residual && p.residual_up) ? residual_row_base(p, n, row - n * DHW) + col : idx;
+        epilogue_store(p, v, n, col, idx, ridx);
     }
 }
 
@@ -467,6 +469,7 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     DGMR_CHECK_ARG((a->KD == 1 || a->KD == 3) && (a->KH == 1 || a->KH == 3) && (a->KW == 1 || a->KW == 3),
                    "dgmr_conv_fwd: kernel %dx%dx%d unsupported", a->KD, a->KH, a->KW);
     DGMR_CHECK_ARG(!a->upsample || (a->H % 2 == 0 && a->W % 2 == 0), "dgmr_conv_fwd: upsample needs even H,W");
+    DGMR_CHECK_ARG(!a->residual_up || (a->D == 1 && a->H % 2 == 0 && a->W % 2 == 0), "dgmr_conv_fwd: residual_up needs a 2-D map with even H,W");
     DGMR_CHECK_ARG((a->pre_a == nullptr) == (a->pre_b == nullptr), "dgmr_conv_fwd: pre_a/pre_b must come together");
     const int64_t M64 = (int64_t)a->N * a->D * a->H * a->W;
     DGMR_CHECK_ARG(M64 > 0 && M64 < (1ll << 31), "dgmr_conv_fwd: M=%lld out of range", (long long)M64);

@@ -745,7 +745,10 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
                     if (p.act_relu) v = fmaxf(v, 0.f);
                     yrow[colj[j]] = v;
                 } else {
-                    epilogue_store(p, acc[i][j][r], n, colj[j], (size_t)m * p.Cout + colj[j]);
+                    const int hh = h0 + ((q >> tw_shift) & (TH - 1)), ww = w0 + (q & (TW - 1)), ni = n + (q >> sub_shift);
+                    const size_t ridx = p.residual_up ? (((size_t)ni * (p.H >> 1) + (hh >> 1)) * (p.W >> 1) + (ww >> 1)) * p.Cout + colj[j]
+                                                      : (size_t)m * p.Cout + colj[j];
+                    epilogue_store(p, acc[i][j][r], ni, colj[j], (size_t)m * p.Cout + colj[j], ridx);
                 }
             }
         }

@@ -88,12 +88,20 @@ struct RowEpi {
     int n;
     float sc;
     int mg;
+    size_t rres;  // element offset of this row in the residual tensor
 };
+// residual_up: the residual is at half resolution [N][H/2][W/2][Cout] and is added with nearest-2x upsampling — the shortcut of an
+// upsampling G-block computed BEFORE the upsample: conv1x1(up(x)) == up(conv1x1(x)) exactly (common.py:142-143,154).
+__device__ __forceinline__ size_t residual_row_base(const dgmr_conv_args& p, int n, int pix /* index inside the sample */) {
+    const int h = pix / p.W, w = pix - h * p.W;
+    return (((size_t)n * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1)) * p.Cout;
+}
 __device__ __forceinline__ RowEpi row_epi(const dgmr_conv_args& p, int row, int DHW) {
     RowEpi e;
     e.n = row / DHW;
     e.sc = p.scale ? p.scale[e.n / p.scale_group] : 1.f;
     e.mg = p.mask_a ? e.n / p.mask_group : 0;
+    e.rres = (p.residual && p.residual_up) ? residual_row_base(p, e.n, row - e.n * DHW) : (size_t)row * p.Cout;
     return e;
 }
 
@@ -110,7 +118,7 @@ __device__ __forceinline__ void epilogue_store_row(const dgmr_conv_args& p, floa
         v = s * p.gru_h[idx] + (1.f - s) * fmaxf(v, 0.f);
     } else {
         if (p.act_relu) v = fmaxf(v, 0.f);
-        if (p.residual) v += p.residual[idx];
+        if (p.residual) v += p.residual[e.rres + col];
         if (p.mask_src) {
             float ms = p.mask_src[idx];
             if (p.mask_a) {
@@ -123,7 +131,7 @@ __device__ __forceinline__ void epilogue_store_row(const dgmr_conv_args& p, floa
     p.y[idx] = v;
 }
 
-__device__ __forceinline__ void epilogue_store(const dgmr_conv_args& p, float v, int n, int col, size_t idx) {
+__device__ __forceinline__ void epilogue_store(const dgmr_conv_args& p, float v, int n, int col, size_t idx, size_t ridx) {
     if (p.addend) v += p.addend[idx];
     if (p.scale) v *= p.scale[n / p.scale_group];
     if (p.bias) v += p.bias[col];
@@ -136,7 +144,7 @@ __device__ __forceinline__ void epilogue_store(const dgmr_conv_args& p, float v,
         v = s * p.gru_h[idx] + (1.f - s) * fmaxf(v, 0.f);
     } else {
         if (p.act_relu) v = fmaxf(v, 0.f);
-        if (p.residual) v += p.residual[idx];
+        if (p.residual) v += p.residual[ridx];
         if (p.mask_src) {
             float ms = p.mask_src[idx];
             if (p.mask_a) {

@@ -247,12 +247,12 @@ class SNConv(_SpectralNormBase):
         self._init_sn(w, b, eps)
 
     def forward(self, x, *, pre_relu: bool = False, bn: Optional[BNState] = None, upsample: bool = False, residual=None,
-                act_relu: bool = False, calls: int = 1, sn: Optional[ops.SNCall] = None):
+                act_relu: bool = False, calls: int = 1, sn: Optional[ops.SNCall] = None, residual_up: bool = False):
         """`calls` > 1: x is a batch of `calls` groups (forecast steps / frames), each group being one call of this module in
         the reference (own power iteration, own sigma).  `sn`: a record drawn earlier with `_sigma` (ConvGRU steps)."""
         if sn is None:
             sn = self._sigma(calls)
-        spec = ConvSpec(upsample=upsample, pre_relu=pre_relu, bn=bn, sn=sn, act_relu=act_relu)
+        spec = ConvSpec(upsample=upsample, pre_relu=pre_relu, bn=bn, sn=sn, act_relu=act_relu, residual_up=residual_up)
         return ops.conv(x, self.weight_orig, self.bias, sn.inv_sigma, residual, spec)
 
 

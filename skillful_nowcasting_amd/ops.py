@@ -240,6 +240,7 @@ class ConvSpec:
     sn: Optional[SNCall] = None  # spectral-norm call record (scale = 1/sigma)
     gamma_scale: bool = False  # scale tensor is a learnable scalar parameter (Attention.gamma)
     act_relu: bool = False  # relu on the output (F.relu(conv(..)), common.py:424)
+    residual_up: bool = False  # the residual is at half resolution and is added with nearest-2x upsampling
 
     @property
     def groups(self) -> int:
@@ -309,9 +310,10 @@ EPI_PLAIN, EPI_GRU_GATE, EPI_GRU_BLEND = 0, 1, 2
 def _launch_conv(x, w_ptr, bias, scale, y, n, d, h, w_, cin, cout, kd, kh, kw, *, upsample=False, pre_relu=False, pre_a=None,
                  pre_b=None, pre_group=1, residual=None, addend=None, mask_src=None, mask_a=None, mask_b=None, mask_group=1,
                  scale_group=None, act_relu=False, w_cin=0, w_coff=0, epi_mode=EPI_PLAIN, gru_h=None, gru_pu=None, pre_out=None,
-                 device=None, w_split=None):
+                 device=None, w_split=None, residual_up=False):
     a = ConvArgs()
     a.w_split = _p(w_split)
+    a.residual_up = int(bool(residual_up))
     a.w_cin, a.w_coff, a.epi_mode = w_cin, w_coff, epi_mode
     a.gru_h, a.gru_pu, a.pre_out = _p(gru_h), _p(gru_pu), _p(pre_out)
     ws = _splitk_ws(device if device is not None else (x.device if isinstance(x, torch.Tensor) else y.device))
@@ -346,6 +348,9 @@ class ConvFn(Function):
         y = empty_cl(oshape, x)
         if residual is not None:
             residual = to_cl(residual)
+            want = (n, cout, h // 2, wd // 2) if spec.residual_up else (oshape)
+            if tuple(residual.shape) != tuple(want):
+                raise RuntimeError(f"conv: residual has shape {tuple(residual.shape)}, expected {tuple(want)}")
         bn = spec.bn
         groups = spec.groups
         if n % groups:
@@ -353,7 +358,7 @@ class ConvFn(Function):
         _launch_conv(x, _p(w), bias, scale, y, n, d, h, wd, cin, cout, kd, kh, kw, upsample=spec.upsample,
                      pre_relu=spec.pre_relu, pre_a=bn.a if bn else None, pre_b=bn.b if bn else None,
                      pre_group=bn.group_size if bn else 1, residual=residual, act_relu=spec.act_relu,
-                     scale_group=n // groups, w_split=_split_planes(w, False) if d == 1 else None)
+                     scale_group=n // groups, w_split=_split_planes(w, False) if d == 1 else None, residual_up=spec.residual_up)
         ctx.spec = spec  # flags only are read from it in backward; its tensors are re-read from saved_tensors
         ctx.has_residual = residual is not None
         # parameters are kept as-is (checkpointing hands back DETACHED copies of saved tensors: .grad must land on the real ones)
@@ -449,7 +454,13 @@ class ConvFn(Function):
                 dbet = grad_buffer(bn.beta) if (bn.beta is not None and bn.beta.requires_grad) else None
                 call("dgmr_bn_bwd_apply", _p(g), _p(x), _p(bn_mean), _p(bn_rstd), _p(bn.gamma), _p(sums), None, _p(dx), _p(dgam),
                      _p(dbet), bn.groups, r, c, int(bn.train), st)
-        d_res = dy if ctx.has_residual else None
+        d_res = None
+        if ctx.has_residual:
+            if spec.residual_up:  # backward of the nearest-2x upsample: sum over the 2x2 window
+                d_res = empty_cl((n, cout, h // 2, wd // 2), dy)
+                call("dgmr_pool_fwd", _p(dy), None, _p(d_res), n, 1, h, wd, cout, 1, 1.0, None, None, None, 1, st)
+            else:
+                d_res = dy
         return dx, None, None, None, d_res, None, None, None
 
 

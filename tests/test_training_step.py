@@ -60,12 +60,19 @@ def _check_post(sd1, rec, keys):
         else:
             scale = ref.abs().max().item()
             assert (got - ref).abs().max().item() <= 1e-3 * scale + 1e-6, k
-    # fingerprints of every tensor in the model
+    # fingerprints of every tensor in the model.  Parameters: with beta1 = 0 the first Adam step is +-lr per element, so an element
+    # whose gradient is rounding noise may land on the other side (2 lr away); allowed for 2 % of a tensor's elements — and for ALL
+    # elements of a conv bias that feeds straight into BatchNorm, whose exact gradient is zero (the reference's own update of those
+    # is the sign of its rounding noise).
+    import re
+
+    noise_bias = re.compile(r"sampler\.(g\d|up_g\d)\.first_conv_3x3\.bias$|sampler\.up_g4\.(last_conv_3x3|conv_1x1)\.bias$")
     cs = _checksums(sd1, keys)
     ref = rec["cs1"]
     for i, k in enumerate(keys):
         n = sd1[k].numel()
-        tol = (2.5 * LR_MAX * n * 0.02 + 1e-3 * ref[i, 1].item() + 1e-4) if _is_param(k) else (2e-3 * ref[i, 1].item() + 1e-5)
+        frac = 1.0 if noise_bias.search(k) else 0.02
+        tol = (2.5 * LR_MAX * n * frac + 1e-3 * ref[i, 1].item() + 1e-4) if _is_param(k) else (2e-3 * ref[i, 1].item() + 1e-5)
         assert abs(cs[i, 1].item() - ref[i, 1].item()) <= tol, f"{k}: abs-sum {cs[i, 1].item()} vs {ref[i, 1].item()}"
 
 
