@@ -62,6 +62,11 @@ def cpu_baseline(kw, hw, T):
     import skillful_nowcasting_amd as S
     from oracle import dgmr_oracle as O
 
+    # torch's CPU convolutions scale badly past a few tens of threads on these shapes: on the 2x EPYC 9575F GPU box one paper-config
+    # generator forward takes 0.88 / 0.75 / 2.13 / 3.80 / 8.70 s at 8 / 16 / 32 / 64 / 128 threads (tools/cpu_threads_probe.py), so
+    # the baseline runs at the best setting rather than at torch's default (all cores)
+    threads = int(os.environ.get("DGMR_CPU_BASELINE_THREADS", "16"))
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
     torch.manual_seed(0)
     model = S.DGMR(**kw)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items() if k.startswith(("generator.", "discriminator."))}
@@ -87,7 +92,8 @@ def cpu_baseline(kw, hw, T):
     t_step = 9 * t_gf + 8 * t_gfb + 8 * t_dfb
     return {
         "value": (4 + T) / t_step, "unit": "radar frames/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"oracle (torch-CPU fp32 restatement of the reference), batch 1: G fwd {t_gf:.2f}s, G fwd+bwd {t_gfb:.2f}s, "
+        "host_cpus": os.cpu_count(),
+        "sample": f"oracle (torch-CPU fp32 restatement of the reference) at its best thread count on this host, batch 1: G fwd {t_gf:.2f}s, G fwd+bwd {t_gfb:.2f}s, "
                   f"D fwd+bwd(2 seq) {t_dfb:.2f}s; step = 9*Gf + 8*Gfb + 8*Dfb = {t_step:.1f}s (reference op counts, SURVEY §3.1)",
     }
 
