@@ -76,6 +76,8 @@ def cpu_baseline(kw, hw, T):
     x = torch.rand(1, 4, 1, hw, hw)
     y = torch.rand(1, T, 1, hw, hw)
     z = O.draw_latent((8, hw // 32, hw // 32))
+    with torch.no_grad():
+        O.generator(sd, "generator.", x, z, T, True)  # warm-up (thread pool, oneDNN primitive caches)
     t0 = time.perf_counter()
     with torch.no_grad():
         O.generator(sd, "generator.", x, z, T, True)
