@@ -13,7 +13,7 @@ i=0
 for CTRS in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $CTRS -f csv -d "$OUT/p$i" -o pmc -- \
-      python "$ROOT/tools/conv_bench.py" --prec=$PREC "$SHAPE" > "$OUT/p$i.log" 2>&1
+      python "$ROOT/tools/conv_bench.py" --prec=$PREC ${EXTRA:-} "$SHAPE" > "$OUT/p$i.log" 2>&1
   echo "pass $i rc=$?"
   F=$(find "$OUT/p$i" -name '*counter_collection.csv' | head -1)
   [ -n "$F" ] && python "$ROOT/tools/pmc_summarize.py" "$F" "$OUT/pmc_pass$i.csv"
