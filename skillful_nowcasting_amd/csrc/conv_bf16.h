@@ -729,26 +729,27 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
         colj[j] = n0 + wn * TN * 32 + j * 32 + (lane & 31);
         bj[j] = (p.bias && colj[j] < p.Cout) ? p.bias[colj[j]] : 0.f;
     }
-    const bool simple = !p.addend && !p.residual && !p.mask_src && p.epi_mode == DGMR_EPI_PLAIN;
+    const bool simple = !p.addend && !p.mask_src && p.epi_mode == DGMR_EPI_PLAIN;  // scale, bias, relu, residual: straight line
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int m = ((n + (q >> sub_shift)) * p.H + h0 + ((q >> tw_shift) & (TH - 1))) * p.W + w0 + (q & (TW - 1));
+            const int hh = h0 + ((q >> tw_shift) & (TH - 1)), ww = w0 + (q & (TW - 1)), ni = n + (q >> sub_shift);
+            const int m = (ni * p.H + hh) * p.W + ww;
             float* yrow = p.y + (size_t)m * p.Cout;
+            const size_t rbase = p.residual_up ? (((size_t)ni * (p.H >> 1) + (hh >> 1)) * (p.W >> 1) + (ww >> 1)) * p.Cout
+                                               : (size_t)m * p.Cout;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (colj[j] >= p.Cout) continue;
                 if (simple) {
                     float v = fmaf(acc[i][j][r], sc, bj[j]);
                     if (p.act_relu) v = fmaxf(v, 0.f);
+                    if (p.residual) v += p.residual[rbase + colj[j]];
                     yrow[colj[j]] = v;
                 } else {
-                    const int hh = h0 + ((q >> tw_shift) & (TH - 1)), ww = w0 + (q & (TW - 1)), ni = n + (q >> sub_shift);
-                    const size_t ridx = p.residual_up ? (((size_t)ni * (p.H >> 1) + (hh >> 1)) * (p.W >> 1) + (ww >> 1)) * p.Cout + colj[j]
-                                                      : (size_t)m * p.Cout + colj[j];
-                    epilogue_store(p, acc[i][j][r], ni, colj[j], (size_t)m * p.Cout + colj[j], ridx);
+                    epilogue_store(p, acc[i][j][r], ni, colj[j], (size_t)m * p.Cout + colj[j], rbase + colj[j]);
                 }
             }
         }
