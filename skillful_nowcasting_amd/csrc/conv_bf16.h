@@ -729,7 +729,15 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
         colj[j] = n0 + wn * TN * 32 + j * 32 + (lane & 31);
         bj[j] = (p.bias && colj[j] < p.Cout) ? p.bias[colj[j]] : 0.f;
     }
-    const bool simple = !p.addend && !p.mask_src && p.epi_mode == DGMR_EPI_PLAIN;  // scale, bias, relu, residual: straight line
+    const bool simple = !p.addend && p.epi_mode == DGMR_EPI_PLAIN;  // scale, bias, relu, residual, relu/BN mask: straight line
+    float maj[TN], mbj[TN];  // affine of the BatchNorm whose relu is being back-propagated through (data gradient), per column
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const bool on = p.mask_a && colj[j] < p.Cout;
+        const size_t g = (size_t)(n / p.mask_group) * p.Cout + (on ? colj[j] : 0);
+        maj[j] = on ? p.mask_a[g] : 1.f;
+        mbj[j] = on ? p.mask_b[g] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -747,6 +755,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
                     float v = fmaf(acc[i][j][r], sc, bj[j]);
                     if (p.act_relu) v = fmaxf(v, 0.f);
                     if (p.residual) v += p.residual[rbase + colj[j]];
+                    if (p.mask_src) v = fmaf(p.mask_src[(size_t)m * p.Cout + colj[j]], maj[j], mbj[j]) > 0.f ? v : 0.f;
                     yrow[colj[j]] = v;
                 } else {
                     epilogue_store(p, acc[i][j][r], ni, colj[j], (size_t)m * p.Cout + colj[j], rbase + colj[j]);
