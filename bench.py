@@ -178,12 +178,11 @@ def main():
         rows = [dict(kernel=lib.dgmr_profile_variant_name(i).decode(), launches=int(cnt[i]), total_ms=ms[i],
                      avg_us=(1e3 * ms[i] / cnt[i]) if cnt[i] else 0.0, tflops=(fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] > 0 else 0.0,
                      flops_per_launch=(fl[i] / cnt[i]) if cnt[i] else 0.0) for i in range(nv)]
-        # forward / data-gradient variants run in the selected precision; the weight-gradient kernels are fp32 MFMA in every mode
+        # every conv kernel (forward, data gradient, weight gradient) runs in the selected arithmetic mode
         mult = {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
         for r in rows:
-            fwd = r["kernel"].startswith("conv_fwd_dgrad")
-            r["peak_tflops"] = PEAK_BF16_MFMA_TFLOPS if (fwd and args.precision != "f32") else PEAK_F32_MFMA_TFLOPS
-            r["mfma_executed_tflops"] = r["tflops"] * (mult if fwd else 1)
+            r["peak_tflops"] = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
+            r["mfma_executed_tflops"] = r["tflops"] * mult
             r["frac"] = r["tflops"] / r["peak_tflops"]
         dom = max(rows, key=lambda r: r["total_ms"])
         tot_ms = sum(r["total_ms"] for r in rows)

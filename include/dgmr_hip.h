@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGMR_ABI_VERSION 4
+#define DGMR_ABI_VERSION 5
 
 int dgmr_abi_version(void);
 const char* dgmr_last_error(void);
@@ -267,6 +267,12 @@ int dgmr_gru_blend_bwd(const float* dout, const float* pu, const float* h, const
 int dgmr_scale_by_dev(const float* x, const float* s, float host_scale, float* y, int64_t n, void* stream);
 /* y = alpha*a + beta*b (b may be NULL) */
 int dgmr_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream);
+/* dst[i][:] = src[:] for i < repeat, rows of n floats (n % 4 == 0): einops 'b c h w -> (repeat b) c h w' at b == 1
+ * (generators.py:146-148) */
+int dgmr_repeat_rows(const float* src, float* dst, int64_t n, int repeat, void* stream);
+/* x is [groups][rows][n] (n % 4 == 0): out[g][:] = sum_r w[(g*rows + r) / rows_per_w] * x[g][r][:]; w == NULL: plain sums.
+ * Sums the per-sample gradients of a ConvGRU whose input is the same latent for every sample and step (generators.py:146-149). */
+int dgmr_group_rowsum(const float* x, const float* w, float* out, int groups, int rows, int64_t n, int rows_per_w, void* stream);
 /* dx = (x > 0) ? dy : 0 */
 int dgmr_relu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 int dgmr_fill(float* p, float value, int64_t n, void* stream);
@@ -320,6 +326,10 @@ int dgmr_profile_enable(int on);
 int dgmr_profile_variants(void);
 const char* dgmr_profile_variant_name(int variant);
 int dgmr_profile_collect(double* total_ms, double* total_flops, int64_t* launches, int n);
+/* Dispatch override for tools/conv_bench.py's tile / split-K sweeps (process-wide; -1 = the library's own choice, which is
+ * also the state at load): variant = index of a conv_fwd_dgrad<..> tile as listed by dgmr_profile_variant_name, ksplit = number
+ * of K slabs (needs a workspace in the args), window = 0 never / 1 whenever the geometry allows the LDS-window 3x3 kernel. */
+int dgmr_conv_tune(int variant, int ksplit, int window);
 
 #ifdef __cplusplus
 }

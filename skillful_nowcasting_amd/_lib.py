@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdgmr_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 P = c_void_p  # every device pointer and the stream travel as void*
 
@@ -85,6 +85,8 @@ SIGNATURES = {
     "dgmr_gru_blend_fwd": [P, P, P, P, L, P],
     "dgmr_gru_blend_bwd": [P, P, P, P, P, P, P, L, P],
     "dgmr_axpby": [P, P, P, f, f, L, P],
+    "dgmr_repeat_rows": [P, P, L, i, P],
+    "dgmr_group_rowsum": [P, P, P, i, i, L, i, P],
     "dgmr_scale_by_dev": [P, P, f, P, L, P],
     "dgmr_relu_bwd": [P, P, P, L, P],
     "dgmr_fill": [P, f, L, P],
@@ -101,6 +103,7 @@ SIGNATURES = {
     "dgmr_set_precision": [i],
     "dgmr_get_precision": [],
     "dgmr_profile_enable": [i],
+    "dgmr_conv_tune": [i, i, i],
     "dgmr_profile_variants": [],
     "dgmr_profile_collect": [P, P, P, i],
 }

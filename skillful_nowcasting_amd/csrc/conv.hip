@@ -216,11 +216,13 @@ struct ProfScope {
 enum { V_F128x128 = 0, V_F64x64, V_F128x96, V_F128x64, V_F128x32, V_W128, V_W64, V_W32, V_WIN128, V_WIN96, V_WIN64, V_COUNT };
 const char* const kVariantNames[V_COUNT] = {
     "conv_fwd_dgrad<128,128>", "conv_fwd_dgrad<64,64>", "conv_fwd_dgrad<128,96>", "conv_fwd_dgrad<128,64>",
-    "conv_fwd_dgrad<128,32>",  "conv_wgrad_kernel<128,128,2,2>", "conv_wgrad_kernel<64,128,2,2>", "conv_wgrad_kernel<32,128,1,4>",
+    "conv_fwd_dgrad<128,32>",  "conv_wgrad<128|96,128>", "conv_wgrad<64,128>", "conv_wgrad<32,128>",
     "conv_fwd_dgrad_win3x3<128px,128>", "conv_fwd_dgrad_win3x3<128px,96>", "conv_fwd_dgrad_win3x3<128px,64>"};
 
 // 0: exact fp32 (v_mfma_f32_32x32x2_f32)   1: bf16x3 split (fp32-class accuracy on the bf16 matrix cores)   2: plain bf16
 int g_precision = 0;
+// dgmr_conv_tune(): -1 = automatic
+int g_tune_variant = -1, g_tune_ksplit = -1, g_tune_window = -1;
 
 // WM x WN: wave grid of the f32 kernel; WMB x WNB: of the bf16 kernels (two register stages: 128x128 needs 8 waves to fit)
 template <int BM, int BN, int WM, int WN, int WMB = WM, int WNB = WN>
@@ -502,13 +504,15 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     else if (bn == 96) variant = V_F128x96;
     else if (bn == 64) variant = wgs128 >= 256 ? V_F128x64 : V_F64x64;
     else variant = V_F128x32;
+    if (g_tune_variant >= V_F128x128 && g_tune_variant <= V_F128x32) variant = g_tune_variant;
     // 3x3 convs of the big feature maps in the bf16 modes: LDS-window kernel (needs pre-split weights)
     // 8x8 maps: a tile is two whole images; every per-sample group (1/sigma, BatchNorm statistics, relu mask) must then hold
     // an even number of samples so that a tile never straddles two groups
     const bool small8 = p.H == 8 && p.W == 8 && !p.upsample && p.N % 2 == 0 && (!p.scale || p.scale_group % 2 == 0) &&
                         (!p.pre_a || p.pre_group % 2 == 0) && (!p.mask_a || p.mask_group % 2 == 0);
     if (g_precision != 0 && p.w_split && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.D == 1 && p.Cin % 8 == 0 &&
-        (p.W == 16 || p.W % 32 == 0 || small8) && (M64 / 128) * ((C + 127) / 128) >= 192) {
+        (p.W == 16 || p.W % 32 == 0 || small8) &&
+        (g_tune_window < 0 ? (M64 / 128) * ((C + 127) / 128) >= 192 : g_tune_window == 1)) {
         const int tw_shift = small8 ? 3 : (p.W == 16 ? 4 : 5);
         const int g_shift = small8 ? 1 : 0;
         const int TWv = 1 << tw_shift, THv = (128 >> tw_shift) >> g_shift;
@@ -552,7 +556,7 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     p.ksplit = 1;
     if (p.splitk_ws && p.splitk_ws_bytes > 0) {
         const int bm = variant == V_F64x64 ? 64 : 128;
-        const int bnv = variant == V_F64x64 ? 64 : bn;
+        const int bnv = variant == V_F128x128 ? 128 : (variant == V_F128x96 ? 96 : (variant == V_F128x32 ? 32 : 64));
         const int64_t wgs = ((M64 + bm - 1) / bm) * ((C + bnv - 1) / bnv);
         const int bk = 32;
         const int nk = (Ktot + bk - 1) / bk;
@@ -563,6 +567,10 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
             if (S > cap) S = cap;
             if (S > 64) S = 64;
             if (S > 1) p.ksplit = (int)S;
+        }
+        if (g_tune_ksplit >= 1) {
+            const int64_t cap = p.splitk_ws_bytes / ((int64_t)M64 * C * 4);
+            p.ksplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(g_tune_ksplit, cap), nk));
         }
     }
     {
@@ -727,6 +735,15 @@ extern "C" int dgmr_set_precision(int mode) {
     return 0;
 }
 extern "C" int dgmr_get_precision(void) { return g_precision; }
+
+extern "C" int dgmr_conv_tune(int variant, int ksplit, int window) {
+    DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 1,
+                   "dgmr_conv_tune: variant %d ksplit %d window %d", variant, ksplit, window);
+    g_tune_variant = variant;
+    g_tune_ksplit = ksplit;
+    g_tune_window = window;
+    return 0;
+}
 
 extern "C" int dgmr_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -420,6 +420,27 @@ __global__ void sum_rows_kernel(const f32x4* __restrict__ x, f32x4* __restrict__
     }
 }
 
+// out[g][c] = sum_r w[(g*R + r) / rows_per_w] * x[g][r][c]  (w == nullptr: plain sums); blockIdx.y = g, one thread per 4 columns
+__global__ void group_rowsum_kernel(const f32x4* __restrict__ x, const float* __restrict__ w, f32x4* __restrict__ out, int R, int64_t C4,
+                                    int rows_per_w) {
+    const int g = blockIdx.y;
+    x += (int64_t)g * R * C4;
+    out += (int64_t)g * C4;
+    GRID_STRIDE(c, C4) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < R; ++r) {
+            const float f = w ? w[((int64_t)g * R + r) / rows_per_w] : 1.f;
+            s += f * x[(int64_t)r * C4 + c];
+        }
+        out[c] = s;
+    }
+}
+
+// dst[i][c] = src[c] for i < repeat  (einops 'b ... -> (repeat b) ...' with b == 1)
+__global__ void repeat_rows_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t C4, int64_t total4) {
+    GRID_STRIDE(i, total4) dst[i] = src[i % C4];
+}
+
 __global__ void colsum_finish_kernel(const double* __restrict__ sums, float* __restrict__ out, int C, int accumulate) {
     GRID_STRIDE(c, C) out[c] = (accumulate ? out[c] : 0.f) + (float)sums[c];
 }
@@ -1082,6 +1103,25 @@ extern "C" int dgmr_colsum(const float* x, float* out, double* tmp, int64_t R, i
     (void)hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C, ST);
     hipLaunchKernelGGL(colsum_kernel, reduce_grid(1, R), dim3(256), 0, ST, x, tmp, R, C);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, tmp, out, C, accumulate);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_group_rowsum(const float* x, const float* w, float* out, int groups, int rows, int64_t n, int rows_per_w,
+                                 void* stream) {
+    DGMR_CHECK_ARG(x && out && groups >= 1 && rows >= 1 && n > 0 && n % 4 == 0 && rows_per_w >= 1,
+                   "dgmr_group_rowsum: groups=%d rows=%d n=%lld (multiple of 4) rows_per_w=%d", groups, rows, (long long)n, rows_per_w);
+    hipLaunchKernelGGL(group_rowsum_kernel, dim3(ew_blocks(n / 4), groups), dim3(EW_THREADS), 0, ST, (const f32x4*)x, w, (f32x4*)out,
+                       rows, (int64_t)(n / 4), rows_per_w);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_repeat_rows(const float* src, float* dst, int64_t n, int repeat, void* stream) {
+    DGMR_CHECK_ARG(src && dst && n > 0 && n % 4 == 0 && repeat >= 1, "dgmr_repeat_rows: n=%lld (multiple of 4) repeat=%d", (long long)n,
+                   repeat);
+    hipLaunchKernelGGL(repeat_rows_kernel, dim3(ew_blocks(n / 4 * repeat)), dim3(EW_THREADS), 0, ST, (const f32x4*)src, (f32x4*)dst,
+                       (int64_t)(n / 4), (int64_t)(n / 4) * repeat);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

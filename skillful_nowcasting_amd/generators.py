@@ -42,8 +42,9 @@ class Sampler(torch.nn.Module, PyTorchModelHubMixin):
     def forward(self, conditioning_states: List[torch.Tensor], latent_dim: torch.Tensor) -> torch.Tensor:
         init_states = conditioning_states
         T = self.forecast_steps
-        # `[latent] * T` (generators.py:146-149): the first ConvGRU sees the same latent at every step
-        h = ops.repeat_batch(latent_dim, T * init_states[0].shape[0])
+        # `[repeat(latent, B)] * T` (generators.py:146-149): the first ConvGRU sees the same map for every sample at every step,
+        # so it is handed over as the single map it is (ConvGRUFn x_shared) instead of T*B copies
+        h = latent_dim
         levels = ((self.convGRU1, self.gru_conv_1x1, self.g1, self.up_g1),
                   (self.convGRU2, self.gru_conv_1x1_2, self.g2, self.up_g2),
                   (self.convGRU3, self.gru_conv_1x1_3, self.g3, self.up_g3),
@@ -52,7 +53,7 @@ class Sampler(torch.nn.Module, PyTorchModelHubMixin):
             # only the ConvGRU is a true recurrence; its T outputs then travel as ONE time-major batch [T*B, C, h, w] through
             # the 1x1 conv, the G-block and the upsampling G-block (one launch per conv instead of T), every forecast step
             # keeping its own spectral-norm sigma and BatchNorm batch statistics exactly as the reference's T calls do
-            h = gru.forward_batched(h, init_states[3 - lvl], T)
+            h = gru.forward_batched(h, init_states[3 - lvl], T, x_shared=(lvl == 0))
             h = c11(h, calls=T)
             h = g(h, calls=T)
             h = upg(h, calls=T)

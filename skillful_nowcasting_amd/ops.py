@@ -632,9 +632,7 @@ class RepeatBatchFn(Function):
         x = to_cl(x)
         assert x.shape[0] == 1
         out = empty_cl((repeat,) + tuple(x.shape[1:]), x)
-        n = x.numel()
-        for i in range(repeat):
-            call("dgmr_axpby", _p(x), None, out.data_ptr() + 4 * n * i, 1.0, 0.0, n, _stream())
+        call("dgmr_repeat_rows", _p(x), _p(out), x.numel(), repeat, _stream())
         ctx.repeat = repeat
         return out
 
@@ -707,19 +705,26 @@ class ConvGRUFn(Function):
     separate gate kernels.  Small-M steps are split over K inside the library to fill the chip.  The backward sweeps t = T-1..0
     with three data-gradient convs per step; the x-part data gradients and all weight gradients (with the per-step
     spectral-norm chain rule) are batched over T afterwards.
+
+    x_shared: x_all is ONE sample [1, Cx, h, w] that every sample at every step receives (the sampler's first ConvGRU is fed
+    `[repeat(latent, B)] * T`, generators.py:146-149).  Its x parts are then three convs of a single 8x8 map instead of T*B
+    identical ones; the backward sums the gate gradients over the samples first (convolution is linear), so the x-part data
+    and weight gradients run on T maps instead of T*B.
     """
 
     @staticmethod
-    def forward(ctx, x_all, h0, params, seqs, steps: int):
+    def forward(ctx, x_all, h0, params, seqs, steps: int, x_shared: bool = False):
         require_hip(x_all)
         require_hip(h0, "initial state")
         x_all, h0 = to_cl(x_all), to_cl(h0)
         wr, br, wu, bu, wc, bc = params
         T = steps
-        tb, cx, hh, ww = x_all.shape
+        nx, cx, hh, ww = x_all.shape
         b, ch = h0.shape[0], h0.shape[1]
-        if tb != T * b or wr.shape[1] != cx + ch or wr.shape[0] != ch:
-            raise RuntimeError(f"ConvGRU: x {tuple(x_all.shape)} / h0 {tuple(h0.shape)} / weight {tuple(wr.shape)} do not fit T={T}")
+        tb = T * b
+        if nx != (1 if x_shared else tb) or wr.shape[1] != cx + ch or wr.shape[0] != ch:
+            raise RuntimeError(f"ConvGRU: x {tuple(x_all.shape)} / h0 {tuple(h0.shape)} / weight {tuple(wr.shape)} do not fit T={T}"
+                               f"{' (shared x)' if x_shared else ''}")
         kh, kw = wr.shape[2], wr.shape[3]
         dev = x_all.device
         n_step = b * ch * hh * ww  # floats per step tensor
@@ -734,11 +739,19 @@ class ConvGRUFn(Function):
         # x parts of the three convs for every step: raw sums (scale and bias are applied with the h part)
         xparts = []
         for w in (wr, wu, wc):
-            xp = empty_cl((tb, ch, hh, ww), x_all)
-            _launch_conv(x_all, _p(w), None, None, xp, tb, 1, hh, ww, cx, ch, 1, kh, kw, w_cin=ct, w_coff=0,
+            xp = empty_cl((nx, ch, hh, ww), x_all)
+            _launch_conv(x_all, _p(w), None, None, xp, nx, 1, hh, ww, cx, ch, 1, kh, kw, w_cin=ct, w_coff=0,
                          w_split=_split_planes(w, False, 0, cx))
+            if x_shared:  # one map for everybody: B copies, read by every step
+                x1, xp = xp, empty_cl((b, ch, hh, ww), x_all)
+                call("dgmr_repeat_rows", _p(x1), _p(xp), n_step // b, b, _stream())
             xparts.append(xp)
         xr, xu, xc = xparts
+        if x_shared:
+            def x_ptr(t_: torch.Tensor, t: int) -> int:
+                return t_.data_ptr()
+        else:
+            x_ptr = step_ptr
         buf = empty_cl(((T + 1) * b, ch, hh, ww), x_all)  # h_{-1} = h0, h_0, ..., h_{T-1}
         _copy(_p(h0), _p(buf), n_step)
         pr, pu, pc, rh = (empty_cl((tb, ch, hh, ww), x_all) for _ in range(4))
@@ -747,14 +760,15 @@ class ConvGRUFn(Function):
         for t in range(T):
             hp, out = step_ptr(buf, t), step_ptr(buf, t + 1)
             _launch_conv(hp, _p(wr), br, scale_ptr(sr, t), step_ptr(rh, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
-                         addend=step_ptr(xr, t), epi_mode=EPI_GRU_GATE, gru_h=hp, pre_out=step_ptr(pr, t), device=dev, w_split=spr)
+                         addend=x_ptr(xr, t), epi_mode=EPI_GRU_GATE, gru_h=hp, pre_out=step_ptr(pr, t), device=dev, w_split=spr)
             _launch_conv(hp, _p(wu), bu, scale_ptr(su, t), step_ptr(pu, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
-                         addend=step_ptr(xu, t), device=dev, w_split=spu)
+                         addend=x_ptr(xu, t), device=dev, w_split=spu)
             _launch_conv(step_ptr(rh, t), _p(wc), bc, scale_ptr(sc, t), out, b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
-                         addend=step_ptr(xc, t), epi_mode=EPI_GRU_BLEND, gru_h=hp, gru_pu=step_ptr(pu, t), pre_out=step_ptr(pc, t),
+                         addend=x_ptr(xc, t), epi_mode=EPI_GRU_BLEND, gru_h=hp, gru_pu=step_ptr(pu, t), pre_out=step_ptr(pc, t),
                          device=dev, w_split=spc)
         ctx.params = params
         ctx.geom = (T, b, cx, ch, hh, ww, kh, kw)
+        ctx.x_shared = x_shared
         ctx.groups = tuple(q.groups for q in seqs)
         ctx.save_for_backward(x_all, buf, pr, pu, pc, rh, sr.inv_sigma, sr.u, sr.v, su.inv_sigma, su.u, su.v, sc.inv_sigma, sc.u, sc.v)
         return buf[b:]
@@ -809,9 +823,31 @@ class ConvGRUFn(Function):
         if ctx.needs_input_grad[1]:
             dh0 = empty_cl((b, ch, hh, ww), dout_all)
             _copy(_p(dh_next), _p(dh0), n_step)
+        x_shared = ctx.x_shared
+        n_img = ch * hh * ww
+        if x_shared:
+            # every sample of a step shares x: sum the gate gradients over the B samples of each step first -> [T, ch, h, w]
+            dsum = []
+            for dp in (dpr, dpu, dpc):
+                ds = empty_cl((T, ch, hh, ww), dout_all)
+                call("dgmr_group_rowsum", _p(dp), None, _p(ds), T, b, n_img, 1, st)
+                dsum.append(ds)
+            x_rep = empty_cl((T, cx, hh, ww), dout_all)  # the shared map once per step, as the weight gradient's "input"
+            call("dgmr_repeat_rows", _p(x_all), _p(x_rep), cx * hh * ww, T, st)
         # ---- x-part data gradient, batched over the T steps (each step with its own 1/sigma) ----
         dx_all = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and x_shared:
+            # dx = sum_k convT_k( sum_t dsum_k[t] / sigma_k[t] ): three convs of ONE map
+            dx_all = empty_cl((1, cx, hh, ww), dout_all)
+            tmp = empty_cl((1, cx, hh, ww), dout_all)
+            chain = ((dsum[0], wr, isr, gr, None, tmp), (dsum[1], wu, isu, gu, tmp, dx_all), (dsum[2], wc, isc, gc, dx_all, tmp))
+            for ds, w, inv_s, g_, res, dst in chain:
+                wsum = empty_cl((1, ch, hh, ww), dout_all)
+                call("dgmr_group_rowsum", _p(ds), _p(inv_s), _p(wsum), 1, T, n_img, T // g_, st)
+                _launch_conv(wsum, _p(_flipped_weight(w, 0, cx)), None, None, dst, 1, 1, hh, ww, ch, cx, 1, kh, kw, residual=res,
+                             w_split=_split_planes(w, True, 0, cx))
+            dx_all = tmp
+        elif ctx.needs_input_grad[0]:
             dx_all = empty_cl((tb, cx, hh, ww), dout_all)
             tmp = empty_cl((tb, cx, hh, ww), dout_all)
             chain = ((dpr, wr, isr, gr, None, tmp), (dpu, wu, isu, gu, tmp, dx_all), (dpc, wc, isc, gc, dx_all, tmp))
@@ -821,8 +857,9 @@ class ConvGRUFn(Function):
             dx_all = tmp
         # ---- weight / bias gradients, batched over T ----
         hprev_all = buf  # rows [0, T*B) are h_{-1} .. h_{T-2}
-        for w, bias, dp, inv_s, u_, v_, g_, hsrc in ((wr, br, dpr, isr, ur, vr, gr, hprev_all), (wu, bu, dpu, isu, uu, vu, gu, hprev_all),
-                                                     (wc, bc, dpc, isc, uc, vc, gc, rh)):
+        for ki, (w, bias, dp, inv_s, u_, v_, g_, hsrc) in enumerate(((wr, br, dpr, isr, ur, vr, gr, hprev_all),
+                                                                     (wu, bu, dpu, isu, uu, vu, gu, hprev_all),
+                                                                     (wc, bc, dpc, isc, uc, vc, gc, rh))):
             m = tb * hh * ww
             want_bias = bias is not None and bias.requires_grad
             if not w.requires_grad:
@@ -832,24 +869,26 @@ class ConvGRUFn(Function):
                 continue
             g = torch.empty(ch * taps * ct, device=dev, dtype=torch.float32)
             dot = torch.zeros(g_, device=dev, dtype=torch.float32)
-            for src, cin, coff in ((x_all, cx, 0), (hsrc, ch, cx)):
+            # x half: T*B maps, or (shared x) the T per-step sums against T copies of the one map; h half: always T*B maps
+            x_half = (x_rep, dsum[ki], T, cx, 0) if x_shared else (x_all, dp, tb, cx, 0)
+            for src, dy, nimg, cin, coff in (x_half, (hsrc, dp, tb, ch, cx)):
                 k = taps * cin
-                ns = call_nsplit(m, ch, k, g_)
+                ns = call_nsplit(nimg * hh * ww, ch, k, g_)
                 partial = torch.empty(ns * ch * k, device=dev, dtype=torch.float32)
                 wa = WgradArgs()
-                wa.x, wa.dy, wa.partial = _p(src), _p(dp), _p(partial)
-                wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = tb, 1, hh, ww, cin, ch
+                wa.x, wa.dy, wa.partial = _p(src), _p(dy), _p(partial)
+                wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = nimg, 1, hh, ww, cin, ch
                 wa.KD, wa.KH, wa.KW = 1, kh, kw
                 wa.upsample, wa.pre_relu, wa.pre_group, wa.nsplit, wa.groups = 0, 0, 1, ns, g_
                 wa.bias_grad = _p(grad_buffer(bias)) if (want_bias and coff == 0) else None  # bias gradient once, with the x half
                 call("dgmr_conv_wgrad", ctypes.byref(wa), st)
                 call("dgmr_wgrad_reduce_slice", _p(partial), ns, g_, ch, taps, cin, ct, coff, _p(w), _p(inv_s), _p(g), _p(dot), st)
             call("dgmr_sn_wgrad_finalize", _p(g), _p(grad_buffer(w)), _p(dot), _p(inv_s), _p(u_), _p(v_), ch, ct, taps, g_, 1, st)
-        return dx_all, dh0, None, None, None
+        return dx_all, dh0, None, None, None, None
 
 
-def conv_gru(x_all, h0, params, seqs, steps: int):
-    return ConvGRUFn.apply(x_all, h0, params, seqs, steps)
+def conv_gru(x_all, h0, params, seqs, steps: int, x_shared: bool = False):
+    return ConvGRUFn.apply(x_all, h0, params, seqs, steps, x_shared)
 
 
 # ---------------------------------------------------------------------------------------------------

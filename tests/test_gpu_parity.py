@@ -100,6 +100,45 @@ def test_convgru():
     _run_golden("convgru_8_4_T3", lambda: ConvGRU(12, 4, 3), lambda m, xs, h: m(list(xs.unbind(0)), h))
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16x3", 2e-4)])
+def test_convgru_shared_input_equals_repeated_input(prec, tol):
+    """The sampler's first ConvGRU gets ONE latent map for every sample and step (generators.py:146-149).  The x_shared path
+    (x parts on one map, gate gradients summed over the samples before the x-part data / weight gradients) must equal the
+    plain path fed with T*B copies: outputs, d latent, d h0 and every parameter gradient."""
+    import copy
+
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import ops
+    from skillful_nowcasting_amd.layers import ConvGRU
+
+    T, B, cx, ch = 3, 4, 16, 8
+    S.set_precision(prec)
+    try:
+        torch.manual_seed(7)
+        a = ConvGRU(cx + ch, ch, 3).to(DEV)
+        b = copy.deepcopy(a)
+        lat = torch.randn(1, cx, 8, 8, device=DEV)
+        h0 = torch.randn(B, ch, 8, 8, device=DEV)
+        cot = torch.randn(T * B, ch, 8, 8, device=DEV)
+        res = []
+        for mod, shared in ((a, True), (b, False)):
+            l, h = lat.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+            x = l if shared else ops.repeat_batch(l, T * B)
+            out = mod.forward_batched(x, h, T, x_shared=shared)
+            (out * cot).sum().backward()
+            res.append((out, l.grad, h.grad, {k: p.grad for k, p in mod.named_parameters()}))
+        torch.cuda.synchronize()
+        (oa, la, ha, pa), (ob, lb, hb, pb) = res
+        _close(oa, ob, tol, "out")
+        _close(la, lb, tol, "d latent")
+        _close(ha, hb, tol, "d h0")
+        assert pa.keys() == pb.keys() and len(pa) == 6
+        for k in pa:
+            _close(pa[k], pb[k], tol, f"grad {k}")
+    finally:
+        S.set_precision("f32")
+
+
 def test_context_stack():
     from skillful_nowcasting_amd import ContextConditioningStack
 

@@ -36,6 +36,7 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
   find "$OUT/prof" -name '*stats*.csv' -exec cp {} "$OUT/prof_keep/" \;
   KT=$(find "$OUT/prof" -name '*kernel_trace.csv' | head -1)
   [ -n "$KT" ] && python tools/trace_by_grid.py "$KT" "$OUT/prof_keep/kernel_by_grid.csv" && head -3 "$KT" > "$OUT/prof_keep/kernel_trace_head.csv"
+  [ -n "$KT" ] && python tools/trace_gaps.py "$KT" "$OUT/prof_keep/kernel_gaps.txt" 20 ${GAPS_LAST_MS:-0}
   rm -rf "$OUT/prof"
   ls -la "$OUT/prof_keep"
 fi
