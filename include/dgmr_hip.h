@@ -328,8 +328,9 @@ const char* dgmr_profile_variant_name(int variant);
 int dgmr_profile_collect(double* total_ms, double* total_flops, int64_t* launches, int n);
 /* Dispatch override for tools/conv_bench.py's tile / split-K sweeps (process-wide; -1 = the library's own choice, which is
  * also the state at load): variant = index of a conv_fwd_dgrad<..> tile as listed by dgmr_profile_variant_name, ksplit = number
- * of K slabs (needs a workspace in the args), window = 0 never / 1 whenever the geometry allows the LDS-window 3x3 kernel. */
-int dgmr_conv_tune(int variant, int ksplit, int window);
+ * of K slabs (needs a workspace in the args), window = 0 never / 1 whenever the geometry allows the LDS-window 3x3 kernel / 2 likewise, with the experimental 256-pixel tiles;
+ * wgrad_window = 0 never / 1 (= automatic) the LDS-window weight-gradient kernel wherever the geometry allows. */
+int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window);
 
 #ifdef __cplusplus
 }

@@ -103,7 +103,7 @@ SIGNATURES = {
     "dgmr_set_precision": [i],
     "dgmr_get_precision": [],
     "dgmr_profile_enable": [i],
-    "dgmr_conv_tune": [i, i, i],
+    "dgmr_conv_tune": [i, i, i, i],
     "dgmr_profile_variants": [],
     "dgmr_profile_collect": [P, P, P, i],
 }

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "conv_bf16.h"
+#include "wgrad_win.h"
 #include "conv_device.h"
 
 namespace {
@@ -222,7 +223,7 @@ const char* const kVariantNames[V_COUNT] = {
 // 0: exact fp32 (v_mfma_f32_32x32x2_f32)   1: bf16x3 split (fp32-class accuracy on the bf16 matrix cores)   2: plain bf16
 int g_precision = 0;
 // dgmr_conv_tune(): -1 = automatic
-int g_tune_variant = -1, g_tune_ksplit = -1, g_tune_window = -1;
+int g_tune_variant = -1, g_tune_ksplit = -1, g_tune_window = -1, g_tune_wgrad_window = -1;
 
 // WM x WN: wave grid of the f32 kernel; WMB x WNB: of the bf16 kernels (two register stages: 128x128 needs 8 waves to fit)
 template <int BM, int BN, int WM, int WN, int WMB = WM, int WNB = WN>
@@ -512,10 +513,13 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
                         (!p.pre_a || p.pre_group % 2 == 0) && (!p.mask_a || p.mask_group % 2 == 0);
     if (g_precision != 0 && p.w_split && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.D == 1 && p.Cin % 8 == 0 &&
         (p.W == 16 || p.W % 32 == 0 || small8) &&
-        (g_tune_window < 0 ? (M64 / 128) * ((C + 127) / 128) >= 192 : g_tune_window == 1)) {
+        (g_tune_window < 0 ? (M64 / 128) * ((C + 127) / 128) >= 192 : g_tune_window >= 1)) {
         const int tw_shift = small8 ? 3 : (p.W == 16 ? 4 : 5);
         const int g_shift = small8 ? 1 : 0;
-        const int TWv = 1 << tw_shift, THv = (128 >> tw_shift) >> g_shift;
+        const int bnw0 = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
+        // 256-pixel tiles (8 x 32): bf16x3 at 96 output channels, whole rows of 32 only
+        const bool big = g_precision == 1 && g_tune_window == 2 && bnw0 == 96 && tw_shift == 5 && p.H % 8 == 0;
+        const int TWv = 1 << tw_shift, THv = ((big ? 256 : 128) >> tw_shift) >> g_shift;
         if (p.H % THv == 0) {
             const int tiles_w = p.W / TWv, tiles_hw = tiles_w * (p.H / THv);
             const int bnw = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
@@ -536,6 +540,8 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
                     hipLaunchKernelGGL((conv3x3_win_kernel<128, 2, 2, 3, 1, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
                 else DGMR_WIN(128, 2, 2);
             }
+            else if (bnw == 96 && big)
+                hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 3, 1, true, 256>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
             else if (bnw == 96) {
                 // bf16x3 at 96 channels: ONE weight stage and the halo fetched at the chunk boundary (48 KB of LDS instead of 63, no
                 // spill at 168 VGPRs) let three workgroups share a CU, which is worth more than the saved barrier (measured
@@ -636,6 +642,27 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int kt = (Ktot + 127) / 128;
     ProfScope ps(a->Cout <= 32 ? V_W32 : (a->Cout <= 64 ? V_W64 : V_W128), 2.0 * (double)M64 * (double)Ktot * (double)a->Cout, s);
+    // 3x3 convs on maps with whole rows of 32 pixels, bf16 modes: LDS-window weight gradient (wgrad_win.h)
+    if (g_precision != 0 && g_tune_wgrad_window != 0 && a->KD == 1 && a->KH == 3 && a->KW == 3 && a->D == 1 && a->W % 32 == 0 &&
+        a->H % 2 == 0) {
+        const int tiles_w = a->W / 32, tiles_hw = (a->H / 2) * tiles_w;
+        const int tiles_per_group = (a->N / groups) * tiles_hw;
+        const int tiles_per_split = (tiles_per_group + spg - 1) / spg;
+        const bool b96 = a->Cout % 96 == 0;
+        const dim3 grid((a->Cin + 31) / 32, b96 ? a->Cout / 96 : (a->Cout + 63) / 64, a->nsplit);
+#define DGMR_WGW(BI_, NS_) \
+    hipLaunchKernelGGL((conv_wgrad_win_kernel<BI_, NS_>), grid, dim3(192), 0, s, p, tiles_w, tiles_hw, tiles_per_split, spg, tiles_per_group)
+        if (b96) {
+            if (g_precision == 1) DGMR_WGW(96, 3);
+            else DGMR_WGW(96, 1);
+        } else {
+            if (g_precision == 1) DGMR_WGW(64, 3);
+            else DGMR_WGW(64, 1);
+        }
+#undef DGMR_WGW
+        DGMR_CHECK_LAUNCH();
+        return 0;
+    }
     if (g_precision != 0) {
         const dim3 blk(256);
         if (a->Cout <= 32) {
@@ -736,12 +763,14 @@ extern "C" int dgmr_set_precision(int mode) {
 }
 extern "C" int dgmr_get_precision(void) { return g_precision; }
 
-extern "C" int dgmr_conv_tune(int variant, int ksplit, int window) {
-    DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 1,
-                   "dgmr_conv_tune: variant %d ksplit %d window %d", variant, ksplit, window);
+extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window) {
+    DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 2 && wgrad_window >= -1 &&
+                       wgrad_window <= 1,
+                   "dgmr_conv_tune: variant %d ksplit %d window %d wgrad_window %d", variant, ksplit, window, wgrad_window);
     g_tune_variant = variant;
     g_tune_ksplit = ksplit;
     g_tune_window = window;
+    g_tune_wgrad_window = wgrad_window;
     return 0;
 }
 

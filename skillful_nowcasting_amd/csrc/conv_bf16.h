@@ -497,16 +497,20 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------------
 // NSTAGE: weight stages in LDS (2: one barrier per tap; 1: two barriers, smaller footprint -> three workgroups per CU).
 // LAZYA: fetch the next halo at the chunk boundary instead of holding it in registers under the nine taps (fewer live VGPRs).
-template <int BN, int WM, int WN, int NS, int NSTAGE = 2, bool LAZYA = false>
-__global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(const dgmr_conv_args p, const int tw_shift,
-                                                                               const int tiles_w, const int tiles_hw,
-                                                                               const int g_shift) {
-    constexpr int BM = 128, CK = 32;
+// BM: output pixels per workgroup.  256 (TW = 32 or 16 only) gives every wave 64 pixels: fewer LDS fragment reads per MFMA
+// ((TM + TN) * planes reads feed TM * TN * terms MFMAs), half the barriers per MFMA and a 1.33x instead of 1.59x halo.
+template <int BN, int WM, int WN, int NS, int NSTAGE = 2, bool LAZYA = false, int BM = 128>
+__global__ __launch_bounds__(256, (NSTAGE == 1 && BM == 128) ? 3 : 2) void conv3x3_win_kernel(const dgmr_conv_args p, const int tw_shift,
+                                                                                             const int tiles_w, const int tiles_hw,
+                                                                                             const int g_shift) {
+    constexpr int CK = 32;
+    constexpr int LOG_BM = BM == 256 ? 8 : 7;
+    static_assert(BM == 128 || BM == 256, "BM");
     constexpr int LDW = CK / 2 + 4;  // 80-byte rows
     constexpr int NP = NS == 3 ? 2 : 1;
     constexpr bool SPLIT = NS == 3;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int AMAX = 6 * 34;                      // halo pixels: 6 x 34 (TW = 32) or 10 x 18 (TW = 16)
+    constexpr int AMAX = BM == 256 ? 10 * 34 : 6 * 34;  // halo pixels: 6 x 34 (TW = 32) or 10 x 18 (TW = 16); BM 256: 10 x 34 / 18 x 18
     constexpr int APASS = (AMAX * 8 + 255) / 256;     // 16-byte fp32 items of the halo per thread
     constexpr int BITEMS = BN * 4 * NP;               // 16-byte bf16 items of one weight stage
     constexpr int BPASS = (BITEMS + 255) / 256;
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void conv3x3_win_kernel(c
     // A tile is 2^g_shift whole small images (8x8 maps: two images of 64 pixels, each with its own 10x10 halo) or, for g_shift
     // == 0, TH x TW pixels of one image.  Groups (1/sigma, BatchNorm statistics, masks) never split the images of a tile (host).
     const int TW = 1 << tw_shift, TH = (BM >> tw_shift) >> g_shift;  // rows per sub-tile
-    const int sub_shift = 7 - g_shift;                                // log2(pixels per sub-tile)
+    const int sub_shift = LOG_BM - g_shift;                           // log2(pixels per sub-tile)
     const int tile = blockIdx.x;
     const int n = g_shift ? (tile << g_shift) : tile / tiles_hw;      // first image of the tile
     const int trem = g_shift ? 0 : tile - n * tiles_hw;

@@ -57,6 +57,8 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--prec="):
             ops.set_precision(a.split("=")[1])
+        if a.startswith("--tune="):  # variant,ksplit,window for dgmr_conv_tune
+            call("dgmr_conv_tune", *[int(v) for v in a.split("=")[1].split(",")])
     print("precision:", ops.get_precision(), flush=True)
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     for name, n, d, h, w, cin, cout, ks, up, bn in SHAPES:

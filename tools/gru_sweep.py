@@ -60,10 +60,10 @@ def main():
                              epi_mode=ops.EPI_GRU_BLEND, gru_h=h, gru_pu=pu, pre_out=pre, w_split=wsp if use_split else None)
 
         print(f"--- {name}: M={m} K={9 * ch} N={ch}  ({flops / 1e9:.2f} GF)", flush=True)
-        call("dgmr_conv_tune", -1, -1, -1)
+        call("dgmr_conv_tune", -1, -1, -1, -1)
         us = bench(fwd)
         print(f"  auto                      {us:8.1f} us  {flops / us / 1e6:7.1f} TF", flush=True)
-        call("dgmr_conv_tune", -1, -1, 1)
+        call("dgmr_conv_tune", -1, -1, 1, -1)
         us = bench(fwd)
         print(f"  window kernel             {us:8.1f} us  {flops / us / 1e6:7.1f} TF", flush=True)
         nk = (9 * ch + 31) // 32
@@ -75,11 +75,11 @@ def main():
             for ks in (1, 2, 3, 4, 6, 8, 12, 16, 24):
                 if ks > nk // 2:
                     break
-                call("dgmr_conv_tune", v, ks, 0)
+                call("dgmr_conv_tune", v, ks, 0, -1)
                 us = bench(fwd)
                 row.append(f"S{ks}:{us:6.1f}")
             print(f"  {vname:8s} " + "  ".join(row), flush=True)
-        call("dgmr_conv_tune", -1, -1, -1)
+        call("dgmr_conv_tune", -1, -1, -1, -1)
 
 
 if __name__ == "__main__":
