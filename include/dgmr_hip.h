@@ -133,6 +133,9 @@ typedef struct dgmr_wgrad_args {
 int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream);
 /* Suggested nsplit (a multiple of groups) for a problem (pure host arithmetic). */
 int dgmr_conv_wgrad_nsplit(int M, int Cout, int K, int groups);
+/* Same with the whole geometry in view (the kernel choice depends on it): fills a->nsplit from the other fields; the caller then
+ * sizes `partial` and calls dgmr_conv_wgrad with the same struct. */
+int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a);
 
 /* With P_q = sum of group q's slabs:  g[Cout*K] = sum_q scale[q] * P_q  (scale == NULL: 1);  dot[q] += <P_q, w>  (dot == NULL:
  * skipped; otherwise [groups], zeroed by the caller / the previous finalize).  groups <= 32. */

@@ -60,6 +60,7 @@ SIGNATURES = {
     "dgmr_conv_flip_weights": [P, P, i, i, i, i, i, i, i, P],
     "dgmr_conv_wgrad": [POINTER(WgradArgs), P],
     "dgmr_conv_wgrad_nsplit": [i, i, i, i],
+    "dgmr_conv_wgrad_plan": [POINTER(WgradArgs)],
     "dgmr_wgrad_reduce": [P, i, i, L, P, P, P, P, P],
     "dgmr_wgrad_reduce_slice": [P, i, i, i, i, i, i, i, P, P, P, P, P],
     "dgmr_sn_wgrad_finalize": [P, P, P, P, P, P, i, i, i, i, i, P],

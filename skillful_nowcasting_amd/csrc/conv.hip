@@ -623,6 +623,33 @@ extern "C" int dgmr_conv_wgrad_nsplit(int M, int Cout, int K, int groups) {
     return (int)(per * groups);
 }
 
+// the LDS-window weight gradient (wgrad_win.h) applies to 3x3 convs on 2-D maps made of whole rows of 32 (or 16) pixels, bf16 modes
+static bool wgrad_uses_window(const dgmr_wgrad_args* a) {
+    return g_precision != 0 && g_tune_wgrad_window != 0 && a->KD == 1 && a->KH == 3 && a->KW == 3 && a->D == 1 &&
+           ((a->W % 32 == 0 && a->H % 2 == 0) || (a->W == 16 && a->H % 4 == 0));
+}
+// tiles of 64 pixels: 2 x 32, or 4 x 16 on 16-pixel-wide maps
+static int wgrad_window_tw_shift(const dgmr_wgrad_args* a) { return a->W % 32 == 0 ? 5 : 4; }
+
+extern "C" int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a) {
+    DGMR_CHECK_ARG(a && a->N > 0 && a->Cin > 0 && a->Cout > 0, "dgmr_conv_wgrad_plan: bad args");
+    const int groups = a->groups < 1 ? 1 : a->groups;
+    const int64_t M = (int64_t)a->N * a->D * a->H * a->W;
+    if (!wgrad_uses_window(a)) {
+        a->nsplit = dgmr_conv_wgrad_nsplit((int)M, a->Cout, a->KD * a->KH * a->KW * a->Cin, groups);
+        return 0;
+    }
+    // workgroups = 32-channel input chunks x output tiles x slabs.  Two are resident per CU: one full round (<= 512 workgroups)
+    // measures better than 1.5 rounds (tail) and than many small slabs (partial-sum traffic); >= 2 tiles of 64 pixels per slab
+    const int per_slab = ((a->Cin + 31) / 32) * (a->Cout % 96 == 0 ? a->Cout / 96 : (a->Cout + 63) / 64);
+    const int64_t tiles_per_group = (int64_t)(a->N / groups) * ((int64_t)a->H * a->W / 64);
+    int64_t per = 512 / ((int64_t)per_slab * groups);  // slabs per group
+    per = std::min<int64_t>(per, tiles_per_group / 2);
+    per = std::max<int64_t>(per, 1);
+    a->nsplit = (int)std::min<int64_t>(per * groups, 4096);
+    return 0;
+}
+
 extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
     DGMR_CHECK_ARG(a && a->x && a->dy && a->partial, "dgmr_conv_wgrad: null pointer");
     DGMR_CHECK_ARG(a->Cin % 4 == 0 && a->Cout % 4 == 0, "dgmr_conv_wgrad: Cin=%d Cout=%d must be multiples of 4", a->Cin,
@@ -643,15 +670,22 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
     const int kt = (Ktot + 127) / 128;
     ProfScope ps(a->Cout <= 32 ? V_W32 : (a->Cout <= 64 ? V_W64 : V_W128), 2.0 * (double)M64 * (double)Ktot * (double)a->Cout, s);
     // 3x3 convs on maps with whole rows of 32 pixels, bf16 modes: LDS-window weight gradient (wgrad_win.h)
-    if (g_precision != 0 && g_tune_wgrad_window != 0 && a->KD == 1 && a->KH == 3 && a->KW == 3 && a->D == 1 && a->W % 32 == 0 &&
-        a->H % 2 == 0) {
-        const int tiles_w = a->W / 32, tiles_hw = (a->H / 2) * tiles_w;
+    if (wgrad_uses_window(a)) {
+        const int tw_shift = wgrad_window_tw_shift(a);
+        const int tiles_w = a->W >> tw_shift, tiles_hw = (a->H / (64 >> tw_shift)) * tiles_w;
         const int tiles_per_group = (a->N / groups) * tiles_hw;
         const int tiles_per_split = (tiles_per_group + spg - 1) / spg;
         const bool b96 = a->Cout % 96 == 0;
         const dim3 grid((a->Cin + 31) / 32, b96 ? a->Cout / 96 : (a->Cout + 63) / 64, a->nsplit);
-#define DGMR_WGW(BI_, NS_) \
-    hipLaunchKernelGGL((conv_wgrad_win_kernel<BI_, NS_>), grid, dim3(192), 0, s, p, tiles_w, tiles_hw, tiles_per_split, spg, tiles_per_group)
+#define DGMR_WGW(BI_, NS_)                                                                                                     \
+    do {                                                                                                                       \
+        if (tw_shift == 5)                                                                                                     \
+            hipLaunchKernelGGL((conv_wgrad_win_kernel<BI_, NS_, 5>), grid, dim3(192), 0, s, p, tiles_w, tiles_hw, tiles_per_split, spg, \
+                               tiles_per_group);                                                                               \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((conv_wgrad_win_kernel<BI_, NS_, 4>), grid, dim3(192), 0, s, p, tiles_w, tiles_hw, tiles_per_split, spg, \
+                               tiles_per_group);                                                                               \
+    } while (0)
         if (b96) {
             if (g_precision == 1) DGMR_WGW(96, 3);
             else DGMR_WGW(96, 1);

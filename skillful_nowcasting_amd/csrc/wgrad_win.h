@@ -6,8 +6,9 @@
 // conv_wgrad_bf16_kernel treats this as a GEMM over an im2col matrix: every workgroup re-gathers (and re-applies the fused
 // BatchNorm/ReLU prologue to, and re-splits into bf16 pairs) its 128 im2col columns for every pixel, i.e. each input element is
 // fetched and converted 9 x (Cout / tile) times; the kernel is bound by that VALU work and the L2 traffic, not by the matrix pipe.
-// Here a workgroup owns 32 INPUT channels x BI output channels and walks a slab of 64-pixel tiles (2 rows x 32 columns):
-//   * the 4 x 34 input halo of the tile is fetched, prologue'd and split ONCE and serves all nine taps;
+// Here a workgroup owns 32 INPUT channels x BI output channels and walks a slab of 64-pixel tiles (2 rows x 32 columns, or 4 x 16
+// on 16-pixel-wide maps):
+//   * the 4 x 34 (6 x 18) input halo of the tile is fetched, prologue'd and split ONCE and serves all nine taps;
 //   * dY of the tile is fetched and split once per 32 input channels;
 //   * both land TRANSPOSED in LDS ([channel][pixel], the reduction index contiguous) through a 4-pixel x 4-channel register
 //     transpose, so MFMA fragments are plain 16-byte reads; the +-1 column shift of a tap is applied in registers (one extra dword
@@ -21,17 +22,22 @@
 
 namespace {
 
-template <int BI, int NS>
+// Two workgroups per CU (the nine accumulators take 144 registers).  Holding the next tile's loads in registers under the MFMAs
+// needs > 256 registers, i.e. one workgroup per CU: measured 1.7x slower - co-residency hides the fetch better than prefetching.
+// TWS: log2 of the tile width (5: tiles of 2 x 32 pixels, 4: 4 x 16) - compile time, the inner loop's addresses fold to constants
+template <int BI, int NS, int TWS>
 __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad_args p, const int tiles_w, const int tiles_hw,
                                                                 const int tiles_per_split, const int splits_per_group,
                                                                 const int tiles_per_group) {
     constexpr int NT = 192, CK = 32;
     constexpr int NP = NS == 3 ? 2 : 1;
     constexpr bool SPLIT = NS == 3;
-    constexpr int XLD = 4 * 24 + 4;  // dwords per input channel: 4 halo rows of 48 bf16 slots (column c at slot 8 + c) + 16 bytes
+    // dwords per input channel: 4 halo rows of 48 bf16 slots (TW = 32) or 6 rows of 32 slots (TW = 16), column c at slot 8 + c of
+    // its row, + 16 bytes of padding
+    constexpr int XLD = 4 * 24 + 4;
     constexpr int YLD = 32 + 4;      // dwords per output channel: 64 pixels + 16 bytes
     constexpr int CB = BI / 32;      // output-channel blocks per wave
-    constexpr int XBLK = 4 * 10 * 8, YBLK = 16 * (BI / 4);  // 4 px x 4 ch blocks: halo rows x 4-px groups x channel quads
+    constexpr int XBLK = 4 * 10 * 8, YBLK = 16 * (BI / 4);  // 4 px x 4 ch blocks: halo rows x 4-px groups x channel quads (TW = 16: 6 x 6 x 8)
     constexpr int XPASS = (XBLK + NT - 1) / NT, YPASS = (YBLK + NT - 1) / NT;
     static_assert(BI == 64 || BI == 96, "BI");
 
@@ -47,6 +53,12 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad
     const int us = p.upsample ? 1 : 0;
     const int Hs = p.H >> us, Ws = p.W >> us;
     const int Ktot = 9 * p.Cin;
+    constexpr int tw_shift = TWS;
+    constexpr int TW = 1 << TWS, TH = 64 >> TWS;  // 32 x 2 or 16 x 4
+    constexpr int XG = (TW >> 2) + 2;              // 4-pixel groups per halo row (columns -4 .. TW+3)
+    constexpr int XPG = (TH + 2) * XG;             // pixel groups per channel quad: 40 or 36
+    constexpr int ROWDW = (TW + 16) >> 1;          // dwords per halo row: 24 or 16
+    static_assert(TWS == 5 || TWS == 4, "tile width");
 
     // ---- staging geometry: quads of lanes = 4 consecutive channel quads of one pixel group (64 contiguous bytes per pixel in HBM;
     // in LDS the 4-way channel stride falls on 2 banks x 2 and the 8-byte pixel groups of the next lanes fill the rest) ----
@@ -56,11 +68,11 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad
     for (int i = 0; i < XPASS; ++i) {
         const int idx = tid + i * NT;
         const int t2 = idx >> 2;
-        const int pgid = t2 % 40, cq = (t2 / 40) * 4 + (idx & 3);
-        x_r[i] = pgid / 10;
-        x_g[i] = pgid - x_r[i] * 10;
+        const int pgid = t2 % XPG, cq = (t2 / XPG) * 4 + (idx & 3);
+        x_r[i] = pgid / XG;
+        x_g[i] = pgid - x_r[i] * XG;
         x_ci[i] = cq * 4;  // channel inside the chunk
-        x_on[i] = idx < XBLK;
+        x_on[i] = idx < XPG * 8;
     }
     int y_pg[YPASS], y_co[YPASS];
     bool y_on[YPASS];
@@ -85,15 +97,14 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad
             for (int r = 0; r < 16; ++r) acc[c][d][r] = 0.f;
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int t = t_begin; t < t_end; ++t) {
+    f32x4 rx[XPASS][4], ry[YPASS][4], bn_a[XPASS], bn_b[XPASS];
+    unsigned xmask[XPASS], ymask[YPASS];
+    // ---- fetch of one tile: every load unconditional (clamped address), masks zero the invalid elements afterwards ----
+    auto fetch = [&](int t) {
         const int n = t / tiles_hw;
         const int trem = t - n * tiles_hw;
         const int th = trem / tiles_w;
-        const int h0 = th * 2, w0 = (trem - th * tiles_w) * 32;
-
-        // ---- fetch: every load unconditional (clamped address), masks zero the invalid elements afterwards ----
-        f32x4 rx[XPASS][4], ry[YPASS][4], bn_a[XPASS], bn_b[XPASS];
-        unsigned xmask[XPASS], ymask[YPASS];
+        const int h0 = th * TH, w0 = (trem - th * tiles_w) << tw_shift;
 #pragma unroll
         for (int i = 0; i < XPASS; ++i) {
             const int ci = chunk * CK + x_ci[i];
@@ -120,12 +131,15 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad
         for (int i = 0; i < YPASS; ++i) {
             const int co = co0 + y_co[i];
             const bool ok = y_on[i] && co < p.Cout;
-            const int hh = h0 + (y_pg[i] >> 3), ww = w0 + (y_pg[i] & 7) * 4;
+            const int hh = h0 + ((y_pg[i] * 4) >> tw_shift), ww = w0 + ((y_pg[i] * 4) & (TW - 1));
             const size_t m0 = ((size_t)n * p.H + hh) * p.W + ww;
 #pragma unroll
             for (int j = 0; j < 4; ++j) ry[i][j] = *reinterpret_cast<const f32x4*>(p.dy + (ok ? (m0 + j) * p.Cout + co : 0));
             ymask[i] = ok ? 0xfu : 0u;
         }
+    };
+    for (int t = t_begin; t < t_end; ++t) {
+        fetch(t);
 
         // ---- prologue, split, 4x4 transpose -> LDS ----
 #pragma unroll
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad
             for (int c = 0; c < 4; ++c) {
                 u32x2 hi, lo;
                 split4<SPLIT>((f32x4){rx[i][0][c], rx[i][1][c], rx[i][2][c], rx[i][3][c]}, hi, lo);
-                uint32_t* dst = Xs + (x_ci[i] + c) * XLD + x_r[i] * 24 + 2 + 2 * x_g[i];
+                uint32_t* dst = Xs + (x_ci[i] + c) * XLD + x_r[i] * ROWDW + 2 + 2 * x_g[i];
                 *reinterpret_cast<u32x2*>(dst) = hi;
                 if (SPLIT) *reinterpret_cast<u32x2*>(dst + CK * XLD) = lo;
             }
@@ -175,8 +189,9 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad
         const int kg = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int hrow = (kk >> 1) + wid;  // halo row of this 16-pixel step under the wave's dy
-            const uint32_t* xb = Xs + (lane & 31) * XLD + hrow * 24 + 4 + (kk & 1) * 8 + kg * 4;
+            // 16-pixel step kk = pixels [16 kk, 16 kk + 16) of the tile: tile row (16 kk) / TW, first column (16 kk) % TW
+            const int hrow = ((kk * 16) >> tw_shift) + wid;  // its halo row under the wave's dy
+            const uint32_t* xb = Xs + (lane & 31) * XLD + hrow * ROWDW + 4 + (((kk * 16) & (TW - 1)) >> 1) + kg * 4;
             const uint32_t* yb = Ys + (lane & 31) * YLD + kk * 8 + kg * 4;
             bf16x8_t xh[3], xl[3], yh[CB], yl[CB];
 #pragma unroll

@@ -398,16 +398,18 @@ class ConvFn(Function):
         groups = spec.groups
         taps = kd * kh * kw
         if w.requires_grad:
-            ns = call_nsplit(m, cout, k, groups)
-            partial = torch.empty(ns * cout * k, device=dev, dtype=torch.float32)
             wa = WgradArgs()
-            wa.x, wa.dy, wa.partial = _p(x), _p(dy), _p(partial)
+            wa.x, wa.dy = _p(x), _p(dy)
             wa.pre_a, wa.pre_b = (_p(bn_a), _p(bn_b)) if bn else (None, None)
             wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, d, h, wd, cin, cout
             wa.KD, wa.KH, wa.KW = kd, kh, kw
-            wa.upsample, wa.pre_relu, wa.pre_group, wa.nsplit = int(spec.upsample), int(spec.pre_relu), (bn.group_size if bn else 1), ns
+            wa.upsample, wa.pre_relu, wa.pre_group = int(spec.upsample), int(spec.pre_relu), (bn.group_size if bn else 1)
             wa.groups = groups
             wa.bias_grad = _p(grad_buffer(bias)) if want_bias else None
+            call("dgmr_conv_wgrad_plan", ctypes.byref(wa))  # slab count: depends on which kernel the library will pick
+            ns = wa.nsplit
+            partial = torch.empty(ns * cout * k, device=dev, dtype=torch.float32)
+            wa.partial = _p(partial)
             call("dgmr_conv_wgrad", ctypes.byref(wa), st)
             gw = grad_buffer(w)
             g = torch.empty(cout * k, device=dev, dtype=torch.float32)
@@ -873,14 +875,16 @@ class ConvGRUFn(Function):
             x_half = (x_rep, dsum[ki], T, cx, 0) if x_shared else (x_all, dp, tb, cx, 0)
             for src, dy, nimg, cin, coff in (x_half, (hsrc, dp, tb, ch, cx)):
                 k = taps * cin
-                ns = call_nsplit(nimg * hh * ww, ch, k, g_)
-                partial = torch.empty(ns * ch * k, device=dev, dtype=torch.float32)
                 wa = WgradArgs()
-                wa.x, wa.dy, wa.partial = _p(src), _p(dy), _p(partial)
+                wa.x, wa.dy = _p(src), _p(dy)
                 wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = nimg, 1, hh, ww, cin, ch
                 wa.KD, wa.KH, wa.KW = 1, kh, kw
-                wa.upsample, wa.pre_relu, wa.pre_group, wa.nsplit, wa.groups = 0, 0, 1, ns, g_
+                wa.upsample, wa.pre_relu, wa.pre_group, wa.groups = 0, 0, 1, g_
                 wa.bias_grad = _p(grad_buffer(bias)) if (want_bias and coff == 0) else None  # bias gradient once, with the x half
+                call("dgmr_conv_wgrad_plan", ctypes.byref(wa))
+                ns = wa.nsplit
+                partial = torch.empty(ns * ch * k, device=dev, dtype=torch.float32)
+                wa.partial = _p(partial)
                 call("dgmr_conv_wgrad", ctypes.byref(wa), st)
                 call("dgmr_wgrad_reduce_slice", _p(partial), ns, g_, ch, taps, cin, ct, coff, _p(w), _p(inv_s), _p(g), _p(dot), st)
             call("dgmr_sn_wgrad_finalize", _p(g), _p(grad_buffer(w)), _p(dot), _p(inv_s), _p(u_), _p(v_), ch, ct, taps, g_, 1, st)
