@@ -331,7 +331,8 @@ const char* dgmr_profile_variant_name(int variant);
 int dgmr_profile_collect(double* total_ms, double* total_flops, int64_t* launches, int n);
 /* Dispatch override for tools/conv_bench.py's tile / split-K sweeps (process-wide; -1 = the library's own choice, which is
  * also the state at load): variant = index of a conv_fwd_dgrad<..> tile as listed by dgmr_profile_variant_name, ksplit = number
- * of K slabs (needs a workspace in the args), window = 0 never / 1 whenever the geometry allows the LDS-window 3x3 kernel / 2 likewise, with the experimental 256-pixel tiles;
+ * of K slabs (needs a workspace in the args), window = 0 never / 1 the register-staged LDS-window 3x3 kernel whenever the geometry allows / 2 likewise, with the experimental
+ * 256-pixel tiles / 3 the LDS-DMA window kernel where eligible (what -1 picks, but also below the automatic size threshold);
  * wgrad_window = 0 never / 1 (= automatic) the LDS-window weight-gradient kernel wherever the geometry allows. */
 int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window);
 

@@ -16,6 +16,7 @@
 
 #include "conv_bf16.h"
 #include "wgrad_win.h"
+#include "conv_win_glds.h"
 #include "conv_device.h"
 
 namespace {
@@ -533,7 +534,17 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         else                                                                                                                 \
             hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
     } while (0)
-            if (bnw == 128) {
+            // bf16x3 with whole 32-channel chunks and whole output tiles: weight stages by LDS-DMA (conv_win_glds.h; measured +4..17 %
+            // over the register-staged kernel below, bit-identical results)
+            if (g_precision == 1 && (g_tune_window < 0 || g_tune_window == 3) && !big && p.Cin % 32 == 0 && C % bnw == 0) {
+                if (bnw == 128)
+                    hipLaunchKernelGGL((conv3x3_glds_kernel<128, 2, 2, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
+                else if (bnw == 96)
+                    hipLaunchKernelGGL((conv3x3_glds_kernel<96, 4, 1, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
+                else
+                    hipLaunchKernelGGL((conv3x3_glds_kernel<64, 4, 1, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
+            }
+            else if (bnw == 128) {
                 // bf16x3: one weight stage + halo fetched at the chunk boundary = 53 KB of LDS and <= 168 VGPRs -> three workgroups per CU
                 // (measured 320 -> 350 TF); plain bf16 keeps the two-stage pipeline
                 if (g_precision == 1)
@@ -798,7 +809,7 @@ extern "C" int dgmr_set_precision(int mode) {
 extern "C" int dgmr_get_precision(void) { return g_precision; }
 
 extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window) {
-    DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 2 && wgrad_window >= -1 &&
+    DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 3 && wgrad_window >= -1 &&
                        wgrad_window <= 1,
                    "dgmr_conv_tune: variant %d ksplit %d window %d wgrad_window %d", variant, ksplit, window, wgrad_window);
     g_tune_variant = variant;

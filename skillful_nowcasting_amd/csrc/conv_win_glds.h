@@ -1,0 +1,262 @@
+// 3x3 convolution with the input window in LDS, WEIGHT STAGES FILLED BY LDS-DMA (forward and data gradient of the big maps).
+//
+// conv3x3_win_kernel copies every weight stage HBM/L2 -> VGPRs -> ds_write_b128 -> LDS.  On gfx950 a 16-byte LDS store moves its
+// address and data registers at 13 cycles per wave-instruction (79 B/clk): the nine stage copies of a 32-channel chunk keep the
+// LDS busy almost as long as all fragment reads together, and LDS time, not the matrix pipe, bounds that kernel.  Here
+//   * the weight stage of tap s+1 is written by global_load_lds_dwordx4 (no registers, no LDS store instruction) into the second
+//     of two stage buffers while tap s is multiplied: ONE barrier per tap instead of two;
+//   * LDS rows are the bare 64 bytes of 32 bf16 (no padding - the DMA image is lane-linear): the 16-byte k-slot s of row r lives
+//     at slot s ^ ((r >> 2) & 3), which keeps the 16 rows of a ds_read_b128 lane group on 16 distinct bank slots; the weight rows
+//     are swizzled through the per-lane SOURCE address of the DMA, the activation rows at their ds_write;
+//   * 26 KB of activations + 2 x 12 KB of weights (96 output channels, bf16x3) = three workgroups per CU.
+// Needs Cin % 32 == 0 and Cout % BN == 0 (a DMA cannot zero-fill); everything else is conv3x3_win_kernel's.
+#pragma once
+#include "conv_bf16.h"
+
+namespace {
+
+// 16 bytes per lane, global -> LDS at (wave-uniform) lds + 16 * lane, no registers in between (global_load_lds_dwordx4).
+// The builtin exists in the device pass only; the host pass needs the kernel body just to emit its launch stub.
+__device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t* lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(gptr, lds, 16, 0, 0);
+#else
+    (void)gptr;
+    (void)lds;
+#endif
+}
+
+template <int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift, const int tiles_w,
+                                                              const int tiles_hw, const int g_shift) {
+    constexpr int BM = 128, CK = 32;
+    constexpr int ROW = CK / 2;  // dwords per LDS row
+    constexpr int NP = NS == 3 ? 2 : 1;
+    constexpr bool SPLIT = NS == 3;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AMAX = 6 * 34;
+    constexpr int APASS = (AMAX * 8 + 255) / 256;
+    constexpr int BUNITS = BN * 4 * NP;  // 16-byte units of one weight stage
+    constexpr int BPASS = BUNITS / 256;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BUNITS % 256 == 0, "bad tile");
+
+    __shared__ __attribute__((aligned(16))) uint32_t smem[NP * AMAX * ROW + 2 * NP * BN * ROW];
+    uint32_t* As = smem;                     // [plane][pixel][ROW]
+    uint32_t* Bs = smem + NP * AMAX * ROW;   // [stage][plane][co][ROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int TW = 1 << tw_shift, TH = (BM >> tw_shift) >> g_shift;
+    const int sub_shift = 7 - g_shift;
+    const int tile = blockIdx.x;
+    const int n = g_shift ? (tile << g_shift) : tile / tiles_hw;
+    const int trem = g_shift ? 0 : tile - n * tiles_hw;
+    const int th = trem / tiles_w;
+    const int h0 = th * TH, w0 = (trem - th * tiles_w) * TW;
+    const int n0 = blockIdx.y * BN;
+    const int us = p.upsample ? 1 : 0;
+    const int Hs = p.H >> us, Ws = p.W >> us;
+    const int oh = (h0 - 1) >> us, ow = (w0 - 1) >> us;
+    const int HTw = (TW >> us) + 2;
+    const int HP = ((TH >> us) + 2) * HTw;
+    const int npix = HP << g_shift;
+    const int nchunks = p.Cin / CK;
+    const int S = nchunks * 9;
+
+    // ---- activation halo (registers -> prologue -> split -> swizzled ds_write), as conv3x3_win_kernel ----
+    const int cq = tid & 7;
+    uint32_t a_goff[APASS];
+    unsigned a_valid = 0;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+        const int pix = (tid >> 3) + i * 32;
+        const int sub = pix / HP, prem = pix - sub * HP;
+        const int lr = prem / HTw, lc = prem - lr * HTw;
+        const int ih = oh + lr, iw = ow + lc;
+        const bool ok = pix < npix && (unsigned)ih < (unsigned)Hs && (unsigned)iw < (unsigned)Ws;
+        a_goff[i] = ok ? (((uint32_t)(n + sub) * Hs + ih) * Ws + iw) * p.Cin + cq * 4 : 0u;
+        a_valid |= (ok ? 1u : 0u) << i;
+    }
+    const float* pa_base = p.pre_a ? p.pre_a : p.x;
+    const float* pb_base = p.pre_a ? p.pre_b : p.x;
+    const uint32_t grp_off = (uint32_t)(n / p.pre_group) * p.Cin;
+
+    auto stage_a = [&](int chunk) {  // fetch, transform and store one 32-channel halo (latency covered by the other workgroups)
+        f32x4 ra[APASS];
+        const int cb = chunk * CK + cq * 4;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i)
+            ra[i] = *reinterpret_cast<const f32x4*>(p.x + (((a_valid >> i) & 1u) ? a_goff[i] + chunk * CK : 0u));
+        const f32x4 rpa = *reinterpret_cast<const f32x4*>(pa_base + (p.pre_a ? grp_off + cb : 0u));
+        const f32x4 rpb = *reinterpret_cast<const f32x4*>(pb_base + (p.pre_a ? grp_off + cb : 0u));
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int pix = (tid >> 3) + i * 32;
+            f32x4 v = ra[i];
+            if (p.pre_a) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], rpa[j], rpb[j]), 0.f);
+            } else if (p.pre_relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            v = ((a_valid >> i) & 1u) ? v : zero4;
+            u32x2 hi, lo;
+            split4<SPLIT>(v, hi, lo);
+            if (pix < AMAX) {
+                uint32_t* dst = As + pix * ROW + ((((cq >> 1) ^ (pix >> 2)) & 3) << 2) + (cq & 1) * 2;
+                *reinterpret_cast<u32x2*>(dst) = hi;
+                if (SPLIT) *reinterpret_cast<u32x2*>(dst + AMAX * ROW) = lo;
+            }
+        }
+    };
+
+    // ---- weights: stage s = chunk * 9 + tap, written by LDS-DMA; unit u of a stage = 16 bytes at LDS offset 16 u ----
+    const size_t plane_stride = (size_t)p.Cout * 9 * p.Cin;  // bf16 elements per plane
+    size_t b_src[BPASS];                                       // element offset of this lane's unit for stage 0
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        const int u = tid + i * 256;
+        const int plane = u / (BN * 4);
+        const int r = (u >> 2) % BN;
+        const int s = (u ^ (r >> 2)) & 3;  // logical k-slot held by physical slot (u & 3) of row r
+        b_src[i] = plane * plane_stride + (size_t)(n0 + r) * 9 * p.Cin + s * 8;
+    }
+    auto dma_b = [&](int s, int stage) {
+        const int chunk = s / 9, tap = s - chunk * 9;
+        const size_t off = (size_t)tap * p.Cin + chunk * CK;
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i)
+            lds_dma16(p.w_split + b_src[i] + off, Bs + stage * NP * BN * ROW + (i * 256 + wid * 64) * 4);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int prow[TM], pcol[TM], pbase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int q = wm * TM * 32 + i * 32 + (lane & 31);
+        prow[i] = (q >> tw_shift) & (TH - 1);
+        pcol[i] = q & (TW - 1);
+        pbase[i] = (q >> sub_shift) * HP;
+    }
+    const int kg = lane >> 5;
+    const int bsw = (lane >> 2) & 3;  // swizzle of this lane's weight rows (row = 32 j + (lane & 31))
+    auto mma = [&](int tap, int stage) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const uint32_t* Ab[TM];
+        int asw[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int lr = ((h0 + prow[i] + dy) >> us) - oh;
+            const int lc = ((w0 + pcol[i] + dx) >> us) - ow;
+            const int pix = pbase[i] + lr * HTw + lc;
+            Ab[i] = As + pix * ROW;
+            asw[i] = (pix >> 2) & 3;
+        }
+        const uint32_t* Bb = Bs + ((stage * NP) * BN + wn * TN * 32 + (lane & 31)) * ROW;
+#pragma unroll
+        for (int kk = 0; kk < CK / 16; ++kk) {
+            const int ks = kk * 2 + kg;  // logical 16-byte k-slot of this lane's fragment
+            bf16x8_t ah[TM], bh[TN], al[TM], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int o = (ks ^ asw[i]) << 2;
+                ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab[i] + o));
+                if (SPLIT) al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab[i] + AMAX * ROW + o));
+            }
+            const int ob = (ks ^ bsw) << 2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + j * 32 * ROW + ob));
+                if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BN + j * 32) * ROW + ob));
+            }
+            __builtin_amdgcn_s_setprio(1);
+            if (SPLIT) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    };
+
+    dma_b(0, 0);
+    stage_a(0);
+    __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int s = chunk * 9 + tap;
+            if (s + 1 < S) dma_b(s + 1, (s + 1) & 1);  // in flight under this tap's MFMAs
+            mma(tap, s & 1);
+            if (tap == 8 && chunk + 1 < nchunks) {
+                __syncthreads();  // every wave is done with this chunk's halo
+                stage_a(chunk + 1);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (conv3x3_win_kernel's) ----
+    const float sc = p.scale ? p.scale[n / p.scale_group] : 1.f;
+    float bj[TN];
+    int colj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        colj[j] = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        bj[j] = (p.bias && colj[j] < p.Cout) ? p.bias[colj[j]] : 0.f;
+    }
+    const bool simple = !p.addend && p.epi_mode == DGMR_EPI_PLAIN;
+    float maj[TN], mbj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const bool on = p.mask_a && colj[j] < p.Cout;
+        const size_t g = (size_t)(n / p.mask_group) * p.Cout + (on ? colj[j] : 0);
+        maj[j] = on ? p.mask_a[g] : 1.f;
+        mbj[j] = on ? p.mask_b[g] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int hh = h0 + ((q >> tw_shift) & (TH - 1)), ww = w0 + (q & (TW - 1)), ni = n + (q >> sub_shift);
+            const int m = (ni * p.H + hh) * p.W + ww;
+            float* yrow = p.y + (size_t)m * p.Cout;
+            const size_t rbase = p.residual_up ? (((size_t)ni * (p.H >> 1) + (hh >> 1)) * (p.W >> 1) + (ww >> 1)) * p.Cout
+                                               : (size_t)m * p.Cout;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (colj[j] >= p.Cout) continue;
+                if (simple) {
+                    float v = fmaf(acc[i][j][r], sc, bj[j]);
+                    if (p.act_relu) v = fmaxf(v, 0.f);
+                    if (p.residual) v += p.residual[rbase + colj[j]];
+                    if (p.mask_src) v = fmaf(p.mask_src[(size_t)m * p.Cout + colj[j]], maj[j], mbj[j]) > 0.f ? v : 0.f;
+                    yrow[colj[j]] = v;
+                } else {
+                    epilogue_store(p, acc[i][j][r], ni, colj[j], (size_t)m * p.Cout + colj[j], rbase + colj[j]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace

@@ -5,7 +5,7 @@ from skillful_nowcasting_amd import ops
 from skillful_nowcasting_amd._lib import call, load
 load(); ops.set_precision("bf16x3")
 dev="cuda"
-for (n,h,w,cin,cout,up,bn) in [(4,64,64,192,96,False,True),(2,128,128,96,96,True,True),(3,32,32,40,192,False,False)]:
+for (n,h,w,cin,cout,up,bn) in [(4,64,64,192,96,False,True),(2,128,128,96,96,True,True),(3,32,32,64,192,False,False),(4,16,16,96,96,False,True),(4,8,8,96,192,False,False)]:
     hin,win_=(h//2,w//2) if up else (h,w)
     x=torch.randn(n*hin*win_*cin,device=dev); wt=torch.randn(cout*9*cin,device=dev)*0.05
     bias=torch.randn(cout,device=dev); scale=torch.full((n,),0.5,device=dev)
@@ -14,7 +14,7 @@ for (n,h,w,cin,cout,up,bn) in [(4,64,64,192,96,False,True),(2,128,128,96,96,True
     wsp=torch.empty(2*wt.numel(),device=dev,dtype=torch.int16)
     call("dgmr_split_weights",wt.data_ptr(),wsp.data_ptr(),cout*9,cin,0,0,ops._stream())
     ys=[]
-    for mode in (1,2,0):
+    for mode in (1,3,0):
         call("dgmr_conv_tune",-1,-1,mode,-1)
         y=torch.empty(n*h*w*cout,device=dev)
         ops._launch_conv(x,wt.data_ptr(),bias,scale,y,n,1,h,w,cin,cout,1,3,3,upsample=up,pre_a=a if bn else None,pre_b=b if bn else None,pre_group=1,scale_group=1,residual=res,w_split=wsp)

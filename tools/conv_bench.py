@@ -22,6 +22,7 @@ SHAPES = [
     ("up_g2.first T18", 288, 1, 32, 32, 384, 384, (1, 3, 3), True, True),
     ("g1.first t1", 16, 1, 8, 8, 768, 768, (1, 3, 3), False, True),
     ("g1.first T18", 288, 1, 8, 8, 768, 768, (1, 3, 3), False, True),
+    ("c64 T18", 288, 1, 64, 64, 192, 64, (1, 3, 3), False, True),
     ("gru1.gate", 16, 1, 8, 8, 1152, 384, (1, 3, 3), False, False),
     ("gru1.h-only", 16, 1, 8, 8, 384, 384, (1, 3, 3), False, False),
     ("gru4.gate", 16, 1, 64, 64, 144, 48, (1, 3, 3), False, False),
