@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--fast", action="store_true", help="strict_reference_semantics=False (skip discarded work)")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "off"])
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tune", default="", help="A/B switch for kernel development: variant,ksplit,window,wgrad_window for "
+                                               "dgmr_conv_tune (-1 = the library's own choice, the default)")
     ap.add_argument("--precision", default=os.environ.get("DGMR_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the conv forward/data-gradient contractions (tensors stay fp32 in HBM)")
     return ap.parse_args()
@@ -131,6 +133,8 @@ def main():
     kw, hw, T = WORKLOADS[args.workload]
     B = args.batch
     S.set_precision(args.precision)
+    if args.tune:
+        _lib.load().dgmr_conv_tune(*[int(v) for v in args.tune.split(",")])
     torch.manual_seed(0)
     model = S.DGMR(strict_reference_semantics=not args.fast, **kw).to(dev)
     if world > 1:

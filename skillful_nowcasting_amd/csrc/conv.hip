@@ -534,9 +534,9 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         else                                                                                                                 \
             hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
     } while (0)
-            // bf16x3 with whole 32-channel chunks and whole output tiles: weight stages by LDS-DMA (conv_win_glds.h; measured +4..17 %
+            // bf16x3: weight stages by LDS-DMA (conv_win_glds.h; measured +4..17 %
             // over the register-staged kernel below, bit-identical results)
-            if (g_precision == 1 && (g_tune_window < 0 || g_tune_window == 3) && !big && p.Cin % 32 == 0 && C % bnw == 0) {
+            if (g_precision == 1 && (g_tune_window < 0 || g_tune_window == 3) && !big) {
                 if (bnw == 128)
                     hipLaunchKernelGGL((conv3x3_glds_kernel<128, 2, 2, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
                 else if (bnw == 96)

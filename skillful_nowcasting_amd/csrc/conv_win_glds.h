@@ -9,7 +9,8 @@
 //     at slot s ^ ((r >> 2) & 3), which keeps the 16 rows of a ds_read_b128 lane group on 16 distinct bank slots; the weight rows
 //     are swizzled through the per-lane SOURCE address of the DMA, the activation rows at their ds_write;
 //   * 26 KB of activations + 2 x 12 KB of weights (96 output channels, bf16x3) = three workgroups per CU.
-// Needs Cin % 32 == 0 and Cout % BN == 0 (a DMA cannot zero-fill); everything else is conv3x3_win_kernel's.
+// A DMA cannot zero-fill: output channels beyond Cout read the last row (their columns are never stored) and input channels
+// beyond Cin read channel group 0 (their activations are exact zeros).  Everything else is conv3x3_win_kernel's.
 #pragma once
 #include "conv_bf16.h"
 
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
     const int HTw = (TW >> us) + 2;
     const int HP = ((TH >> us) + 2) * HTw;
     const int npix = HP << g_shift;
-    const int nchunks = p.Cin / CK;
+    const int nchunks = (p.Cin + CK - 1) / CK;
     const int S = nchunks * 9;
 
     // ---- activation halo (registers -> prologue -> split -> swizzled ds_write), as conv3x3_win_kernel ----
@@ -84,11 +85,13 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
     auto stage_a = [&](int chunk) {  // fetch, transform and store one 32-channel halo (latency covered by the other workgroups)
         f32x4 ra[APASS];
         const int cb = chunk * CK + cq * 4;
+        const bool kok = cb < p.Cin;
+        const unsigned valid = kok ? a_valid : 0u;
 #pragma unroll
         for (int i = 0; i < APASS; ++i)
-            ra[i] = *reinterpret_cast<const f32x4*>(p.x + (((a_valid >> i) & 1u) ? a_goff[i] + chunk * CK : 0u));
-        const f32x4 rpa = *reinterpret_cast<const f32x4*>(pa_base + (p.pre_a ? grp_off + cb : 0u));
-        const f32x4 rpb = *reinterpret_cast<const f32x4*>(pb_base + (p.pre_a ? grp_off + cb : 0u));
+            ra[i] = *reinterpret_cast<const f32x4*>(p.x + (((valid >> i) & 1u) ? a_goff[i] + chunk * CK : 0u));
+        const f32x4 rpa = *reinterpret_cast<const f32x4*>(pa_base + ((p.pre_a && kok) ? grp_off + cb : 0u));
+        const f32x4 rpb = *reinterpret_cast<const f32x4*>(pb_base + ((p.pre_a && kok) ? grp_off + cb : 0u));
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
-            v = ((a_valid >> i) & 1u) ? v : zero4;
+            v = ((valid >> i) & 1u) ? v : zero4;
             u32x2 hi, lo;
             split4<SPLIT>(v, hi, lo);
             if (pix < AMAX) {
@@ -114,21 +117,24 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
 
     // ---- weights: stage s = chunk * 9 + tap, written by LDS-DMA; unit u of a stage = 16 bytes at LDS offset 16 u ----
     const size_t plane_stride = (size_t)p.Cout * 9 * p.Cin;  // bf16 elements per plane
-    size_t b_src[BPASS];                                       // element offset of this lane's unit for stage 0
+    size_t b_src[BPASS];  // element offset of this lane's weight row (tap 0, channel 0)
+    int b_ch[BPASS];      // first channel (inside a chunk) of the 16-byte k-slot this lane fills
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
         const int u = tid + i * 256;
         const int plane = u / (BN * 4);
         const int r = (u >> 2) % BN;
-        const int s = (u ^ (r >> 2)) & 3;  // logical k-slot held by physical slot (u & 3) of row r
-        b_src[i] = plane * plane_stride + (size_t)(n0 + r) * 9 * p.Cin + s * 8;
+        b_ch[i] = ((u ^ (r >> 2)) & 3) * 8;  // logical k-slot held by physical slot (u & 3) of row r
+        b_src[i] = plane * plane_stride + (size_t)min(n0 + r, p.Cout - 1) * 9 * p.Cin;
     }
     auto dma_b = [&](int s, int stage) {
         const int chunk = s / 9, tap = s - chunk * 9;
-        const size_t off = (size_t)tap * p.Cin + chunk * CK;
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i)
-            lds_dma16(p.w_split + b_src[i] + off, Bs + stage * NP * BN * ROW + (i * 256 + wid * 64) * 4);
+        for (int i = 0; i < BPASS; ++i) {
+            const int ci = chunk * CK + b_ch[i];
+            lds_dma16(p.w_split + b_src[i] + (size_t)tap * p.Cin + (ci < p.Cin ? ci : 0),
+                      Bs + stage * NP * BN * ROW + (i * 256 + wid * 64) * 4);
+        }
     };
 
     f32x16 acc[TM][TN];

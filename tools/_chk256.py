@@ -5,7 +5,7 @@ from skillful_nowcasting_amd import ops
 from skillful_nowcasting_amd._lib import call, load
 load(); ops.set_precision("bf16x3")
 dev="cuda"
-for (n,h,w,cin,cout,up,bn) in [(4,64,64,192,96,False,True),(2,128,128,96,96,True,True),(3,32,32,64,192,False,False),(4,16,16,96,96,False,True),(4,8,8,96,192,False,False)]:
+for (n,h,w,cin,cout,up,bn) in [(4,64,64,192,96,False,True),(2,128,128,96,96,True,True),(3,32,32,64,192,False,False),(4,16,16,96,96,False,True),(4,8,8,96,192,False,False),(3,64,64,48,48,False,True),(2,32,32,40,96,False,False),(2,32,32,24,200,True,True),(2,64,64,96,48,False,False)]:
     hin,win_=(h//2,w//2) if up else (h,w)
     x=torch.randn(n*hin*win_*cin,device=dev); wt=torch.randn(cout*9*cin,device=dev)*0.05
     bias=torch.randn(cout,device=dev); scale=torch.full((n,),0.5,device=dev)
