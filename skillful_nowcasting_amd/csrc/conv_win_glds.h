@@ -117,24 +117,28 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
 
     // ---- weights: stage s = chunk * 9 + tap, written by LDS-DMA; unit u of a stage = 16 bytes at LDS offset 16 u ----
     const size_t plane_stride = (size_t)p.Cout * 9 * p.Cin;  // bf16 elements per plane
-    size_t b_src[BPASS];  // element offset of this lane's weight row (tap 0, channel 0)
-    int b_ch[BPASS];      // first channel (inside a chunk) of the 16-byte k-slot this lane fills
+    // per-lane element offsets of the row / k-slot this lane fills (32 bits: a weight plane is < 2^31 elements); the tap / chunk part of
+    // the address is wave-uniform and goes into the scalar base of global_load_lds.  b_tail: the same with k-slots beyond Cin
+    // redirected to channel group 0 (only the last chunk of a Cin % 32 != 0 layer uses it)
+    uint32_t b_off[BPASS], b_tail[BPASS];
+    const int c_last = (nchunks - 1) * CK;
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
         const int u = tid + i * 256;
         const int plane = u / (BN * 4);
         const int r = (u >> 2) % BN;
-        b_ch[i] = ((u ^ (r >> 2)) & 3) * 8;  // logical k-slot held by physical slot (u & 3) of row r
-        b_src[i] = plane * plane_stride + (size_t)min(n0 + r, p.Cout - 1) * 9 * p.Cin;
+        const int ch = ((u ^ (r >> 2)) & 3) * 8;  // first channel (inside a chunk) of the logical k-slot held by physical slot u & 3
+        const uint32_t row = (uint32_t)(plane * plane_stride) + (uint32_t)min(n0 + r, p.Cout - 1) * 9u * p.Cin;
+        b_off[i] = row + ch;
+        b_tail[i] = row + (c_last + ch < p.Cin ? c_last + ch : 0);  // absolute channel: the tail's scalar base has no chunk offset
     }
-    auto dma_b = [&](int s, int stage) {
-        const int chunk = s / 9, tap = s - chunk * 9;
+    const bool has_tail = (p.Cin & (CK - 1)) != 0;
+    auto dma_b = [&](int chunk, int tap, int stage) {
+        const bool tail = has_tail && chunk == nchunks - 1;
+        const uint16_t* base = p.w_split + ((size_t)tap * p.Cin + (tail ? 0 : chunk * CK));
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            const int ci = chunk * CK + b_ch[i];
-            lds_dma16(p.w_split + b_src[i] + (size_t)tap * p.Cin + (ci < p.Cin ? ci : 0),
-                      Bs + stage * NP * BN * ROW + (i * 256 + wid * 64) * 4);
-        }
+        for (int i = 0; i < BPASS; ++i)
+            lds_dma16(base + (tail ? b_tail[i] : b_off[i]), Bs + stage * NP * BN * ROW + (i * 256 + wid * 64) * 4);
     };
 
     f32x16 acc[TM][TN];
@@ -145,29 +149,31 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int prow[TM], pcol[TM], pbase[TM];
+    // halo pixel of this lane under each filter row / column: pix = rowpix[dy] + colpix[dx] (the taps are unrolled below)
+    int rowpix[TM][3], colpix[TM][3];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int q = wm * TM * 32 + i * 32 + (lane & 31);
-        prow[i] = (q >> tw_shift) & (TH - 1);
-        pcol[i] = q & (TW - 1);
-        pbase[i] = (q >> sub_shift) * HP;
+        const int prow = (q >> tw_shift) & (TH - 1), pcol = q & (TW - 1), pbase = (q >> sub_shift) * HP;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            rowpix[i][d] = pbase + (((h0 + prow + d - 1) >> us) - oh) * HTw;
+            colpix[i][d] = ((w0 + pcol + d - 1) >> us) - ow;
+        }
     }
     const int kg = lane >> 5;
     const int bsw = (lane >> 2) & 3;  // swizzle of this lane's weight rows (row = 32 j + (lane & 31))
-    auto mma = [&](int tap, int stage) {
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const uint32_t* Bb0 = Bs + (wn * TN * 32 + (lane & 31)) * ROW;
+    auto mma = [&](int dyi, int dxi, int stage) {
         const uint32_t* Ab[TM];
         int asw[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int lr = ((h0 + prow[i] + dy) >> us) - oh;
-            const int lc = ((w0 + pcol[i] + dx) >> us) - ow;
-            const int pix = pbase[i] + lr * HTw + lc;
+            const int pix = rowpix[i][dyi] + colpix[i][dxi];
             Ab[i] = As + pix * ROW;
             asw[i] = (pix >> 2) & 3;
         }
-        const uint32_t* Bb = Bs + ((stage * NP) * BN + wn * TN * 32 + (lane & 31)) * ROW;
+        const uint32_t* Bb = Bb0 + stage * NP * BN * ROW;
 #pragma unroll
         for (int kk = 0; kk < CK / 16; ++kk) {
             const int ks = kk * 2 + kg;  // logical 16-byte k-slot of this lane's fragment
@@ -203,16 +209,20 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
         }
     };
 
-    dma_b(0, 0);
+    dma_b(0, 0, 0);
     stage_a(0);
     __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
 #pragma unroll 1
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int s = chunk * 9 + tap;
-            if (s + 1 < S) dma_b(s + 1, (s + 1) & 1);  // in flight under this tap's MFMAs
-            mma(tap, s & 1);
-            if (tap == 8 && chunk + 1 < nchunks) {
+            const int st = (chunk + tap) & 1;  // stage of s = 9 chunk + tap
+            // the next stage's DMA is in flight under this tap's MFMAs
+            if (tap < 8) dma_b(chunk, tap + 1, st ^ 1);
+            else if (more) dma_b(chunk + 1, 0, st ^ 1);
+            mma(tap / 3, tap % 3, st);
+            if (tap == 8 && more) {
                 __syncthreads();  // every wave is done with this chunk's halo
                 stage_a(chunk + 1);
             }
