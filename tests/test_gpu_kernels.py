@@ -1,0 +1,117 @@
+"""GPU: kernel variants of one operator against each other, through the C ABI (dgmr_conv_tune selects the variant).
+
+  * LDS-window 3x3 conv: the LDS-DMA kernel (conv_win_glds.h) and the register-staged one (conv_bf16.h) run the same MFMA sequence
+    on the same operands - bit-identical outputs; the implicit-GEMM kernel differs by summation order only;
+  * LDS-window weight gradient (wgrad_win.h) vs the im2col weight gradient: same per-group partial sums and bias gradient
+    (tolerance: bf16x3 product rounding x summation order, 2e-5 of the largest entry).
+"""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture()
+def tuned():
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd._lib import call
+
+    S.set_precision("bf16x3")
+    yield lambda *v: call("dgmr_conv_tune", *v)
+    call("dgmr_conv_tune", -1, -1, -1, -1)
+    S.set_precision("f32")
+
+
+# n, h, w (output), cin, cout, upsample, batchnorm-on-load, residual
+CONV_CASES = [
+    (4, 64, 64, 192, 96, False, True, True),
+    (2, 128, 128, 96, 96, True, True, False),
+    (3, 32, 32, 64, 192, False, False, True),
+    (4, 16, 16, 96, 96, False, True, False),
+    (4, 8, 8, 96, 192, False, False, False),
+    (3, 64, 64, 48, 48, False, True, False),     # Cin and Cout tails of the 32-channel chunk / 64-column tile
+    (2, 32, 32, 40, 96, False, False, False),
+    (2, 32, 32, 24, 200, True, True, True),
+    (2, 64, 64, 96, 128, False, False, False),
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,up,bn,res", CONV_CASES)
+def test_window_conv_variants_agree(tuned, n, h, w, cin, cout, up, bn, res):
+    from skillful_nowcasting_amd import ops
+    from skillful_nowcasting_amd._lib import call
+
+    torch.manual_seed(1)
+    hin, win = (h // 2, w // 2) if up else (h, w)
+    x = torch.randn(n * hin * win * cin, device=DEV)
+    wt = torch.randn(cout * 9 * cin, device=DEV) * 0.05
+    bias = torch.randn(cout, device=DEV)
+    scale = torch.rand(n, device=DEV) + 0.5
+    a = torch.rand(n * cin, device=DEV) + 0.5
+    b = torch.randn(n * cin, device=DEV) * 0.1
+    r = torch.randn(n * h * w * cout, device=DEV) if res else None
+    wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
+    call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, ops._stream())
+    ys = {}
+    for mode in (1, 3, 0):  # register-staged window, LDS-DMA window, implicit GEMM
+        tuned(-1, -1, mode, -1)
+        y = torch.full((n * h * w * cout,), float("nan"), device=DEV)
+        ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, 1, h, w, cin, cout, 1, 3, 3, upsample=up, pre_a=a if bn else None,
+                         pre_b=b if bn else None, pre_group=1, scale_group=1, residual=r, w_split=wsp)
+        torch.cuda.synchronize()
+        ys[mode] = y
+    assert not torch.isnan(ys[3]).any()
+    assert torch.equal(ys[1], ys[3]), f"window kernels differ: max {float((ys[1] - ys[3]).abs().max()):.3e}"
+    tol = 2e-6 * float(ys[0].abs().max())
+    assert float((ys[3] - ys[0]).abs().max()) <= tol
+
+
+# n, h, w, cin, cout, upsample, batchnorm-on-load, call groups
+WGRAD_CASES = [
+    (2, 32, 32, 40, 96, False, True, 2),
+    (2, 64, 64, 32, 48, True, True, 1),
+    (3, 32, 64, 96, 192, False, False, 3),
+    (2, 16, 16, 64, 96, False, True, 2),
+    (3, 16, 16, 32, 64, True, False, 1),
+    (6, 32, 32, 96, 128, False, True, 3),
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,up,bn,groups", WGRAD_CASES)
+def test_window_wgrad_matches_im2col_wgrad(tuned, n, h, w, cin, cout, up, bn, groups):
+    from skillful_nowcasting_amd import ops
+    from skillful_nowcasting_amd._lib import WgradArgs, call
+
+    torch.manual_seed(2)
+    hin, win = (h // 2, w // 2) if up else (h, w)
+    x = torch.randn(n * hin * win * cin, device=DEV)
+    dy = torch.randn(n * h * w * cout, device=DEV)
+    a = torch.rand(groups * cin, device=DEV) + 0.5
+    b = torch.randn(groups * cin, device=DEV) * 0.3
+    k = 9 * cin
+    res = {}
+    for mode in (0, 1):  # im2col, window
+        tuned(-1, -1, -1, mode)
+        bias = torch.zeros(cout, device=DEV)
+        wa = WgradArgs()
+        wa.x, wa.dy = x.data_ptr(), dy.data_ptr()
+        wa.pre_a, wa.pre_b = (a.data_ptr(), b.data_ptr()) if bn else (None, None)
+        wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, 1, h, w, cin, cout
+        wa.KD, wa.KH, wa.KW = 1, 3, 3
+        wa.upsample, wa.pre_relu, wa.pre_group, wa.groups = int(up), int(not bn), n // groups, groups
+        wa.bias_grad = bias.data_ptr()
+        call("dgmr_conv_wgrad_plan", ctypes.byref(wa))
+        ns = wa.nsplit
+        assert ns >= groups and ns % groups == 0
+        partial = torch.full((ns, cout, k), float("nan"), device=DEV)
+        wa.partial = partial.data_ptr()
+        call("dgmr_conv_wgrad", ctypes.byref(wa), ops._stream())
+        torch.cuda.synchronize()
+        res[mode] = (partial.view(groups, ns // groups, cout, k).double().sum(1), bias.double())
+    (g0, b0), (g1, b1) = res[0], res[1]
+    assert not torch.isnan(g1).any()
+    assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
+    assert float((b0 - b1).abs().max()) <= 2e-5 * float(b0.abs().max())

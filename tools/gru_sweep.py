@@ -63,9 +63,10 @@ def main():
         call("dgmr_conv_tune", -1, -1, -1, -1)
         us = bench(fwd)
         print(f"  auto                      {us:8.1f} us  {flops / us / 1e6:7.1f} TF", flush=True)
-        call("dgmr_conv_tune", -1, -1, 1, -1)
-        us = bench(fwd)
-        print(f"  window kernel             {us:8.1f} us  {flops / us / 1e6:7.1f} TF", flush=True)
+        for mode, label in ((1, "window kernel (registers)"), (3, "window kernel (LDS-DMA)  ")):
+            call("dgmr_conv_tune", -1, -1, mode, -1)
+            us = bench(fwd)
+            print(f"  {label} {us:8.1f} us  {flops / us / 1e6:7.1f} TF", flush=True)
         nk = (9 * ch + 31) // 32
         for v, vname in VARIANTS.items():
             bn = int(vname.split("x")[1])

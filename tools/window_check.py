@@ -1,3 +1,6 @@
+"""LDS-window 3x3 conv kernels against each other and against the implicit-GEMM kernel through the C ABI (GPU only):
+register-staged window kernel (dgmr_conv_tune window=1) vs LDS-DMA window kernel (3) must be bit-identical; both vs the generic
+kernel (0) differ by summation order only.  python tools/window_check.py"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
@@ -19,5 +22,5 @@ for (n,h,w,cin,cout,up,bn) in [(4,64,64,192,96,False,True),(2,128,128,96,96,True
         y=torch.empty(n*h*w*cout,device=dev)
         ops._launch_conv(x,wt.data_ptr(),bias,scale,y,n,1,h,w,cin,cout,1,3,3,upsample=up,pre_a=a if bn else None,pre_b=b if bn else None,pre_group=1,scale_group=1,residual=res,w_split=wsp)
         torch.cuda.synchronize(); ys.append(y)
-    print((n,h,w,cin,cout,up,bn),"win128 vs win256 max diff",(ys[0]-ys[1]).abs().max().item(),"vs generic",(ys[0]-ys[2]).abs().max().item(),"scale",ys[0].abs().max().item())
+    print((n,h,w,cin,cout,up,bn),"register-staged vs LDS-DMA window max diff",(ys[0]-ys[1]).abs().max().item(),"vs generic",(ys[0]-ys[2]).abs().max().item(),"scale",ys[0].abs().max().item())
 call("dgmr_conv_tune",-1,-1,-1,-1)
