@@ -510,9 +510,12 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     // 3x3 convs of the big feature maps in the bf16 modes: LDS-window kernel (needs pre-split weights)
     // 8x8 maps: a tile is two whole images; every per-sample group (1/sigma, BatchNorm statistics, relu mask) must then hold
     // an even number of samples so that a tile never straddles two groups
-    const bool small8 = p.H == 8 && p.W == 8 && !p.upsample && p.N % 2 == 0 && (!p.scale || p.scale_group % 2 == 0) &&
+    const bool small8 = p.H == 8 && p.W == 8 && p.D == 1 && !p.upsample && p.N % 2 == 0 && (!p.scale || p.scale_group % 2 == 0) &&
                         (!p.pre_a || p.pre_group % 2 == 0) && (!p.mask_a || p.mask_group % 2 == 0);
-    if (g_precision != 0 && p.w_split && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.D == 1 && p.Cin % 8 == 0 &&
+    // the LDS-DMA kernel (bf16x3) also takes 3x3x3 convs, plane by plane
+    const bool glds_ok = g_precision == 1 && (g_tune_window < 0 || g_tune_window == 3);
+    const bool is3d = p.KD == 3 && p.D > 1 && glds_ok && !p.upsample && !p.residual_up;
+    if (g_precision != 0 && p.w_split && ((p.KD == 1 && p.D == 1) || is3d) && p.KH == 3 && p.KW == 3 && p.Cin % 8 == 0 &&
         (p.W == 16 || p.W % 32 == 0 || small8) &&
         (g_tune_window < 0 ? (M64 / 128) * ((C + 127) / 128) >= 192 : g_tune_window >= 1)) {
         const int tw_shift = small8 ? 3 : (p.W == 16 ? 4 : 5);
@@ -524,7 +527,7 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         if (p.H % THv == 0) {
             const int tiles_w = p.W / TWv, tiles_hw = tiles_w * (p.H / THv);
             const int bnw = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
-            const dim3 grid((unsigned)(g_shift ? p.N >> g_shift : p.N * tiles_hw), (unsigned)((C + bnw - 1) / bnw));
+            const dim3 grid((unsigned)(g_shift ? p.N >> g_shift : p.N * p.D * tiles_hw), (unsigned)((C + bnw - 1) / bnw));
             const int v = bnw == 128 ? V_WIN128 : (bnw == 96 ? V_WIN96 : V_WIN64);
             ProfScope ps(v, flops, s);
 #define DGMR_WIN(BN_, WM_, WN_)                                                                                              \
@@ -536,7 +539,7 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     } while (0)
             // bf16x3: weight stages by LDS-DMA (conv_win_glds.h; measured +4..17 %
             // over the register-staged kernel below, bit-identical results)
-            if (g_precision == 1 && (g_tune_window < 0 || g_tune_window == 3) && !big) {
+            if (glds_ok && !big) {
                 if (bnw == 128)
                     hipLaunchKernelGGL((conv3x3_glds_kernel<128, 2, 2, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
                 else if (bnw == 96)

@@ -9,6 +9,9 @@
 //     at slot s ^ ((r >> 2) & 3), which keeps the 16 rows of a ds_read_b128 lane group on 16 distinct bank slots; the weight rows
 //     are swizzled through the per-lane SOURCE address of the DMA, the activation rows at their ds_write;
 //   * 26 KB of activations + 2 x 12 KB of weights (96 output channels, bf16x3) = three workgroups per CU.
+// 3x3x3 convolutions (the temporal discriminator's 3-D blocks, discriminators.py:189-205) run through the same kernel: a tile lies
+// in one depth plane, every 32-channel chunk is walked as three groups of nine taps, and the halo of input plane d + kd - 1 is
+// restaged per group (all zeros when that plane is outside the volume).
 // A DMA cannot zero-fill: output channels beyond Cout read the last row (their columns are never stored) and input channels
 // beyond Cin read channel group 0 (their activations are exact zeros).  Everything else is conv3x3_win_kernel's.
 #pragma once
@@ -50,7 +53,10 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
     const int TW = 1 << tw_shift, TH = (BM >> tw_shift) >> g_shift;
     const int sub_shift = 7 - g_shift;
     const int tile = blockIdx.x;
-    const int n = g_shift ? (tile << g_shift) : tile / tiles_hw;
+    const int n = g_shift ? (tile << g_shift) : tile / tiles_hw;  // first image of the tile; 3-D: depth plane (sample * D + d)
+    const int KD = p.KD;                                           // 1, or 3 (then g_shift == 0)
+    const int smp = KD == 3 ? n / p.D : n;                         // sample of the tile's first image: statistics / sigma groups
+    const int dpl = KD == 3 ? n - smp * p.D : 0;
     const int trem = g_shift ? 0 : tile - n * tiles_hw;
     const int th = trem / tiles_w;
     const int h0 = th * TH, w0 = (trem - th * tiles_w) * TW;
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
     const int HP = ((TH >> us) + 2) * HTw;
     const int npix = HP << g_shift;
     const int nchunks = (p.Cin + CK - 1) / CK;
-    const int S = nchunks * 9;
+    const int taps = 9 * KD;
 
     // ---- activation halo (registers -> prologue -> split -> swizzled ds_write), as conv3x3_win_kernel ----
     const int cq = tid & 7;
@@ -80,16 +86,20 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
     }
     const float* pa_base = p.pre_a ? p.pre_a : p.x;
     const float* pb_base = p.pre_a ? p.pre_b : p.x;
-    const uint32_t grp_off = (uint32_t)(n / p.pre_group) * p.Cin;
+    const uint32_t grp_off = (uint32_t)(smp / p.pre_group) * p.Cin;
+    const uint32_t plane_elems = (uint32_t)Hs * Ws * p.Cin;
 
-    auto stage_a = [&](int chunk) {  // fetch, transform and store one 32-channel halo (latency covered by the other workgroups)
+    // fetch, transform and store one 32-channel halo (latency covered by the other workgroups); kd: depth tap of a 3-D conv
+    auto stage_a = [&](int chunk, int kd) {
         f32x4 ra[APASS];
         const int cb = chunk * CK + cq * 4;
-        const bool kok = cb < p.Cin;
+        const int dz = KD == 3 ? kd - 1 : 0;
+        const bool kok = cb < p.Cin && (unsigned)(dpl + dz) < (unsigned)p.D;
         const unsigned valid = kok ? a_valid : 0u;
+        const uint32_t shift = chunk * CK + dz * (int)plane_elems;  // wraps consistently for dz = -1
 #pragma unroll
         for (int i = 0; i < APASS; ++i)
-            ra[i] = *reinterpret_cast<const f32x4*>(p.x + (((valid >> i) & 1u) ? a_goff[i] + chunk * CK : 0u));
+            ra[i] = *reinterpret_cast<const f32x4*>(p.x + (((valid >> i) & 1u) ? a_goff[i] + shift : 0u));
         const f32x4 rpa = *reinterpret_cast<const f32x4*>(pa_base + ((p.pre_a && kok) ? grp_off + cb : 0u));
         const f32x4 rpb = *reinterpret_cast<const f32x4*>(pb_base + ((p.pre_a && kok) ? grp_off + cb : 0u));
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
     };
 
     // ---- weights: stage s = chunk * 9 + tap, written by LDS-DMA; unit u of a stage = 16 bytes at LDS offset 16 u ----
-    const size_t plane_stride = (size_t)p.Cout * 9 * p.Cin;  // bf16 elements per plane
+    const size_t plane_stride = (size_t)p.Cout * 9 * p.KD * p.Cin;  // bf16 elements per plane
     // per-lane element offsets of the row / k-slot this lane fills (32 bits: a weight plane is < 2^31 elements); the tap / chunk part of
     // the address is wave-uniform and goes into the scalar base of global_load_lds.  b_tail: the same with k-slots beyond Cin
     // redirected to channel group 0 (only the last chunk of a Cin % 32 != 0 layer uses it)
@@ -128,12 +138,12 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
         const int plane = u / (BN * 4);
         const int r = (u >> 2) % BN;
         const int ch = ((u ^ (r >> 2)) & 3) * 8;  // first channel (inside a chunk) of the logical k-slot held by physical slot u & 3
-        const uint32_t row = (uint32_t)(plane * plane_stride) + (uint32_t)min(n0 + r, p.Cout - 1) * 9u * p.Cin;
+        const uint32_t row = (uint32_t)(plane * plane_stride) + (uint32_t)min(n0 + r, p.Cout - 1) * (uint32_t)taps * p.Cin;
         b_off[i] = row + ch;
         b_tail[i] = row + (c_last + ch < p.Cin ? c_last + ch : 0);  // absolute channel: the tail's scalar base has no chunk offset
     }
     const bool has_tail = (p.Cin & (CK - 1)) != 0;
-    auto dma_b = [&](int chunk, int tap, int stage) {
+    auto dma_b = [&](int chunk, int tap, int stage) {  // tap: 0 .. 9 KD - 1
         const bool tail = has_tail && chunk == nchunks - 1;
         const uint16_t* base = p.w_split + ((size_t)tap * p.Cin + (tail ? 0 : chunk * CK));
 #pragma unroll
@@ -210,28 +220,32 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
     };
 
     dma_b(0, 0, 0);
-    stage_a(0);
+    stage_a(0, 0);
     __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
+    const int ngroups = nchunks * KD;  // groups of nine taps: (chunk, kd)
 #pragma unroll 1
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const bool more = chunk + 1 < nchunks;
+    for (int g = 0; g < ngroups; ++g) {
+        const int chunk = KD == 3 ? g / 3 : g;
+        const int kd = KD == 3 ? g - chunk * 3 : 0;
+        const bool more = g + 1 < ngroups;
+        const int nchunk = (KD == 3 && kd < 2) ? chunk : chunk + 1, nkd = (KD == 3 && kd < 2) ? kd + 1 : 0;  // the next group
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int st = (chunk + tap) & 1;  // stage of s = 9 chunk + tap
+            const int st = (g + tap) & 1;  // stage of s = 9 g + tap
             // the next stage's DMA is in flight under this tap's MFMAs
-            if (tap < 8) dma_b(chunk, tap + 1, st ^ 1);
-            else if (more) dma_b(chunk + 1, 0, st ^ 1);
+            if (tap < 8) dma_b(chunk, kd * 9 + tap + 1, st ^ 1);
+            else if (more) dma_b(nchunk, nkd * 9, st ^ 1);
             mma(tap / 3, tap % 3, st);
             if (tap == 8 && more) {
-                __syncthreads();  // every wave is done with this chunk's halo
-                stage_a(chunk + 1);
+                __syncthreads();  // every wave is done with this group's halo
+                stage_a(nchunk, nkd);
             }
             __syncthreads();
         }
     }
 
     // ---- epilogue (conv3x3_win_kernel's) ----
-    const float sc = p.scale ? p.scale[n / p.scale_group] : 1.f;
+    const float sc = p.scale ? p.scale[smp / p.scale_group] : 1.f;
     float bj[TN];
     int colj[TN];
 #pragma unroll
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const bool on = p.mask_a && colj[j] < p.Cout;
-        const size_t g = (size_t)(n / p.mask_group) * p.Cout + (on ? colj[j] : 0);
+        const size_t g = (size_t)(smp / p.mask_group) * p.Cout + (on ? colj[j] : 0);
         maj[j] = on ? p.mask_a[g] : 1.f;
         mbj[j] = on ? p.mask_b[g] : 0.f;
     }
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
                     if (p.mask_src) v = fmaf(p.mask_src[(size_t)m * p.Cout + colj[j]], maj[j], mbj[j]) > 0.f ? v : 0.f;
                     yrow[colj[j]] = v;
                 } else {
-                    epilogue_store(p, acc[i][j][r], ni, colj[j], (size_t)m * p.Cout + colj[j], rbase + colj[j]);
+                    epilogue_store(p, acc[i][j][r], KD == 3 ? smp : ni, colj[j], (size_t)m * p.Cout + colj[j], rbase + colj[j]);
                 }
             }
         }

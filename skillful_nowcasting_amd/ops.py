@@ -274,11 +274,12 @@ _PRECISION_CODE = 0  # mirror of the library's mode (set_precision keeps it in s
 
 
 def _split_planes(w: torch.Tensor, flipped: bool, coff: int = 0, cin: Optional[int] = None) -> Optional[torch.Tensor]:
-    """bf16 (hi, lo) planes of a 2-D 3x3 conv weight — optionally of its input-channel slice [coff, coff+cin) — or of the flipped /
-    transposed version used by the data gradient; cached until the parameter changes.  None when the LDS-window kernel cannot take
-    this conv (mode f32, not 3x3, channel count % 8)."""
-    if _PRECISION_CODE == 0 or w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
+    """bf16 (hi, lo) planes of a 3x3 (or 3x3x3) conv weight — optionally of its input-channel slice [coff, coff+cin) — or of the
+    flipped / transposed version used by the data gradient; cached until the parameter changes.  None when the LDS-window kernels
+    cannot take this conv (mode f32, not 3x3[x3], channel count % 8)."""
+    if _PRECISION_CODE == 0 or w.dim() not in (4, 5) or any(k != 3 for k in w.shape[2:]):
         return None
+    taps = 9 if w.dim() == 4 else 27
     cout, cin_total = w.shape[0], w.shape[1]
     if cin is None:
         cin = cin_total
@@ -290,11 +291,11 @@ def _split_planes(w: torch.Tensor, flipped: bool, coff: int = 0, cin: Optional[i
     hit = _split_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
-    out = torch.empty(2 * cout * 9 * cin, device=w.device, dtype=torch.int16)
+    out = torch.empty(2 * cout * taps * cin, device=w.device, dtype=torch.int16)
     if flipped:  # the flipped slice is already dense
-        call("dgmr_split_weights", _p(_flipped_weight(w, coff, cin)), _p(out), rows_c * 9, k_c, 0, 0, _stream())
+        call("dgmr_split_weights", _p(_flipped_weight(w, coff, cin)), _p(out), rows_c * taps, k_c, 0, 0, _stream())
     else:
-        call("dgmr_split_weights", _p(w), _p(out), rows_c * 9, k_c, cin_total, coff, _stream())
+        call("dgmr_split_weights", _p(w), _p(out), rows_c * taps, k_c, cin_total, coff, _stream())
     _split_cache[key] = (tag, out, weakref.ref(w, lambda _r, k=key: _split_cache.pop(k, None)))
     return out
 
@@ -358,7 +359,7 @@ class ConvFn(Function):
         _launch_conv(x, _p(w), bias, scale, y, n, d, h, wd, cin, cout, kd, kh, kw, upsample=spec.upsample,
                      pre_relu=spec.pre_relu, pre_a=bn.a if bn else None, pre_b=bn.b if bn else None,
                      pre_group=bn.group_size if bn else 1, residual=residual, act_relu=spec.act_relu,
-                     scale_group=n // groups, w_split=_split_planes(w, False) if d == 1 else None, residual_up=spec.residual_up)
+                     scale_group=n // groups, w_split=_split_planes(w, False), residual_up=spec.residual_up)
         ctx.spec = spec  # flags only are read from it in backward; its tensors are re-read from saved_tensors
         ctx.has_residual = residual is not None
         # parameters are kept as-is (checkpointing hands back DETACHED copies of saved tensors: .grad must land on the real ones)
@@ -434,7 +435,7 @@ class ConvFn(Function):
             if spec.upsample:
                 hi = empty_cl((n, cin, h, wd) if x.dim() == 4 else (n, cin, d, h, wd), dy)
                 _launch_conv(dy, _p(wt), None, scale, hi, n, d, h, wd, cout, cin, kd, kh, kw, scale_group=n // groups,
-                             w_split=_split_planes(w, True) if d == 1 else None)
+                             w_split=_split_planes(w, True))
                 g = empty_cl(x.shape, dy)
                 call("dgmr_pool_fwd", _p(hi), None, _p(g), n, d, h, wd, cin, 1, 1.0, _p(x) if (bn or spec.pre_relu) else None,
                      _p(bn_a) if bn else None, _p(bn_b) if bn else None, bn.group_size if bn else 1, st)
@@ -443,7 +444,7 @@ class ConvFn(Function):
                 _launch_conv(dy, _p(wt), None, scale, g, n, d, h, wd, cout, cin, kd, kh, kw,
                              mask_src=x if (bn or spec.pre_relu) else None, mask_a=bn_a if bn else None,
                              mask_b=bn_b if bn else None, mask_group=bn.group_size if bn else 1, scale_group=n // groups,
-                             w_split=_split_planes(w, True) if d == 1 else None)
+                             w_split=_split_planes(w, True))
             if bn is None:
                 dx = g
             else:

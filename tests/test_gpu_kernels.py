@@ -69,6 +69,36 @@ def test_window_conv_variants_agree(tuned, n, h, w, cin, cout, up, bn, res):
     assert float((ys[3] - ys[0]).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("n,d,h,w,cin,cout,relu,res", [
+    (2, 6, 32, 32, 48, 48, True, True),      # the temporal discriminator's first 3-D block shape (channel tails on both sides)
+    (3, 4, 16, 16, 16, 96, False, False),
+    (1, 5, 32, 64, 96, 128, True, False),
+])
+def test_window_conv3d_matches_implicit_gemm(tuned, n, d, h, w, cin, cout, relu, res):
+    """3x3x3 convs go through the LDS-DMA window kernel plane by plane (zero planes beyond the volume)."""
+    from skillful_nowcasting_amd import ops
+    from skillful_nowcasting_amd._lib import call
+
+    torch.manual_seed(3)
+    x = torch.randn(n * d * h * w * cin, device=DEV)
+    wt = torch.randn(cout * 27 * cin, device=DEV) * 0.05
+    bias = torch.randn(cout, device=DEV)
+    scale = torch.rand(n, device=DEV) + 0.5
+    r = torch.randn(n * d * h * w * cout, device=DEV) if res else None
+    wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
+    call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 27, cin, 0, 0, ops._stream())
+    ys = {}
+    for mode in (3, 0):
+        tuned(-1, -1, mode, -1)
+        y = torch.full((n * d * h * w * cout,), float("nan"), device=DEV)
+        ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, d, h, w, cin, cout, 3, 3, 3, pre_relu=relu, scale_group=1, residual=r,
+                         w_split=wsp)
+        torch.cuda.synchronize()
+        ys[mode] = y
+    assert not torch.isnan(ys[3]).any()
+    assert float((ys[3] - ys[0]).abs().max()) <= 2e-6 * float(ys[0].abs().max())
+
+
 # n, h, w, cin, cout, upsample, batchnorm-on-load, call groups
 WGRAD_CASES = [
     (2, 32, 32, 40, 96, False, True, 2),

@@ -28,6 +28,8 @@ SHAPES = [
     ("gru4.gate", 16, 1, 64, 64, 144, 48, (1, 3, 3), False, False),
     ("gru_1x1_4 T18", 288, 1, 64, 64, 48, 96, (1, 1, 1), False, False),
     ("tempD.d1.last 3d", 32, 22, 64, 64, 48, 48, (3, 3, 3), False, False),
+    ("tempD.d2.first 3d", 32, 11, 32, 32, 48, 96, (3, 3, 3), False, False),
+    ("tempD.d2.last 3d", 32, 11, 32, 32, 96, 96, (3, 3, 3), False, False),
     ("tempD.d1.first 3d", 32, 22, 64, 64, 4, 48, (3, 3, 3), False, False),
     ("spatD.d2.first f8", 256, 1, 32, 32, 48, 96, (1, 3, 3), False, False),
     ("spatD.d5 f8", 256, 1, 4, 4, 384, 768, (1, 3, 3), False, False),
@@ -77,9 +79,9 @@ def main():
         flops = 2.0 * n * d * h * w * cout * cin * kd * kh * kw
 
         wsp = None
-        if ops.get_precision() != "f32" and ks == (1, 3, 3) and cin % 8 == 0 and "--nowin" not in sys.argv:
+        if ops.get_precision() != "f32" and ks in ((1, 3, 3), (3, 3, 3)) and cin % 8 == 0 and "--nowin" not in sys.argv:
             wsp = torch.empty(2 * wt.numel(), device=dev, dtype=torch.int16)
-            call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, ops._stream())
+            call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * kd * 9, cin, 0, 0, ops._stream())
 
         def fwd():
             ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, d, h, w, cin, cout, kd, kh, kw, upsample=up,
