@@ -169,6 +169,67 @@ __global__ void splitk_reduce_kernel(const dgmr_conv_args p, const int M, const 
     }
 }
 
+// The same for Cout % 4 == 0 and M * Cout < 2^31 (every ConvGRU step): four columns per thread, the S partial sums and all the
+// epilogue's operands (addend, ConvGRU state, residual, mask source) fetched as independent 16-byte loads before any arithmetic -
+// the scalar kernel above chains ~S + 5 dependent memory round trips and three integer divisions per element.
+__global__ void splitk_reduce4_kernel(const dgmr_conv_args p, const int M, const int S) {
+    const uint32_t total4 = (uint32_t)((size_t)M * p.Cout / 4);
+    const uint32_t DHW = (uint32_t)(p.D * p.H * p.W);
+    const uint32_t c4 = (uint32_t)p.Cout / 4;
+    const f32x4* ws = reinterpret_cast<const f32x4*>(p.splitk_ws);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+        f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
+        int z = 0;
+        for (; z + 4 <= S; z += 4) {
+            a0 += ws[(size_t)z * total4 + i];
+            a1 += ws[(size_t)(z + 1) * total4 + i];
+            a2 += ws[(size_t)(z + 2) * total4 + i];
+            a3 += ws[(size_t)(z + 3) * total4 + i];
+        }
+        for (; z < S; ++z) a0 += ws[(size_t)z * total4 + i];
+        const uint32_t row = i / c4, col = (i - row * c4) * 4;
+        const uint32_t n = row / DHW;
+        const size_t idx = (size_t)i * 4;
+        f32x4 ad = zero4, hv = zero4, pv = zero4, rs = zero4, ms = zero4, bs = zero4, ma = {1.f, 1.f, 1.f, 1.f}, mb = zero4;
+        const float sc = p.scale ? p.scale[n / p.scale_group] : 1.f;
+        if (p.addend) ad = *reinterpret_cast<const f32x4*>(p.addend + idx);
+        if (p.bias) bs = *reinterpret_cast<const f32x4*>(p.bias + col);
+        if (p.epi_mode != DGMR_EPI_PLAIN) hv = *reinterpret_cast<const f32x4*>(p.gru_h + idx);
+        if (p.epi_mode == DGMR_EPI_GRU_BLEND) pv = *reinterpret_cast<const f32x4*>(p.gru_pu + idx);
+        if (p.epi_mode == DGMR_EPI_PLAIN && p.residual)
+            rs = *reinterpret_cast<const f32x4*>(p.residual + (p.residual_up ? residual_row_base(p, n, row - n * DHW) + col : idx));
+        if (p.epi_mode == DGMR_EPI_PLAIN && p.mask_src) {
+            ms = *reinterpret_cast<const f32x4*>(p.mask_src + idx);
+            if (p.mask_a) {
+                const size_t g = (size_t)(n / p.mask_group) * p.Cout + col;
+                ma = *reinterpret_cast<const f32x4*>(p.mask_a + g);
+                mb = *reinterpret_cast<const f32x4*>(p.mask_b + g);
+            }
+        }
+        f32x4 v = ((a0 + a1) + (a2 + a3)) + ad;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = p.scale ? v[j] * sc : v[j];
+            v[j] += bs[j];
+            if (p.epi_mode == DGMR_EPI_GRU_GATE) {
+                o[j] = sigmoid_(v[j]) * hv[j];
+            } else if (p.epi_mode == DGMR_EPI_GRU_BLEND) {
+                const float sg = sigmoid_(pv[j]);
+                o[j] = sg * hv[j] + (1.f - sg) * fmaxf(v[j], 0.f);
+            } else {
+                float t = p.act_relu ? fmaxf(v[j], 0.f) : v[j];
+                if (p.residual) t += rs[j];
+                if (p.mask_src) t = fmaf(ms[j], ma[j], mb[j]) > 0.f ? t : 0.f;
+                o[j] = t;
+            }
+        }
+        if (p.epi_mode != DGMR_EPI_PLAIN) *reinterpret_cast<f32x4*>(p.pre_out + idx) = v;
+        *reinterpret_cast<f32x4*>(p.y + idx) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Optional per-launch timing (bench.py's roofline leg): HIP events recorded on the launch stream around every
 // conv / wgrad kernel, grouped by tile variant.  Off by default; never used inside the timed region.
@@ -243,8 +304,13 @@ int launch_conv(const dgmr_conv_args& a, int M, int Ktot, hipStream_t s) {
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, WM, WN>), grid, dim3(64 * WM * WN), 0, s, a, M, Ktot, per);
     if (Seff > 1) {
         const size_t total = (size_t)M * a.Cout;
-        const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a, M, Seff);
+        if (a.Cout % 4 == 0 && total < (1ull << 31)) {
+            const int blocks = (int)std::min<size_t>((total / 4 + 255) / 256, 2048);
+            hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, s, a, M, Seff);
+        } else {
+            const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a, M, Seff);
+        }
     }
     return 0;
 }

@@ -253,8 +253,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
         colj[j] = n0 + wn * TN * 32 + j * 32 + (lane & 31);
         bj[j] = (p.bias && colj[j] < p.Cout) ? p.bias[colj[j]] : 0.f;
     }
-    const bool simple = !p.addend && p.epi_mode == DGMR_EPI_PLAIN;
-    float maj[TN], mbj[TN];
+    float maj[TN], mbj[TN];  // affine of the BatchNorm whose relu is being back-propagated through (data gradient), per column
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const bool on = p.mask_a && colj[j] < p.Cout;
@@ -262,27 +261,67 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
         maj[j] = on ? p.mask_a[g] : 1.f;
         mbj[j] = on ? p.mask_b[g] : 0.f;
     }
+    // Every variant is straight-line per output row: the loads of a row (addend, ConvGRU state, residual, mask source) are issued
+    // together, unconditionally, on clamped addresses.  (The element-wise generic epilogue with its per-element divisions and
+    // dependent loads made a ConvGRU step conv spend as long in its epilogue as in its 18 taps.)
+    const int emode = p.epi_mode;
+    const int cmax = p.Cout - 1;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int hh = h0 + ((q >> tw_shift) & (TH - 1)), ww = w0 + (q & (TW - 1)), ni = n + (q >> sub_shift);
-            const int m = (ni * p.H + hh) * p.W + ww;
-            float* yrow = p.y + (size_t)m * p.Cout;
-            const size_t rbase = p.residual_up ? (((size_t)ni * (p.H >> 1) + (hh >> 1)) * (p.W >> 1) + (ww >> 1)) * p.Cout
-                                               : (size_t)m * p.Cout;
+            const size_t mrow = (size_t)((ni * p.H + hh) * p.W + ww) * p.Cout;
+            const size_t rrow = p.residual_up ? (((size_t)ni * (p.H >> 1) + (hh >> 1)) * (p.W >> 1) + (ww >> 1)) * p.Cout : mrow;
+            float v[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (colj[j] >= p.Cout) continue;
-                if (simple) {
-                    float v = fmaf(acc[i][j][r], sc, bj[j]);
-                    if (p.act_relu) v = fmaxf(v, 0.f);
-                    if (p.residual) v += p.residual[rbase + colj[j]];
-                    if (p.mask_src) v = fmaf(p.mask_src[(size_t)m * p.Cout + colj[j]], maj[j], mbj[j]) > 0.f ? v : 0.f;
-                    yrow[colj[j]] = v;
-                } else {
-                    epilogue_store(p, acc[i][j][r], KD == 3 ? smp : ni, colj[j], (size_t)m * p.Cout + colj[j], rbase + colj[j]);
+            for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
+            if (p.addend) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] += p.addend[mrow + min(colj[j], cmax)];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) v[j] = fmaf(v[j], sc, bj[j]);
+            if (emode == DGMR_EPI_PLAIN) {
+                float rs[TN], ms[TN];
+                if (p.residual) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) rs[j] = p.residual[rrow + min(colj[j], cmax)];
+                }
+                if (p.mask_src) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) ms[j] = p.mask_src[mrow + min(colj[j], cmax)];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float o = v[j];
+                    if (p.act_relu) o = fmaxf(o, 0.f);
+                    if (p.residual) o += rs[j];
+                    if (p.mask_src) o = fmaf(ms[j], maj[j], mbj[j]) > 0.f ? o : 0.f;
+                    if (colj[j] < p.Cout) p.y[mrow + colj[j]] = o;
+                }
+            } else {  // ConvGRU step: pre_out = v; gate: y = sigmoid(v) * h; blend: y = s*h + (1-s)*relu(v), s = sigmoid(pu)
+                float hv[TN], pv[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) hv[j] = p.gru_h[mrow + min(colj[j], cmax)];
+                if (emode == DGMR_EPI_GRU_BLEND) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) pv[j] = p.gru_pu[mrow + min(colj[j], cmax)];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float o;
+                    if (emode == DGMR_EPI_GRU_BLEND) {
+                        const float sg = sigmoid_(pv[j]);
+                        o = sg * hv[j] + (1.f - sg) * fmaxf(v[j], 0.f);
+                    } else {
+                        o = sigmoid_(v[j]) * hv[j];
+                    }
+                    if (colj[j] < p.Cout) {
+                        p.pre_out[mrow + colj[j]] = v[j];
+                        p.y[mrow + colj[j]] = o;
+                    }
                 }
             }
         }

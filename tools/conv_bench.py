@@ -23,6 +23,10 @@ SHAPES = [
     ("g1.first t1", 16, 1, 8, 8, 768, 768, (1, 3, 3), False, True),
     ("g1.first T18", 288, 1, 8, 8, 768, 768, (1, 3, 3), False, True),
     ("c64 T18", 288, 1, 64, 64, 192, 64, (1, 3, 3), False, True),
+    ("lat Cin32", 16, 1, 64, 64, 32, 64, (1, 3, 3), False, False),
+    ("lat Cin64", 16, 1, 64, 64, 64, 64, (1, 3, 3), False, False),
+    ("lat Cin128", 16, 1, 64, 64, 128, 64, (1, 3, 3), False, False),
+    ("lat Cin256", 16, 1, 64, 64, 256, 64, (1, 3, 3), False, False),
     ("gru1.gate", 16, 1, 8, 8, 1152, 384, (1, 3, 3), False, False),
     ("gru1.h-only", 16, 1, 8, 8, 384, 384, (1, 3, 3), False, False),
     ("gru4.gate", 16, 1, 64, 64, 144, 48, (1, 3, 3), False, False),
