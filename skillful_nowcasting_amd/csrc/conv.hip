@@ -543,6 +543,9 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     DGMR_CHECK_ARG((a->pre_a == nullptr) == (a->pre_b == nullptr), "dgmr_conv_fwd: pre_a/pre_b must come together");
     const int64_t M64 = (int64_t)a->N * a->D * a->H * a->W;
     DGMR_CHECK_ARG(M64 > 0 && M64 < (1ll << 31), "dgmr_conv_fwd: M=%lld out of range", (long long)M64);
+    // the kernels address the input with 32-bit element offsets
+    DGMR_CHECK_ARG((M64 >> (a->upsample ? 2 : 0)) * a->Cin < (1ll << 32), "dgmr_conv_fwd: input of %lld x %d elements exceeds 2^32",
+                   (long long)M64, a->Cin);
     DGMR_CHECK_ARG(a->epi_mode == DGMR_EPI_PLAIN || (a->pre_out && a->gru_h && (a->epi_mode != DGMR_EPI_GRU_BLEND || a->gru_pu)),
                    "dgmr_conv_fwd: epi_mode %d needs pre_out / gru_h / gru_pu", a->epi_mode);
     DGMR_CHECK_ARG(a->w_cin == 0 || (a->w_cin >= a->w_coff + a->Cin && a->w_coff >= 0 && a->w_coff % 4 == 0 && a->w_cin % 4 == 0),

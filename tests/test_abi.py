@@ -84,6 +84,44 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     assert b"null pointer" in lib.dgmr_last_error()
 
 
+def test_wgrad_plan_is_host_arithmetic(lib):
+    """dgmr_conv_wgrad_plan fills nsplit from the geometry alone (no launch): a multiple of the call groups, at least one slab per
+    group, and - in the bf16 modes, for 3x3 convs on maps made of whole rows of 32 / 16 pixels - sized for the window kernel."""
+    from skillful_nowcasting_amd._lib import WgradArgs
+
+    def plan(prec, n, h, w, cin, cout, k, groups):
+        assert lib.dgmr_set_precision(prec) == 0
+        a = WgradArgs()
+        a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, 1, h, w, cin, cout
+        a.KD, a.KH, a.KW = 1, k, k
+        a.groups, a.pre_group = groups, 1
+        assert lib.dgmr_conv_wgrad_plan(ctypes.byref(a)) == 0
+        return a.nsplit
+
+    try:
+        for prec in (0, 1, 2):
+            for (n, h, w, cin, cout, k, groups) in [(288, 128, 128, 96, 96, 3, 18), (288, 16, 16, 768, 768, 3, 18), (16, 8, 8, 768, 768, 3, 1),
+                                                    (288, 64, 64, 48, 96, 1, 18), (4, 32, 32, 8, 8, 3, 2), (36, 64, 64, 192, 192, 3, 18)]:
+                ns = plan(prec, n, h, w, cin, cout, k, groups)
+                assert ns >= groups and ns % groups == 0 and ns <= 4096, (prec, n, h, w, cin, cout, k, groups, ns)
+        # window path (bf16x3, 3x3, W % 32 == 0): one round of <= 512 workgroups = chunks x output tiles x slabs
+        ns = plan(1, 288, 128, 128, 96, 96, 3, 18)
+        assert 3 * 1 * ns <= 512 and ns == 162
+        # f32 mode keeps the im2col kernel's slab count
+        assert plan(0, 288, 128, 128, 96, 96, 3, 18) == lib.dgmr_conv_wgrad_nsplit(288 * 128 * 128, 96, 9 * 96, 18)
+    finally:
+        lib.dgmr_set_precision(0)
+
+
+def test_tune_and_small_op_argument_checks(lib):
+    assert lib.dgmr_conv_tune(-1, -1, -1, -1) == 0
+    assert lib.dgmr_conv_tune(99, -1, -1, -1) < 0 and b"dgmr_conv_tune" in lib.dgmr_last_error()
+    assert lib.dgmr_conv_tune(-1, -1, -1, -1) == 0
+    buf = (ctypes.c_float * 8)()
+    assert lib.dgmr_repeat_rows(buf, buf, 6, 2, None) < 0 and b"multiple of 4" in lib.dgmr_last_error()
+    assert lib.dgmr_group_rowsum(buf, None, buf, 1, 2, 6, 1, None) < 0 and b"multiple of 4" in lib.dgmr_last_error()
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from skillful_nowcasting_amd import _lib
 
