@@ -717,6 +717,7 @@ static int wgrad_window_tw_shift(const dgmr_wgrad_args* a) { return a->W % 32 ==
 extern "C" int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a) {
     DGMR_CHECK_ARG(a && a->N > 0 && a->Cin > 0 && a->Cout > 0, "dgmr_conv_wgrad_plan: bad args");
     const int groups = a->groups < 1 ? 1 : a->groups;
+    DGMR_CHECK_ARG(a->N % groups == 0, "dgmr_conv_wgrad_plan: N=%d not divisible by groups=%d", a->N, groups);
     const int64_t M = (int64_t)a->N * a->D * a->H * a->W;
     if (!wgrad_uses_window(a)) {
         a->nsplit = dgmr_conv_wgrad_nsplit((int)M, a->Cout, a->KD * a->KH * a->KW * a->Cin, groups);
@@ -743,6 +744,9 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
                    a->nsplit, a->N, groups);
     const int64_t M64 = (int64_t)a->N * a->D * a->H * a->W;
     DGMR_CHECK_ARG(M64 > 0 && M64 < (1ll << 31), "dgmr_conv_wgrad: M out of range");
+    // 32-bit element offsets into x (as in dgmr_conv_fwd)
+    DGMR_CHECK_ARG((M64 >> (a->upsample ? 2 : 0)) * a->Cin < (1ll << 32), "dgmr_conv_wgrad: input of %lld x %d elements exceeds 2^32",
+                   (long long)M64, a->Cin);
     dgmr_wgrad_args p = *a;
     if (p.pre_group < 1) p.pre_group = 1;
     const int M = (int)M64, Ktot = a->KD * a->KH * a->KW * a->Cin;
