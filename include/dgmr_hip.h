@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGMR_ABI_VERSION 5
+#define DGMR_ABI_VERSION 6
 
 int dgmr_abi_version(void);
 const char* dgmr_last_error(void);
@@ -138,7 +138,7 @@ int dgmr_conv_wgrad_nsplit(int M, int Cout, int K, int groups);
 int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a);
 
 /* With P_q = sum of group q's slabs:  g[Cout*K] = sum_q scale[q] * P_q  (scale == NULL: 1);  dot[q] += <P_q, w>  (dot == NULL:
- * skipped; otherwise [groups], zeroed by the caller / the previous finalize).  groups <= 32. */
+ * skipped; otherwise [groups], zeroed by the caller / the previous finalize).  groups <= 128. */
 int dgmr_wgrad_reduce(const float* partial, int nsplit, int groups, int64_t numel, const float* w, const float* scale, float* g,
                       float* dot, void* stream);
 /* Same for a weight gradient computed on an input-channel slice: partial is [nsplit][Cout][taps][cin_slice]; element
@@ -192,6 +192,11 @@ typedef struct dgmr_sn_desc {
     int32_t Cout, Cin, taps, T;
     float eps;
     int32_t row_block0, col_block0, reserved;
+    /* perm[t] (DEVICE array of T ints, or NULL = identity): the group ("slot") of the batched launch that the t-th call of the
+     * sequence belongs to.  inv_sigma / u_hist / v_hist are written at slot perm[t]; the module's u, v end at the LAST call's.
+     * Batched generator draws run the calls (draw d, step t) as groups [t][d] of one batch while the reference's call order is
+     * draw-major (and draw-reversed in the activation-checkpoint recompute, dgmr/dgmr.py:176). */
+    const int32_t* perm;
 } dgmr_sn_desc;
 int dgmr_spectral_sigma_seq_multi(const dgmr_sn_desc* descs_dev, int n, int total_row_blocks, int total_col_blocks, int max_cout,
                                   float* arena, void* stream);
@@ -203,12 +208,13 @@ int dgmr_spectral_sigma_seq_multi(const dgmr_sn_desc* descs_dev, int n, int tota
  * ---------------------------------------------------------------------------------------------- */
 /* sums[g][0][c] += sum_r x ; sums[g][1][c] += sum_r x^2   (double accumulators, zeroed by the caller). */
 int dgmr_bn_stats(const float* x, double* sums, int G, int64_t R, int C, void* stream);
-/* train: mean/var from sums -> a = gamma*rstd, b = beta - mean*a ; updates running stats once per group in order
- * (momentum, unbiased var) and num_batches_tracked += G.  eval (sums == NULL): a,b from running stats (G == 1).
- * save_mean/save_rstd: [G][C] for the backward. */
+/* train: mean/var from sums -> a = gamma*rstd, b = beta - mean*a ; updates running stats once per group (momentum, unbiased
+ * var) and num_batches_tracked += G.  The updates are applied in the order order[0], order[1], ... (DEVICE array of G group
+ * indices; NULL = 0..G-1): the order in which the reference called the module on those groups.
+ * eval (sums == NULL): a,b from running stats (G == 1).  save_mean/save_rstd: [G][C] for the backward. */
 int dgmr_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked, float* a, float* b, float* save_mean, float* save_rstd, int G,
-                     int64_t R, int C, float eps, float momentum, void* stream);
+                     int64_t R, int C, float eps, float momentum, const int32_t* order, void* stream);
 /* sums[g][0][c] = sum_r g ; sums[g][1][c] = sum_r g * xhat   with xhat = (x-mean)*rstd  (sums zeroed by caller). */
 int dgmr_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* rstd, double* sums, int G,
                        int64_t R, int C, void* stream);
@@ -235,11 +241,13 @@ int dgmr_pool_fwd(const float* x, const float* addend, float* y, int N, int D, i
 int dgmr_pool_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, int pd, float scale, void* stream);
 /* frames [B][T][C][H][W] (reference layout) -> channels-last space-to-depth tiles.
  * out[(b*F+f)][H/(2p)][W/(2p)][4C] with channel (c*4 + dy*2 + dx) (PixelUnshuffle(2) order), frame = idx[f],
- * p = pool ? 2 : 1 (AvgPool2d(2) first).  idx == NULL -> frames 0..F-1.  out_frame_major: 1 -> row (f*B+b). */
+ * p = pool ? 2 : 1 (AvgPool2d(2) first).  idx == NULL -> frames 0..F-1.  out_frame_major: 1 -> row (f*B+b).
+ * idx is [B / idx_group][F]: samples b .. b + idx_group - 1 share one row of frame indices (idx_group <= 0: one row for all) -
+ * several discriminator calls, each with its own random frame draw (discriminators.py:199), batched into one. */
 int dgmr_frames_s2d(const float* frames, const int32_t* idx, float* out, int B, int T, int C, int H, int W, int F, int pool,
-                    int frame_major, void* stream);
+                    int frame_major, int idx_group, void* stream);
 int dgmr_frames_s2d_bwd(const float* dout, const int32_t* idx, float* dframes /* accumulated */, int B, int T, int C, int H,
-                        int W, int F, int pool, int frame_major, void* stream);
+                        int W, int F, int pool, int frame_major, int idx_group, void* stream);
 /* channels-last [B][h][w][4C] -> frames[b][t][c][2h][2w] (PixelShuffle(2)) and its backward. */
 int dgmr_d2s_frames(const float* x, float* frames, int B, int T, int t, int C, int h, int w, void* stream);
 int dgmr_d2s_frames_bwd(const float* dframes, float* dx, int B, int T, int t, int C, int h, int w, void* stream);
@@ -273,9 +281,14 @@ int dgmr_axpby(const float* a, const float* b, float* y, float alpha, float beta
 /* dst[i][:] = src[:] for i < repeat, rows of n floats (n % 4 == 0): einops 'b c h w -> (repeat b) c h w' at b == 1
  * (generators.py:146-148) */
 int dgmr_repeat_rows(const float* src, float* dst, int64_t n, int repeat, void* stream);
-/* x is [groups][rows][n] (n % 4 == 0): out[g][:] = sum_r w[(g*rows + r) / rows_per_w] * x[g][r][:]; w == NULL: plain sums.
+/* x is [groups][rows][n] (n % 4 == 0): out[g][:] = sum_r w[((g*rows + r) / rows_per_w) * w_stride + col_block] * x[g][r][:] where
+ * col_block = column / (n / w_stride) (w_stride 1: one weight per row); w == NULL: plain sums.
  * Sums the per-sample gradients of a ConvGRU whose input is the same latent for every sample and step (generators.py:146-149). */
-int dgmr_group_rowsum(const float* x, const float* w, float* out, int groups, int rows, int64_t n, int rows_per_w, void* stream);
+int dgmr_group_rowsum(const float* x, const float* w, float* out, int groups, int rows, int64_t n, int rows_per_w, int w_stride,
+                      void* stream);
+/* dst[(k*repeat + r)][:] = src[k][:] for k < nblocks, r < repeat, rows of `block` floats (block % 4 == 0):
+ * einops 'k c h w -> (k repeat) c h w' - one latent map per generator draw handed to the `repeat` samples of that draw. */
+int dgmr_repeat_interleave(const float* src, float* dst, int64_t nblocks, int64_t block, int repeat, void* stream);
 /* dx = (x > 0) ? dy : 0 */
 int dgmr_relu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 int dgmr_fill(float* p, float value, int64_t n, void* stream);
@@ -309,10 +322,11 @@ int dgmr_linear1_bwd(const float* dy, const float* x, const float* w, const floa
 /* loss = mean(relu(1 - real)) + mean(relu(1 + gen)); d_real/d_gen = gradient * gscale */
 int dgmr_hinge_disc(const float* s_real, const float* s_gen, float* loss, float* d_real, float* d_gen, int n_real, int n_gen,
                     void* stream);
-/* loss = mult * sum_i |mean_k pred_k[i] - y[i]| * max(y[i]+1, cap);  pred_k = preds + k*pred_stride.
+/* loss = mult * sum_i |mean_k pred_k[i] - y[i]| * w[i];  pred_k = preds + k*pred_stride;  w = weights (explicit, [n]) or, when
+ * weights == NULL, the reference's default weight_fn max(y[i]+1, cap) (dgmr/dgmr.py:20-33) evaluated in the kernel.
  * acc: one double, zero on entry, left zero.  dweight[i] (optional) = sign(.)*w/K, the per-prediction gradient / mult. */
-int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_stride, const float* target, float cap, double* acc,
-                        float* loss, float mult, float* dweight, int64_t n, void* stream);
+int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_stride, const float* target, const float* weights, float cap,
+                        double* acc, float* loss, float mult, float* dweight, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Adam — torch.optim.Adam as constructed at dgmr/dgmr.py:292-300 (eps 1e-8, no weight decay, no amsgrad).

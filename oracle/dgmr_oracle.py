@@ -417,3 +417,38 @@ def training_step(sd: SD, images: torch.Tensor, future: torch.Tensor, hp: dict, 
     adam(gp, hp["gen_lr"])
     gen(images)  # the logging forward (dgmr.py:213): advances u/v, BN statistics and the CPU RNG
     return float(d_loss.detach()), float(g_loss.detach()), float(grid.detach())
+
+
+def validation_step(sd: SD, images: torch.Tensor, future: torch.Tensor, hp: dict, train: bool = False):
+    """`DGMR.validation_step` (dgmr/dgmr.py:220-290) on the state dict: two (generator forward + discriminator loss) rounds, the
+    generator loss over `generation_steps` draws, one more forward - no optimisation.  `train` is the module's mode (Lightning
+    validates in eval mode; in train mode the forwards advance u / v and the BatchNorm statistics in `sd`).  Returns
+    (d_loss, g_loss, grid_loss) as floats.  RNG consumption as in the reference: z per generator forward, frame indices per
+    discriminator call."""
+    T = hp["forecast_steps"]
+
+    def gen(x):
+        z = draw_latent(hp["latent_shape"])
+        return generator(sd, "generator.", x, z, T, train)
+
+    def disc(x):
+        idxs = torch.randint(low=0, high=x.size(1), size=(hp.get("num_spatial_frames", 8),))
+        return discriminator(sd, "discriminator.", x, idxs.tolist(), train)
+
+    with torch.no_grad():
+        real_sequence = torch.cat([images, future], dim=1)
+        b = images.shape[0]
+        for _ in range(2):
+            predictions = gen(images)
+            out = disc(torch.cat([real_sequence, torch.cat([images, predictions], dim=1)], dim=0))
+            s_real, s_gen = out[:b], out[b:]
+            d_loss = loss_hinge_disc(s_gen[:, 0:1], s_real[:, 0:1]) + loss_hinge_disc(s_gen[:, 1:2], s_real[:, 1:2])
+        predictions = [gen(images) for _ in range(hp["generation_steps"])]
+        grid = grid_cell_loss(torch.stack(predictions, dim=0).mean(dim=0), future, hp["precip_weight_cap"])
+        scores = []
+        for p_ in predictions:
+            out = disc(torch.cat([real_sequence, torch.cat([images, p_], dim=1)], dim=0))
+            scores.append(out[b:])
+        g_loss = loss_hinge_gen(torch.cat(scores, dim=0)) + hp["grid_lambda"] * grid
+        gen(images)
+    return float(d_loss), float(g_loss), float(grid)

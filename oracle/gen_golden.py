@@ -158,6 +158,8 @@ def main():
     td = TemporalDiscriminator(input_channels=1, num_layers=1)
     record("temporal_disc_L1", td, [torch.rand(2, 8, 1, 32, 32)], lambda m, x: m(x), grad_params=False)
     training_step_golden()
+    training_steps_adv_golden()
+    validation_step_golden()
 
 
 TS_KW = dict(forecast_steps=2, input_channels=1, output_shape=128, latent_channels=384, context_channels=192, generation_steps=2)
@@ -248,5 +250,107 @@ def training_step_golden():
     print("training_step golden: losses", rec["losses"].tolist(), bw)
 
 
+ADV_HP = dict(grid_lambda=0.0, beta1=0.5, disc_lr=2e-6, gen_lr=5e-6)
+ADV_STEPS = 3
+
+
+def training_steps_adv_golden():
+    """THREE consecutive `DGMR.training_step`s with a visible adversarial path (dgmr/dgmr.py:137-218).
+
+    In the default-hyper-parameter golden above, 20 * grid_cell_reg ~ 1e11 swamps loss_hinge_gen by ten orders of magnitude and the
+    second D pass saturates the hinge, so the chain  hinge_gen -> discriminator data gradient -> generator  is invisible there.
+    Here grid_lambda = 0 (the generator's gradient is purely adversarial and well conditioned: no sign() cotangent), the learning
+    rates are small enough that every hinge stays active over all six D updates, and beta1 = 0.5 with three steps exercises Adam's
+    first moment, both bias corrections (step 2..6 for D, 2..3 for G) and every weight-derived cache across optimiser updates.
+    """
+    from dgmr import DGMR
+
+    torch.manual_seed(42)
+    model = DGMR(**TS_KW, **ADV_HP)
+    keys0, cs0 = checksums(model.state_dict())
+    torch.manual_seed(43)
+    images, future = torch.rand(2, 4, 1, 128, 128), torch.rand(2, 2, 1, 128, 128)
+    logged = []
+    model.log_dict = lambda d, **k: logged.append([float(d["train/d_loss"]), float(d["train/g_loss"]), float(d["train/grid_loss"])])
+    bw = []
+    model.manual_backward = lambda loss: (bw.append(float(loss.detach())), loss.backward())
+    g_opt, d_opt = model.optimizers()
+    named = dict(model.named_parameters())
+    grads = {}
+    count = {"g": 0, "d": 0}
+
+    def wrap(opt, prefix, tag, want_call):
+        orig = opt.step
+
+        def step(*a, **k):
+            count[tag] += 1
+            if count[tag] == want_call:
+                for kk in GRAD_KEYS:
+                    if kk.startswith(prefix):
+                        p = named[kk[len("generator."):]] if kk.startswith("generator.") else named[kk]
+                        grads["grad." + kk] = p.grad.detach().clone().contiguous()
+            return orig(*a, **k)
+
+        opt.step = step
+
+    wrap(g_opt, "generator.", "g", ADV_STEPS)            # the generator's gradient at its LAST step
+    wrap(d_opt, "discriminator.", "d", 2 * ADV_STEPS)    # the discriminator's at its last (6th) step
+    torch.manual_seed(44)
+    for i in range(ADV_STEPS):
+        model.training_step((images, future), i)
+    sd1 = model.state_dict()
+    keys1, cs1 = checksums(sd1)
+    assert keys0 == keys1
+    rec = {"images": images, "future": future, "cs0": cs0, "cs1": cs1,
+           "losses": torch.tensor(logged, dtype=torch.float64),           # [step][d, g, grid]
+           "backward_losses": torch.tensor(bw, dtype=torch.float64)}      # per step: d pass 1, d pass 2, g
+    rec.update(grads)
+    for k in ["generator.sampler.conv_1x1.bias", "generator.sampler.bn.running_mean", "generator.sampler.bn.weight",
+              "generator.latent_stack.conv_3x3.parametrizations.weight.original",
+              "generator.conditioning_stack.d1.first_conv_3x3.parametrizations.weight.original",
+              "generator.sampler.convGRU4.cell.read_gate_conv.parametrizations.weight.0._u",
+              "generator.sampler.up_g4.first_conv_3x3.parametrizations.weight.0._v",
+              "generator.sampler.g1.bn1.running_var",
+              "discriminator.spatial_discriminator.fc.parametrizations.weight.original",
+              "discriminator.temporal_discriminator.d1.first_conv_3x3.parametrizations.weight.original",
+              "discriminator.spatial_discriminator.bn.running_var"]:
+        rec["post." + k] = sd1[k].detach().clone().contiguous()
+    hp = dict(TS_KW)
+    hp.update(ADV_HP)
+    save_file(rec, os.path.join(OUT, "training_steps_adv.safetensors"),
+              metadata={"keys": json.dumps(keys0), "kw": json.dumps(hp), "seeds": "[42, 43, 44]", "steps": str(ADV_STEPS)})
+    print("training_steps_adv golden: backward losses", bw)
+
+
+def validation_step_golden():
+    """`DGMR.validation_step` of the unmodified reference (dgmr/dgmr.py:220-290): the three logged losses, in eval mode under
+    no_grad (how Lightning's validation loop calls it) and in train mode (buffers then advance: their fingerprints are stored)."""
+    from dgmr import DGMR
+
+    rec = {}
+    for mode in ("eval", "train"):
+        torch.manual_seed(42)
+        model = DGMR(**TS_KW)
+        model.train(mode == "train")
+        torch.manual_seed(43)
+        images, future = torch.rand(2, 4, 1, 128, 128), torch.rand(2, 2, 1, 128, 128)
+        logged = {}
+        model.log_dict = lambda d, **k: logged.update({kk: float(v) for kk, v in d.items()})
+        torch.manual_seed(45)
+        with torch.no_grad():
+            model.validation_step((images, future), 0)
+        keys, cs = checksums(model.state_dict())
+        rec[f"{mode}.losses"] = torch.tensor([logged["val/d_loss"], logged["val/g_loss"], logged["val/grid_loss"]], dtype=torch.float64)
+        rec[f"{mode}.cs1"] = cs
+        print(f"validation_step golden ({mode}):", rec[f"{mode}.losses"].tolist())
+    rec["images"], rec["future"] = images, future
+    save_file(rec, os.path.join(OUT, "validation_step.safetensors"),
+              metadata={"keys": json.dumps(keys), "kw": json.dumps(TS_KW), "seeds": "[42, 43, 45]"})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:  # regenerate selected fixtures only, e.g. `python oracle/gen_golden.py training_steps_adv_golden`
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        main()

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdgmr_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 P = c_void_p  # every device pointer and the stream travel as void*
 
@@ -49,7 +49,7 @@ class SNDesc(Structure):
         ("w", P), ("gram", P), ("u", P), ("v", P),
         ("inv_sigma_off", c_int64), ("u_hist_off", c_int64), ("v_hist_off", c_int64), ("tmp_off", c_int64),
         ("Cout", c_int32), ("Cin", c_int32), ("taps", c_int32), ("T", c_int32), ("eps", c_float),
-        ("row_block0", c_int32), ("col_block0", c_int32), ("reserved", c_int32),
+        ("row_block0", c_int32), ("col_block0", c_int32), ("reserved", c_int32), ("perm", P),
     ]
 
 
@@ -68,15 +68,15 @@ SIGNATURES = {
     "dgmr_spectral_sigma_seq": [P, P, P, P, P, P, P, P, P, i, i, i, f, i, P],
     "dgmr_spectral_sigma_seq_multi": [P, i, i, i, i, P, P],
     "dgmr_bn_stats": [P, P, i, L, i, P],
-    "dgmr_bn_finalize": [P, P, P, P, P, P, P, P, P, P, i, L, i, f, f, P],
+    "dgmr_bn_finalize": [P, P, P, P, P, P, P, P, P, P, i, L, i, f, f, P, P],
     "dgmr_bn_bwd_reduce": [P, P, P, P, P, i, L, i, P],
     "dgmr_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, P, i, L, i, i, P],
     "dgmr_colsum": [P, P, P, L, i, i, P],
     "dgmr_affine": [P, P, P, P, i, L, i, i, P],
     "dgmr_pool_fwd": [P, P, P, i, i, i, i, i, i, f, P, P, P, i, P],
     "dgmr_pool_bwd": [P, P, i, i, i, i, i, i, f, P],
-    "dgmr_frames_s2d": [P, P, P, i, i, i, i, i, i, i, i, P],
-    "dgmr_frames_s2d_bwd": [P, P, P, i, i, i, i, i, i, i, i, P],
+    "dgmr_frames_s2d": [P, P, P, i, i, i, i, i, i, i, i, i, P],
+    "dgmr_frames_s2d_bwd": [P, P, P, i, i, i, i, i, i, i, i, i, P],
     "dgmr_d2s_frames": [P, P, i, i, i, i, i, i, P],
     "dgmr_d2s_frames_bwd": [P, P, i, i, i, i, i, i, P],
     "dgmr_permute_nt": [P, P, i, i, L, P],
@@ -87,7 +87,8 @@ SIGNATURES = {
     "dgmr_gru_blend_bwd": [P, P, P, P, P, P, P, L, P],
     "dgmr_axpby": [P, P, P, f, f, L, P],
     "dgmr_repeat_rows": [P, P, L, i, P],
-    "dgmr_group_rowsum": [P, P, P, i, i, L, i, P],
+    "dgmr_group_rowsum": [P, P, P, i, i, L, i, i, P],
+    "dgmr_repeat_interleave": [P, P, L, L, i, P],
     "dgmr_scale_by_dev": [P, P, f, P, L, P],
     "dgmr_relu_bwd": [P, P, P, L, P],
     "dgmr_fill": [P, f, L, P],
@@ -98,7 +99,7 @@ SIGNATURES = {
     "dgmr_linear1_fwd": [P, P, P, P, P, i, i, i, P],
     "dgmr_linear1_bwd": [P, P, P, P, P, P, P, i, i, i, P],
     "dgmr_hinge_disc": [P, P, P, P, P, i, i, P],
-    "dgmr_grid_cell_loss": [P, i, L, P, f, P, P, f, P, L, P],
+    "dgmr_grid_cell_loss": [P, i, L, P, P, f, P, P, f, P, L, P],
     "dgmr_adam": [P, P, P, P, L, f, f, f, f, i, P],
     "dgmr_split_weights": [P, P, L, i, i, i, P],
     "dgmr_set_precision": [i],

@@ -34,15 +34,16 @@ class GBlock(torch.nn.Module):
         self.first_conv_3x3 = conv2d(input_channels, input_channels, 3, eps=spectral_normalized_eps)
         self.last_conv_3x3 = conv2d(input_channels, output_channels, 3, eps=spectral_normalized_eps)
 
-    def forward(self, x: torch.Tensor, calls: int = 1) -> torch.Tensor:
-        """`calls` > 1: x holds `calls` consecutive calls of this block (forecast steps) as one time-major batch; every call
-        keeps its own BatchNorm batch statistics and spectral-norm sigma."""
+    def forward(self, x: torch.Tensor, calls: int = 1, layout=None) -> torch.Tensor:
+        """`calls` > 1: x holds `calls` consecutive calls of this block (forecast steps [x generator draws]) as one batch; every
+        call keeps its own BatchNorm batch statistics and spectral-norm sigma; `layout`: ops.CallLayout."""
+        kw = dict(calls=calls, layout=layout)
         if x.shape[1] != self.output_channels:
-            sc = self.conv_1x1(x, calls=calls)
+            sc = self.conv_1x1(x, **kw)
         else:
             sc = x
-        x2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x, calls), calls=calls)
-        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls), residual=sc, calls=calls)
+        x2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x, calls, layout), **kw)
+        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls, layout), residual=sc, **kw)
 
 
 class UpsampleGBlock(torch.nn.Module):
@@ -61,12 +62,13 @@ class UpsampleGBlock(torch.nn.Module):
         self.first_conv_3x3 = conv2d(input_channels, input_channels, 3, eps=spectral_normalized_eps)
         self.last_conv_3x3 = conv2d(input_channels, output_channels, 3, eps=spectral_normalized_eps)
 
-    def forward(self, x: torch.Tensor, calls: int = 1) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, calls: int = 1, layout=None) -> torch.Tensor:
         # shortcut: conv1x1(upsample(x)) == upsample(conv1x1(x)) exactly (a 1x1 conv acts per pixel), so it is evaluated on the
         # low-resolution map (4x fewer FLOPs and bytes) and upsampled inside the last conv's residual add
-        sc = self.conv_1x1(x, calls=calls)
-        x2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x, calls), upsample=True, calls=calls)
-        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls), residual=sc, residual_up=True, calls=calls)
+        kw = dict(calls=calls, layout=layout)
+        sc = self.conv_1x1(x, **kw)
+        x2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x, calls, layout), upsample=True, **kw)
+        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls, layout), residual=sc, residual_up=True, **kw)
 
 
 class DBlock(torch.nn.Module):
@@ -87,18 +89,20 @@ class DBlock(torch.nn.Module):
         self.last_conv_3x3 = conv2d(output_channels, output_channels, 3)
         self.relu = torch.nn.ReLU()
 
-    def forward(self, x: torch.Tensor, calls: int = 1) -> torch.Tensor:
-        """`calls` > 1: x is a frame-major batch of `calls` consecutive calls of this block (one spectral-norm sigma each)."""
+    def forward(self, x: torch.Tensor, calls: int = 1, layout=None) -> torch.Tensor:
+        """`calls` > 1: x is a batch of `calls` consecutive calls of this block (one spectral-norm sigma each); `layout`:
+        ops.CallLayout when the groups are not in call order."""
+        kw = dict(calls=calls, layout=layout)
         if self.input_channels != self.output_channels:
-            x1 = self.conv_1x1(x, calls=calls)
+            x1 = self.conv_1x1(x, **kw)
             if not self.keep_same_output:
                 x1 = ops.avg_pool_add(x1, None, self._pd)
         else:
             x1 = x
-        h = self.first_conv_3x3(x, pre_relu=self.first_relu, calls=calls)
+        h = self.first_conv_3x3(x, pre_relu=self.first_relu, **kw)
         if self.keep_same_output:
-            return self.last_conv_3x3(h, pre_relu=True, residual=x1, calls=calls)
-        h = self.last_conv_3x3(h, pre_relu=True, calls=calls)
+            return self.last_conv_3x3(h, pre_relu=True, residual=x1, **kw)
+        h = self.last_conv_3x3(h, pre_relu=True, **kw)
         return ops.avg_pool_add(h, x1, self._pd)
 
 
@@ -144,23 +148,32 @@ class ContextConditioningStack(torch.nn.Module, PyTorchModelHubMixin):
         self.conv4 = conv2d(oc * 2 * ic, oc * ic, 3)
         self.relu = torch.nn.ReLU()
 
-    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    def forward(self, x: torch.Tensor, draws: int = 1, reverse: bool = False):
+        """-> 4 conditioning states.  `draws` > 1 (train mode): the stack as the reference's `draws` consecutive generator forwards
+        would run it on the same frames - the data is identical but every forward has its own spectral-norm sigmas, so the outputs
+        differ per draw: [draws * B, C, h, w], draw-major.  `reverse`: the draws are visited last-to-first (checkpoint recompute)."""
         ops.require_hip(x, "context frames")
         b, steps = x.shape[0], x.shape[1]
         # PixelUnshuffle(2) of every frame, written channels-last and frame-major in one launch; the four context steps then
         # run through d1..d4 as ONE batch of `steps` calls (each call keeps its own spectral-norm sigma)
         s = ops.frames_s2d(x, None, pool=False, frame_major=True)
+        lay_blk = lay_mix = None
+        if draws > 1 or reverse:
+            if draws > 1:
+                s = ops.repeat_batch(s, draws)  # [draw][step][sample]
+            lay_blk = ops.CallLayout(draws, steps, time_major=False, reverse=reverse)
+            lay_mix = ops.CallLayout(draws, 1, time_major=False, reverse=reverse)
         scales = []
         for blk in (self.d1, self.d2, self.d3, self.d4):
-            s = blk(s, calls=steps)
+            s = blk(s, calls=steps * draws, layout=lay_blk)
             scales.append(s)
-        return tuple(self._mixing_layer(scales[lvl], conv, steps) for lvl, conv in
+        return tuple(self._mixing_layer(scales[lvl], conv, steps, draws, lay_mix) for lvl, conv in
                      enumerate((self.conv1, self.conv2, self.conv3, self.conv4)))
 
-    def _mixing_layer(self, inputs, conv_block, steps):
+    def _mixing_layer(self, inputs, conv_block, steps, draws: int = 1, layout=None):
         # "b t c h w -> b (c t) h w" (common.py:423) as a channel-interleaving copy, then relu(SN-conv3x3)
-        stacked = ops.time_to_channels(inputs, steps)
-        return conv_block(stacked, act_relu=True)
+        stacked = ops.time_to_channels(inputs, steps, draws)
+        return conv_block(stacked, act_relu=True, calls=draws, layout=layout)
 
 
 class LatentConditioningStack(torch.nn.Module, PyTorchModelHubMixin):
@@ -179,17 +192,22 @@ class LatentConditioningStack(torch.nn.Module, PyTorchModelHubMixin):
             self.att_block = AttentionLayer(input_channels=output_channels // 4, output_channels=output_channels // 4)
         self.l_block4 = LBlock(input_channels=output_channels // 4, output_channels=output_channels)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        # z is drawn on the CPU generator exactly as the reference does (common.py:481-483): fixed seeds give the
-        # same latent on both sides.  Only 8*h*w floats cross PCIe.
+    def draw(self, x: torch.Tensor) -> torch.Tensor:
+        """One latent draw [1, shape[0], h, w] on x's device.  z comes from the CPU generator exactly as in the reference
+        (common.py:481-483): fixed seeds give the same latent on both sides.  Only 8*h*w floats cross PCIe."""
         z = self.distribution.sample(self.shape)
-        z = torch.permute(z, (3, 0, 1, 2)).type_as(x)
-        return self.forward_latent(z)
+        return torch.permute(z, (3, 0, 1, 2)).type_as(x)
 
-    def forward_latent(self, z: torch.Tensor) -> torch.Tensor:
-        """The stack applied to a given draw z of shape [1, shape[0], h, w]."""
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.forward_latent(self.draw(x))
+
+    def forward_latent(self, z: torch.Tensor, reverse: bool = False) -> torch.Tensor:
+        """The stack applied to given draws z of shape [draws, shape[0], h, w]: one call of the reference's stack per draw (only
+        the first conv carries per-call state, its spectral-norm sigma); `reverse`: calls made last-draw-first."""
         ops.require_hip(z, "latent draw")
-        z = self.conv_3x3(z)
+        draws = z.shape[0]
+        lay = ops.CallLayout(draws, 1, time_major=False, reverse=reverse) if (draws > 1 or reverse) else None
+        z = self.conv_3x3(z, calls=draws, layout=lay)
         z = self.l_block1(z)
         z = self.l_block2(z)
         z = self.l_block3(z)

@@ -458,18 +458,21 @@ __global__ void flip_weights_kernel(const float* __restrict__ w, float* __restri
 }
 
 // g[i] = sum_grp scale[grp] * P_grp[i],  dot[grp] += <P_grp, w>   with P_grp = sum of the group's slabs.
-constexpr int WG_MAX_GROUPS = 32;
+// groups = calls of the module that one batched launch covers: forecast steps / frames (<= 32) or, with the generator draws of
+// a step batched as well, draws x steps (6 x 18 = 108 at the paper configuration)
+constexpr int WG_MAX_GROUPS = 128;
 // Partial element i = (co, tap, ci) of a [Cout][taps][cs] slab lands at j = (co*taps + tap)*ct + coff + ci of g / w
 // (cs == ct, coff == 0: j == i).
+template <int MAXG>
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int groups, size_t numel,
                                     const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ g,
                                     float* __restrict__ dot, int taps, int cs, int ct, int coff) {
-    __shared__ float red[WG_MAX_GROUPS][4];
+    __shared__ float red[MAXG][4];
     const int spg = nsplit / groups;
     const size_t rowlen = (size_t)taps * cs;
-    float d[WG_MAX_GROUPS];
+    float d[MAXG];  // one running <P_q, W> per group, in registers (MAXG = 128: ~3 waves per SIMD, still an HBM-bound stream)
 #pragma unroll
-    for (int q = 0; q < WG_MAX_GROUPS; ++q) d[q] = 0.f;
+    for (int q = 0; q < MAXG; ++q) d[q] = 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
         size_t j = i;
         if (cs != ct) {
@@ -480,7 +483,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
         const float wi = w ? w[j] : 0.f;
         float tot = 0.f;
 #pragma unroll
-        for (int q = 0; q < WG_MAX_GROUPS; ++q) {
+        for (int q = 0; q < MAXG; ++q) {
             if (q < groups) {
                 float s = 0.f;
                 for (int k = 0; k < spg; ++k) s += partial[(size_t)(q * spg + k) * numel + i];
@@ -493,7 +496,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
     if (dot) {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-        for (int q = 0; q < WG_MAX_GROUPS; ++q) {
+        for (int q = 0; q < MAXG; ++q) {
             if (q < groups) {
                 const float v = wave_sum(d[q]);
                 if (lane == 0) red[q][wid] = v;
@@ -825,8 +828,12 @@ extern "C" int dgmr_wgrad_reduce(const float* partial, int nsplit, int groups, i
                    groups, WG_MAX_GROUPS, nsplit);
     DGMR_CHECK_ARG(!dot || w, "dgmr_wgrad_reduce: dot needs w");
     const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 1024);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups, (size_t)numel,
-                       w, scale, g, dot, 1, 1, 1, 0);
+    if (groups <= 32)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups,
+                           (size_t)numel, w, scale, g, dot, 1, 1, 1, 0);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<WG_MAX_GROUPS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups,
+                           (size_t)numel, w, scale, g, dot, 1, 1, 1, 0);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
@@ -842,8 +849,12 @@ extern "C" int dgmr_wgrad_reduce_slice(const float* partial, int nsplit, int gro
     const int64_t numel = (int64_t)Cout * taps * cin_slice;
     const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 1024);
     // cs == ct would short-circuit the index map: force the mapped path whenever this is a true slice
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups, (size_t)numel,
-                       w, scale, g, dot, taps, cin_slice, cin_total, coff);
+    if (groups <= 32)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups,
+                           (size_t)numel, w, scale, g, dot, taps, cin_slice, cin_total, coff);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<WG_MAX_GROUPS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups,
+                           (size_t)numel, w, scale, g, dot, taps, cin_slice, cin_total, coff);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
@@ -858,7 +869,7 @@ extern "C" int dgmr_sn_wgrad_finalize(const float* g, float* gw, float* dot, con
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(sn_wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, s, g, gw, dot, inv_sigma, u, v, Cout, Cin, taps, groups,
                        accumulate);
-    if (dot) hipLaunchKernelGGL(zero_n_kernel, dim3(1), dim3(64), 0, s, dot, groups);
+    if (dot) hipLaunchKernelGGL(zero_n_kernel, dim3(1), dim3(WG_MAX_GROUPS), 0, s, dot, groups);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

@@ -30,6 +30,11 @@ __device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t* lds) {
 #endif
 }
 
+// An LDS-DMA is a pending LDS write on the issuing wave's VM counter and nothing else orders it: before the barrier that publishes a
+// stage to the other waves every wave drains its own DMAs EXPLICITLY (hipcc currently happens to emit this wait in front of
+// __syncthreads(), but the memory model does not oblige it to; tests/test_abi.py greps the disassembly for it).
+__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift, const int tiles_w,
                                                               const int tiles_hw, const int g_shift) {
@@ -221,7 +226,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
 
     dma_b(0, 0, 0);
     stage_a(0, 0);
-    __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
+    dma_drain();
+    __syncthreads();
     const int ngroups = nchunks * KD;  // groups of nine taps: (chunk, kd)
 #pragma unroll 1
     for (int g = 0; g < ngroups; ++g) {
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
                 __syncthreads();  // every wave is done with this group's halo
                 stage_a(nchunk, nkd);
             }
+            dma_drain();  // the stage written under this tap's MFMAs is read by every wave after the barrier
             __syncthreads();
         }
     }

@@ -298,10 +298,12 @@ __global__ __launch_bounds__(1024) void sn_chain_multi_kernel(const dgmr_sn_desc
             y2 += red[16 + k];
         }
         const float dd = fmaxf(sqrtf(fmaxf(n2, 0.f)), eps);
-        for (int i = threadIdx.x; i < Cout; i += blockDim.x) u_hist[(size_t)t * Cout + i] = ucur[i];
+        // call t of the sequence belongs to group `slot` of the batched launch that consumes it (perm == NULL: slot == t)
+        const int slot = d.perm ? d.perm[t] : t;
+        for (int i = threadIdx.x; i < Cout; i += blockDim.x) u_hist[(size_t)slot * Cout + i] = ucur[i];
         if (threadIdx.x == 0) {
             dnorm[t] = dd;
-            inv_sigma[t] = dd / n2;
+            inv_sigma[slot] = dd / n2;
         }
         __syncthreads();
         if (t + 1 < T) {
@@ -324,26 +326,36 @@ __global__ void sn_cols_multi_kernel(const dgmr_sn_desc* __restrict__ descs, int
     float* v_hist = arena + d.v_hist_off;
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int k = (blockIdx.x - d.col_block0) * 64 + c;
-    float acc[SN_TMAX];
+    // sequences longer than SN_TMAX calls (batched generator draws: draws x forecast steps) go in chunks; W is re-read from L2
+    for (int tc = 0; tc < T; tc += SN_TMAX) {
+        const int Tc = min(SN_TMAX, T - tc);
+        float acc[SN_TMAX];
+        int slot[SN_TMAX];
 #pragma unroll
-    for (int t = 0; t < SN_TMAX; ++t) acc[t] = 0.f;
-    if (k < K)
-        for (int i = rg; i < Cout; i += 4) {
-            const float wv = d.w[(size_t)i * K + k];
-#pragma unroll
-            for (int t = 0; t < SN_TMAX; ++t)
-                if (t < T) acc[t] = fmaf(wv, u_hist[(size_t)t * Cout + i], acc[t]);
+        for (int t = 0; t < SN_TMAX; ++t) {
+            acc[t] = 0.f;
+            slot[t] = t < Tc ? (d.perm ? d.perm[tc + t] : tc + t) : 0;
         }
+        if (k < K)
+            for (int i = rg; i < Cout; i += 4) {
+                const float wv = d.w[(size_t)i * K + k];
 #pragma unroll
-    for (int t = 0; t < SN_TMAX; ++t) part[rg][t][c] = acc[t];
-    __syncthreads();
-    if (k < K) {
-        const int tp = k / d.Cin, ci = k - tp * d.Cin;
-        const size_t j = (size_t)ci * d.taps + tp;
-        for (int t = rg; t < T; t += 4) {
-            const float s = (part[0][t][c] + part[1][t][c] + part[2][t][c] + part[3][t][c]) / dnorm[t];
-            v_hist[(size_t)t * K + j] = s;
-            if (t == T - 1) d.v[j] = s;
+                for (int t = 0; t < SN_TMAX; ++t)
+                    if (t < Tc) acc[t] = fmaf(wv, u_hist[(size_t)slot[t] * Cout + i], acc[t]);
+            }
+        __syncthreads();  // the previous chunk's sums have been consumed
+#pragma unroll
+        for (int t = 0; t < SN_TMAX; ++t) part[rg][t][c] = acc[t];
+        __syncthreads();
+        if (k < K) {
+            const int tp = k / d.Cin, ci = k - tp * d.Cin;
+            const size_t j = (size_t)ci * d.taps + tp;
+            for (int t = rg; t < Tc; t += 4) {
+                const float sv = (part[0][t][c] + part[1][t][c] + part[2][t][c] + part[3][t][c]) / dnorm[tc + t];
+                const int sl = d.perm ? d.perm[tc + t] : tc + t;
+                v_hist[(size_t)sl * K + j] = sv;
+                if (tc + t == T - 1) d.v[j] = sv;
+            }
         }
     }
 }
@@ -422,17 +434,27 @@ __global__ void sum_rows_kernel(const f32x4* __restrict__ x, f32x4* __restrict__
 
 // out[g][c] = sum_r w[(g*R + r) / rows_per_w] * x[g][r][c]  (w == nullptr: plain sums); blockIdx.y = g, one thread per 4 columns
 __global__ void group_rowsum_kernel(const f32x4* __restrict__ x, const float* __restrict__ w, f32x4* __restrict__ out, int R, int64_t C4,
-                                    int rows_per_w) {
+                                    int rows_per_w, int w_stride) {
     const int g = blockIdx.y;
     x += (int64_t)g * R * C4;
     out += (int64_t)g * C4;
+    const int64_t wblock = C4 / w_stride;  // columns (in float4) that share one weight column
     GRID_STRIDE(c, C4) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        const int64_t wc = w_stride > 1 ? c / wblock : 0;
         for (int r = 0; r < R; ++r) {
-            const float f = w ? w[((int64_t)g * R + r) / rows_per_w] : 1.f;
+            const float f = w ? w[(((int64_t)g * R + r) / rows_per_w) * w_stride + wc] : 1.f;
             s += f * x[(int64_t)r * C4 + c];
         }
         out[c] = s;
+    }
+}
+
+// dst[(k*repeat + r)][:] = src[k][:]: every block of C4 float4 repeated `repeat` times in place ('k ... -> (k repeat) ...')
+__global__ void repeat_interleave_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t C4, int repeat, int64_t total4) {
+    GRID_STRIDE(i, total4) {
+        const int64_t row = i / C4;
+        dst[i] = src[(row / repeat) * C4 + (i - row * C4)];
     }
 }
 
@@ -448,7 +470,8 @@ __global__ void colsum_finish_kernel(const double* __restrict__ sums, float* __r
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
                                    float* __restrict__ a, float* __restrict__ b, float* __restrict__ save_mean,
-                                   float* __restrict__ save_rstd, int G, int64_t R, int C, float eps, float momentum) {
+                                   float* __restrict__ save_rstd, int G, int64_t R, int C, float eps, float momentum,
+                                   const int32_t* __restrict__ order) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt && sums) nbt[0] += G;
     if (c >= C) return;
@@ -464,7 +487,9 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float*
         return;
     }
     float rmc = rm[c], rvc = rv[c];
-    for (int g = 0; g < G; ++g) {
+    for (int q = 0; q < G; ++q) {
+        // the q-th call of the module (the order in which the reference updates its running statistics) is group order[q] of the batch
+        const int g = order ? order[q] : q;
         const double mean = sums[((size_t)g * 2 + 0) * C + c] / (double)R;
         double var = sums[((size_t)g * 2 + 1) * C + c] / (double)R - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -601,7 +626,7 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dy, float* __restrict_
 }
 
 __global__ void frames_s2d_kernel(const float* __restrict__ fr, const int32_t* __restrict__ idx, float* __restrict__ out, int B,
-                                  int T, int C, int H, int W, int F, int p, int frame_major) {
+                                  int T, int C, int H, int W, int F, int p, int frame_major, int idx_group) {
     const int Ho = H / (2 * p), Wo = W / (2 * p), Co = 4 * C;
     const int64_t total = (int64_t)B * F * Ho * Wo * Co;
     const float inv = 1.f / (float)(p * p);
@@ -621,7 +646,7 @@ __global__ void frames_s2d_kernel(const float* __restrict__ fr, const int32_t* _
             b = t / F;
         }
         const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
-        const int tf = idx ? idx[f] : f;
+        const int tf = idx ? idx[(b / idx_group) * F + f] : f;
         const float* src = fr + (((size_t)b * T + tf) * C + c) * H * W;
         float s = 0.f;
         for (int py = 0; py < p; ++py)
@@ -631,7 +656,7 @@ __global__ void frames_s2d_kernel(const float* __restrict__ fr, const int32_t* _
 }
 
 __global__ void frames_s2d_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx, float* __restrict__ dfr,
-                                      int B, int T, int C, int H, int W, int F, int p, int frame_major) {
+                                      int B, int T, int C, int H, int W, int F, int p, int frame_major, int idx_group) {
     const int Ho = H / (2 * p), Wo = W / (2 * p), Co = 4 * C;
     const int64_t total = (int64_t)B * F * Ho * Wo * Co;
     const float inv = 1.f / (float)(p * p);
@@ -651,7 +676,7 @@ __global__ void frames_s2d_bwd_kernel(const float* __restrict__ dout, const int3
             b = t / F;
         }
         const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
-        const int tf = idx ? idx[f] : f;
+        const int tf = idx ? idx[(b / idx_group) * F + f] : f;
         float* dst = dfr + (((size_t)b * T + tf) * C + c) * H * W;
         const float g = dout[i] * inv;
         for (int py = 0; py < p; ++py)
@@ -953,8 +978,9 @@ __global__ void hinge_disc_kernel(const float* __restrict__ s_real, const float*
     if (threadIdx.x == 0) loss[0] = a / n_real + b / n_gen;
 }
 
-__global__ void grid_cell_kernel(const float* __restrict__ preds, int K, int64_t stride, const float* __restrict__ target, float cap,
-                                 double* __restrict__ acc, float* __restrict__ dweight, int64_t n) {
+__global__ void grid_cell_kernel(const float* __restrict__ preds, int K, int64_t stride, const float* __restrict__ target,
+                                 const float* __restrict__ weights, float cap, double* __restrict__ acc, float* __restrict__ dweight,
+                                 int64_t n) {
     __shared__ float red[32];
     float s = 0.f;
     const float invK = 1.f / (float)K;
@@ -963,7 +989,7 @@ __global__ void grid_cell_kernel(const float* __restrict__ preds, int K, int64_t
         for (int k = 0; k < K; ++k) m += preds[(size_t)k * stride + i];
         m *= invK;
         const float y = target[i];
-        const float w = fmaxf(y + 1.f, cap);
+        const float w = weights ? weights[i] : fmaxf(y + 1.f, cap);
         const float d = (m - y) * w;
         s += fabsf(d);
         if (dweight) dweight[i] = (d > 0.f ? w : (d < 0.f ? -w : 0.f)) * invK;
@@ -1063,11 +1089,11 @@ extern "C" int dgmr_bn_stats(const float* x, double* sums, int G, int64_t R, int
 
 extern "C" int dgmr_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                 int64_t* num_batches_tracked, float* a, float* b, float* save_mean, float* save_rstd, int G,
-                                int64_t R, int C, float eps, float momentum, void* stream) {
+                                int64_t R, int C, float eps, float momentum, const int32_t* order, void* stream) {
     DGMR_CHECK_ARG(running_mean && running_var && a && b, "dgmr_bn_finalize: null pointer");
     DGMR_CHECK_ARG(sums || G == 1, "dgmr_bn_finalize: eval mode needs G == 1");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, sums, gamma, beta, running_mean, running_var,
-                       num_batches_tracked, a, b, save_mean, save_rstd, G, R, C, eps, momentum);
+                       num_batches_tracked, a, b, save_mean, save_rstd, G, R, C, eps, momentum, order);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
@@ -1108,11 +1134,23 @@ extern "C" int dgmr_colsum(const float* x, float* out, double* tmp, int64_t R, i
 }
 
 extern "C" int dgmr_group_rowsum(const float* x, const float* w, float* out, int groups, int rows, int64_t n, int rows_per_w,
-                                 void* stream) {
-    DGMR_CHECK_ARG(x && out && groups >= 1 && rows >= 1 && n > 0 && n % 4 == 0 && rows_per_w >= 1,
-                   "dgmr_group_rowsum: groups=%d rows=%d n=%lld (multiple of 4) rows_per_w=%d", groups, rows, (long long)n, rows_per_w);
+                                 int w_stride, void* stream) {
+    if (w_stride < 1) w_stride = 1;
+    DGMR_CHECK_ARG(x && out && groups >= 1 && rows >= 1 && n > 0 && n % 4 == 0 && rows_per_w >= 1 && (n / 4) % w_stride == 0,
+                   "dgmr_group_rowsum: groups=%d rows=%d n=%lld (multiple of 4) rows_per_w=%d w_stride=%d", groups, rows, (long long)n,
+                   rows_per_w, w_stride);
     hipLaunchKernelGGL(group_rowsum_kernel, dim3(ew_blocks(n / 4), groups), dim3(EW_THREADS), 0, ST, (const f32x4*)x, w, (f32x4*)out,
-                       rows, (int64_t)(n / 4), rows_per_w);
+                       rows, (int64_t)(n / 4), rows_per_w, w_stride);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_repeat_interleave(const float* src, float* dst, int64_t nblocks, int64_t block, int repeat, void* stream) {
+    DGMR_CHECK_ARG(src && dst && nblocks > 0 && block > 0 && block % 4 == 0 && repeat >= 1,
+                   "dgmr_repeat_interleave: nblocks=%lld block=%lld (multiple of 4) repeat=%d", (long long)nblocks, (long long)block, repeat);
+    const int64_t total4 = nblocks * repeat * (block / 4);
+    hipLaunchKernelGGL(repeat_interleave_kernel, dim3(ew_blocks(total4)), dim3(EW_THREADS), 0, ST, (const f32x4*)src, (f32x4*)dst,
+                       (int64_t)(block / 4), repeat, total4);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
@@ -1158,24 +1196,26 @@ extern "C" int dgmr_pool_bwd(const float* dy, float* dx, int N, int D, int H, in
 }
 
 extern "C" int dgmr_frames_s2d(const float* frames, const int32_t* idx, float* out, int B, int T, int C, int H, int W, int F,
-                               int pool, int frame_major, void* stream) {
+                               int pool, int frame_major, int idx_group, void* stream) {
+    if (idx_group < 1) idx_group = B;
     DGMR_CHECK_ARG(frames && out, "dgmr_frames_s2d: null pointer");
     const int p = pool ? 2 : 1;
     DGMR_CHECK_ARG(H % (2 * p) == 0 && W % (2 * p) == 0, "dgmr_frames_s2d: H=%d W=%d not divisible by %d", H, W, 2 * p);
     const int64_t total = (int64_t)B * F * (H / (2 * p)) * (W / (2 * p)) * 4 * C;
     hipLaunchKernelGGL(frames_s2d_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, frames, idx, out, B, T, C, H, W, F, p,
-                       frame_major);
+                       frame_major, idx_group);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int dgmr_frames_s2d_bwd(const float* dout, const int32_t* idx, float* dframes, int B, int T, int C, int H, int W, int F,
-                                   int pool, int frame_major, void* stream) {
+                                   int pool, int frame_major, int idx_group, void* stream) {
+    if (idx_group < 1) idx_group = B;
     DGMR_CHECK_ARG(dout && dframes, "dgmr_frames_s2d_bwd: null pointer");
     const int p = pool ? 2 : 1;
     const int64_t total = (int64_t)B * F * (H / (2 * p)) * (W / (2 * p)) * 4 * C;
     hipLaunchKernelGGL(frames_s2d_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dout, idx, dframes, B, T, C, H, W, F,
-                       p, frame_major);
+                       p, frame_major, idx_group);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
@@ -1331,11 +1371,11 @@ extern "C" int dgmr_hinge_disc(const float* s_real, const float* s_gen, float* l
     return 0;
 }
 
-extern "C" int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_stride, const float* target, float cap, double* acc,
-                                   float* loss, float mult, float* dweight, int64_t n, void* stream) {
+extern "C" int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_stride, const float* target, const float* weights, float cap,
+                                   double* acc, float* loss, float mult, float* dweight, int64_t n, void* stream) {
     DGMR_CHECK_ARG(preds && target && acc && loss && K > 0 && n > 0, "dgmr_grid_cell_loss: bad args");
-    hipLaunchKernelGGL(grid_cell_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, preds, K, pred_stride, target, cap, acc,
-                       dweight, n);
+    hipLaunchKernelGGL(grid_cell_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, preds, K, pred_stride, target, weights, cap,
+                       acc, dweight, n);
     hipLaunchKernelGGL(grid_cell_finish_kernel, dim3(1), dim3(1), 0, ST, acc, loss, mult);
     DGMR_CHECK_LAUNCH();
     return 0;

@@ -24,10 +24,6 @@ import torch
 import torch.distributed as dist
 
 
-def _numel_storage(p: torch.Tensor) -> int:
-    return p.numel()
-
-
 class FlatGrads:
     """One flat gradient buffer for a list of parameters; ``p.grad`` become views with p's own strides."""
 
@@ -113,3 +109,8 @@ class GradSync:
         for fg in (self.gen, self.disc):
             for p in fg.params:
                 dist.broadcast(p.data, src=src, group=self.pg)
+        # p.data writes bump neither p._version nor the optimiser's epoch, which key the W W^T / flipped / split-plane caches:
+        # any forward that ran before this broadcast (warm-up, smoke, eval) must not leave stale copies behind on ranks != src
+        from . import ops
+
+        ops.bump_weights_epoch()

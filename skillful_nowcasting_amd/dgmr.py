@@ -50,8 +50,40 @@ except Exception:  # pragma: no cover - depends on the environment
 
 
 def weight_fn(y, precip_weight_cap=24.0):
-    """w(y) = max(y + 1, cap) (dgmr/dgmr.py:20-33); applied inside the grid-cell loss kernel."""
+    """w(y) = max(y + 1, cap) (dgmr/dgmr.py:20-33); GridCellLoss evaluates this one inside its kernel."""
     return torch.max(y + 1, torch.tensor(precip_weight_cap, device=y.device))
+
+
+weight_fn.fused_in_kernel = True  # losses.GridCellLoss: any OTHER weight function is called on the targets instead
+
+
+class _CheckpointedDraws(torch.autograd.Function):
+    """Activation checkpointing of the generator pass's `generation_steps` forwards (dgmr/dgmr.py:176), batched.
+
+    forward: the draws run under no_grad (nothing is kept but the inputs and the latent draws).  backward: the reference's
+    `checkpoint(self.forward, images, use_reentrant=False)` re-runs each forward when autograd first needs one of its saved tensors
+    - in REVERSE draw order, because the engine processes the latest-created graph first - and back-propagates through the
+    recomputed graph.  The recompute advances every spectral-norm u / v and BatchNorm running statistic a second time and its
+    (different) sigmas and batch statistics are the ones the gradients see; torch.utils.checkpoint restores the CPU
+    RNG state for the recompute, i.e. the same latents are used and the global RNG stream is left untouched.  Here: ONE batched
+    recompute whose call sequence is assigned last-draw-first (`reverse=True`), then one backward through it.  Parameter
+    gradients are accumulated by the kernels straight into `param.grad`; `anchor` (any generator parameter) only ties this node
+    to the graph, `images` receives no gradient (nothing reads it)."""
+
+    @staticmethod
+    def forward(ctx, anchor, images, zs, generator, draws):
+        ctx.generator, ctx.draws = generator, draws
+        ctx.save_for_backward(images, zs)
+        with torch.no_grad():
+            return generator.forward_draws(images, draws, zs=zs)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        images, zs = ctx.saved_tensors
+        with torch.enable_grad():
+            out = ctx.generator.forward_draws(images.detach(), ctx.draws, reverse=True, zs=zs)
+            torch.autograd.backward(out, grad_out)
+        return None, None, None, None, None
 
 
 class DGMR(
@@ -103,10 +135,19 @@ class DGMR(
         return self.generator(x)
 
     # ------------------------------------------------------------------------------------------
-    def _generate(self, images):
+    def _generate(self, images, draws: int, grad: bool):
+        """`draws` generator forwards of the reference on `images` as one batched launch set -> [draws * B, T, C, H, W].
+
+        grad=False (discriminator passes, logging): no graph.  grad=True (generator pass): with strict reference semantics the
+        forwards are activation-checkpointed like the reference's (dgmr/dgmr.py:176), see _CheckpointedDraws."""
+        if not grad:
+            with torch.no_grad():
+                return self.generator.forward_draws(images, draws)
         if self.strict_reference_semantics:
-            return checkpoint(self.forward, images, use_reentrant=False)
-        return self.forward(images)
+            zs = torch.cat([self.latent_stack.draw(images) for _ in range(draws)], dim=0)
+            anchor = next(p for p in self.generator.parameters() if p.requires_grad)
+            return _CheckpointedDraws.apply(anchor, images, zs, self.generator, draws)
+        return self.generator.forward_draws(images, draws)
 
     def _disc_losses(self, images, future_images, predictions):
         generated_sequence = torch.cat([images, predictions], dim=1)
@@ -120,16 +161,20 @@ class DGMR(
                          loss_hinge_disc(score_generated_temporal, score_real_temporal))
 
     def _gen_losses(self, images, future_images, predictions):
-        grid_cell_reg = self.grid_regularizer.forward_stacked(torch.stack(predictions, dim=0), future_images)
+        """`predictions`: [K * B, T, C, H, W], the K generator draws stacked draw-major.  The reference scores every draw with its
+        own discriminator call on cat(real, draw) (dgmr/dgmr.py:186-193); the K calls run as one batch here, each keeping its own
+        frame draw, spectral-norm sigmas and BatchNorm1d statistics (the real half of every call only feeds those statistics)."""
+        b = images.shape[0]
+        k = predictions.shape[0] // b
+        preds = predictions.view(k, b, *predictions.shape[1:])
+        grid_cell_reg = self.grid_regularizer.forward_stacked(preds, future_images)
         real_sequence = torch.cat([images, future_images], dim=1)
-        generated_scores = []
-        for x in predictions:
-            g_seq = torch.cat([images, x], dim=1)
-            concatenated_inputs = torch.cat([real_sequence, g_seq], dim=0)
-            concatenated_outputs = self.discriminator(concatenated_inputs)
-            score_real, score_generated = torch.split(concatenated_outputs, [real_sequence.shape[0], g_seq.shape[0]], dim=0)
-            generated_scores.append(score_generated)
-        generator_disc_loss = loss_hinge_gen(torch.cat(generated_scores, dim=0))
+        g_seq = torch.cat([images.unsqueeze(0).expand(k, *images.shape), preds], dim=2)  # [K, B, 4+T, C, H, W]
+        concatenated_inputs = torch.cat([real_sequence.unsqueeze(0).expand(k, *real_sequence.shape).unsqueeze(1), g_seq.unsqueeze(1)],
+                                        dim=1)  # [K, (real, generated), B, ...]
+        concatenated_outputs = self.discriminator(concatenated_inputs.reshape(2 * k * b, *real_sequence.shape[1:]), calls=k)
+        score_generated = concatenated_outputs.view(k, 2, b, *concatenated_outputs.shape[1:])[:, 1]
+        generator_disc_loss = loss_hinge_gen(score_generated.reshape(k * b, *concatenated_outputs.shape[1:]))
         generator_loss = ops.axpby(generator_disc_loss, grid_cell_reg, 1.0, self.grid_lambda)
         return generator_loss, grid_cell_reg
 
@@ -141,6 +186,7 @@ class DGMR(
         self.global_iteration += 1
         g_opt, d_opt = self.optimizers()
         strict = self.strict_reference_semantics
+        b = images.shape[0]
         if self.grad_sync is not None:
             self.grad_sync.broadcast_buffers()
         ##########################
@@ -152,17 +198,13 @@ class DGMR(
                 # reference: predictions = checkpoint(self.forward, images), NOT detached (dgmr.py:150-157).  Its D-loss
                 # backward therefore (a) re-runs the generator forward once (checkpoint recompute, same RNG state -> same z),
                 # which advances u/v and the BatchNorm running statistics a second time, and (b) back-propagates into generator
-                # gradients that g_opt.zero_grad() (dgmr.py:199) discards.  (a) is replayed for its side effects, (b) is dead.
-                rng0 = torch.get_rng_state()
+                # gradients that g_opt.zero_grad() (dgmr.py:199) discards.  (a) is replayed for its side effects - as the second
+                # of two "draws" that share one z, in the same batched launches as the first - and (b) is dead.
+                z = self.latent_stack.draw(images)
                 with torch.no_grad():
-                    predictions = self.forward(images)
-                    rng1 = torch.get_rng_state()
-                    torch.set_rng_state(rng0)
-                    self.forward(images)
-                    torch.set_rng_state(rng1)
+                    predictions = self.generator.forward_draws(images, 2, zs=torch.cat([z, z], dim=0))[:b]
             else:
-                with torch.no_grad():
-                    predictions = self.forward(images)
+                predictions = self._generate(images, 1, grad=False)
             discriminator_loss = self._disc_losses(images, future_images, predictions)
             self.manual_backward(discriminator_loss)
             if self.grad_sync is not None:
@@ -171,41 +213,56 @@ class DGMR(
         ######################
         # Optimize Generator #
         ######################
-        predictions = [self._generate(images) for _ in range(self.generation_steps)]
+        predictions = self._generate(images, self.generation_steps, grad=True)
         # D's parameter gradients from this pass are never read (the next d_opt.zero_grad() clears them): not computed
-        for p in self.discriminator.parameters():
+        d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
+        for p in d_params:
             p.requires_grad_(False)
-        generator_loss, grid_cell_reg = self._gen_losses(images, future_images, predictions)
-        g_opt.zero_grad()
-        self.manual_backward(generator_loss)
-        if self.grad_sync is not None:
-            self.grad_sync.sync("g")
-        g_opt.step()
-        for p in self.discriminator.parameters():
-            p.requires_grad_(True)
+        try:
+            generator_loss, grid_cell_reg = self._gen_losses(images, future_images, predictions)
+            g_opt.zero_grad()
+            self.manual_backward(generator_loss)
+            if self.grad_sync is not None:
+                self.grad_sync.sync("g")
+            g_opt.step()
+        finally:  # an exception (OOM, a refused launch) must not leave the discriminator frozen for a caller that retries
+            for p in d_params:
+                p.requires_grad_(True)
         self.log_dict({"train/d_loss": discriminator_loss, "train/g_loss": generator_loss, "train/grid_loss": grid_cell_reg},
                       prog_bar=True)
         if strict or self.visualize:
-            with torch.no_grad():  # the logging forward (dgmr.py:213): only its side effects on buffers / RNG matter
-                generated_images = self(images)
+            # the logging forward (dgmr.py:213): only its side effects on buffers / RNG matter
+            generated_images = self._generate(images, 1, grad=False)
             if self.visualize:
                 self.visualize_step(images, future_images, generated_images, self.global_iteration, step="train")
         return {"d_loss": discriminator_loss.detach(), "g_loss": generator_loss.detach(), "grid_loss": grid_cell_reg.detach()}
 
     def validation_step(self, batch, batch_idx):
-        """dgmr/dgmr.py:220-290: the same losses without optimisation."""
+        """dgmr/dgmr.py:220-290: the same losses without optimisation.  Runs under no_grad (Lightning's validation loop does the
+        same); train / eval mode is the caller's, exactly as with the reference module."""
         images, future_images = batch
         images = images.float()
         future_images = future_images.float()
-        for _ in range(2):
-            predictions = self(images)
-            discriminator_loss = self._disc_losses(images, future_images, predictions)
-        predictions = [self(images) for _ in range(self.generation_steps)]
-        generator_loss, grid_cell_reg = self._gen_losses(images, future_images, predictions)
-        self.log_dict({"val/d_loss": discriminator_loss, "val/g_loss": generator_loss, "val/grid_loss": grid_cell_reg}, prog_bar=True)
-        generated_images = self(images)
+        with torch.no_grad():
+            for _ in range(2):
+                predictions = self._generate(images, 1, grad=False)
+                discriminator_loss = self._disc_losses(images, future_images, predictions)
+            predictions = self._generate(images, self.generation_steps, grad=False)
+            generator_loss, grid_cell_reg = self._gen_losses(images, future_images, predictions)
+            self.log_dict({"val/d_loss": discriminator_loss, "val/g_loss": generator_loss, "val/grid_loss": grid_cell_reg},
+                          prog_bar=True)
+            generated_images = self._generate(images, 1, grad=False)
         if self.visualize:
             self.visualize_step(images, future_images, generated_images, self.global_iteration, step="val")
+        return {"d_loss": discriminator_loss.detach(), "g_loss": generator_loss.detach(), "grid_loss": grid_cell_reg.detach()}
+
+    def sample(self, images, num_samples: int = None):
+        """Ensemble nowcast: `num_samples` forecasts per input sequence -> [num_samples, B, T, C, H, W] (the reference's usage is a
+        Python loop of `model(x)` calls, README.md:73-91; here the context stack runs once and the sampler on all draws at once).
+        Call under model.eval() for inference; in train mode it is `num_samples` consecutive train-mode forwards."""
+        k = self.num_samples if num_samples is None else num_samples
+        out = self._generate(images.float(), k, grad=False)
+        return out.view(k, images.shape[0], *out.shape[1:])
 
     def attach_data_parallel(self, process_group=None, chunk_mb: int = 64):
         """One-process-per-GPU data parallelism: flat gradient buffers + RCCL all-reduce after each backward."""

@@ -16,15 +16,25 @@ class Discriminator(torch.nn.Module, PyTorchModelHubMixin):
                                                           conv_type=conv_type)
         self.temporal_discriminator = TemporalDiscriminator(input_channels=input_channels, conv_type=conv_type)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        with SNScope(self, tuple(x.shape)):  # all spectral-norm iterations of both discriminators up front
-            spatial_loss = self.spatial_discriminator(x)
-            temporal_loss = self.temporal_discriminator(x)
+    def forward(self, x: torch.Tensor, calls: int = 1) -> torch.Tensor:
+        """`calls` > 1: x stacks the inputs of `calls` consecutive calls of the reference's discriminator ([calls * N, T, C, H, W]:
+        the generator pass scores each of its draws with a separate call, dgmr/dgmr.py:186-193).  Each call keeps its own random
+        frame draw, spectral-norm sigmas and BatchNorm1d batch statistics, all advanced in call order."""
+        if x.shape[0] % calls:
+            raise RuntimeError(f"discriminator: batch {x.shape[0]} is not divisible into {calls} calls")
+        with SNScope(self, (tuple(x.shape), calls)):  # all spectral-norm iterations of both discriminators up front
+            spatial_loss = self.spatial_discriminator(x, calls=calls)
+            temporal_loss = self.temporal_discriminator(x, calls=calls)
         return torch.cat([spatial_loss, temporal_loss], dim=1)
 
 
 def _sum_heads(reps, frames):
     return ops.sum_groups(reps, frames).unsqueeze(1)  # [frames*N, 1] -> [N, 1, 1]
+
+
+def _frame_layout(calls: int, frames: int):
+    """Groups of a frame-major batch that stacks `calls` discriminator calls: [frame][call]; reference order: call-major."""
+    return ops.CallLayout(calls, frames, time_major=True) if calls > 1 else None
 
 
 class TemporalDiscriminator(torch.nn.Module, PyTorchModelHubMixin):
@@ -48,22 +58,24 @@ class TemporalDiscriminator(torch.nn.Module, PyTorchModelHubMixin):
         self.relu = torch.nn.ReLU()
         self.bn = BatchNorm1d(2 * internal_chn * input_channels)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, calls: int = 1) -> torch.Tensor:
         ops.require_hip(x, "discriminator frames")
         # AvgPool3d((1,2,2)) + PixelUnshuffle(2) + permute to N C T H W, written once as N T H W C
         x = ops.frames_s2d(x, None, pool=True, frame_major=False, as_3d=True)
-        x = self.d1(x)
-        x = self.d2(x)
+        x = self.d1(x, calls=calls)  # the 3-D blocks run once per discriminator call: groups are already in call order
+        x = self.d2(x, calls=calls)
         # the reference loops over the remaining frames (discriminators.py:119-133); here they form one frame-major batch and
         # every block / head runs once, each frame keeping its own spectral-norm sigma and BatchNorm1d batch statistics
         frames = x.size(2)
+        lay = _frame_layout(calls, frames)
+        groups = frames * calls
         rep = ops.frames_to_batch(x)
         for d in self.intermediate_dblocks:
-            rep = d(rep, calls=frames)
-        rep = self.d_last(rep, calls=frames)
+            rep = d(rep, calls=groups, layout=lay)
+        rep = self.d_last(rep, calls=groups, layout=lay)
         rep = ops.relu_sum_hw(rep)
-        rep = self.bn(rep, groups=frames)
-        rep = self.fc(rep, calls=frames)
+        rep = self.bn(rep, groups=groups, layout=lay)
+        rep = self.fc(rep, calls=groups, layout=lay)
         return _sum_heads(rep, frames)
 
 
@@ -88,20 +100,22 @@ class SpatialDiscriminator(torch.nn.Module, PyTorchModelHubMixin):
         self.relu = torch.nn.ReLU()
         self.bn = BatchNorm1d(2 * internal_chn * input_channels)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, calls: int = 1) -> torch.Tensor:
         ops.require_hip(x, "discriminator frames")
-        # frame indices come from the CPU generator exactly as in the reference (discriminators.py:199)
-        idxs = torch.randint(low=0, high=x.size()[1], size=(self.num_timesteps,))
+        # frame indices come from the CPU generator exactly as in the reference (discriminators.py:199): one draw per call
+        idxs = torch.stack([torch.randint(low=0, high=x.size()[1], size=(self.num_timesteps,)) for _ in range(calls)])
         idxs_dev = idxs.to(device=x.device, dtype=torch.int32)
         frames = self.num_timesteps
+        lay = _frame_layout(calls, frames)
+        groups = frames * calls
         # AvgPool2d(2) + PixelUnshuffle(2) of the drawn frames, frame-major: the reference's per-frame loop
         # (discriminators.py:201-226) as one batch of `frames` calls per block
-        rep = ops.frames_s2d(x, idxs_dev, pool=True, frame_major=True)
-        rep = self.d1(rep, calls=frames)
+        rep = ops.frames_s2d(x, idxs_dev, pool=True, frame_major=True, idx_group=x.shape[0] // calls)
+        rep = self.d1(rep, calls=groups, layout=lay)
         for d in self.intermediate_dblocks:
-            rep = d(rep, calls=frames)
-        rep = self.d6(rep, calls=frames)
+            rep = d(rep, calls=groups, layout=lay)
+        rep = self.d6(rep, calls=groups, layout=lay)
         rep = ops.relu_sum_hw(rep)
-        rep = self.bn(rep, groups=frames)
-        rep = self.fc(rep, calls=frames)
+        rep = self.bn(rep, groups=groups, layout=lay)
+        rep = self.fc(rep, calls=groups, layout=lay)
         return _sum_heads(rep, frames)

@@ -39,9 +39,15 @@ class Sampler(torch.nn.Module, PyTorchModelHubMixin):
         self.conv_1x1 = SNConv(lc // 16, 4 * output_channels, 1)
         self.depth2space = torch.nn.PixelShuffle(upscale_factor=2)
 
-    def forward(self, conditioning_states: List[torch.Tensor], latent_dim: torch.Tensor) -> torch.Tensor:
+    def forward(self, conditioning_states: List[torch.Tensor], latent_dim: torch.Tensor, draws: int = 1,
+                reverse: bool = False) -> torch.Tensor:
+        """`draws` > 1: `draws` generator forwards of the reference in one go - conditioning states [draws * B, ...] (draw-major),
+        one latent map per draw [draws, C, h, w]; returns [draws * B, T, C, H, W].  Every (draw, step) keeps its own spectral-norm
+        sigma and BatchNorm statistics, advanced in the reference's order (draw-major; `reverse`: last draw first)."""
         init_states = conditioning_states
         T = self.forecast_steps
+        lay = ops.CallLayout(draws, T, time_major=True, reverse=reverse) if (draws > 1 or reverse) else None
+        calls = T * draws
         # `[repeat(latent, B)] * T` (generators.py:146-149): the first ConvGRU sees the same map for every sample at every step,
         # so it is handed over as the single map it is (ConvGRUFn x_shared) instead of T*B copies
         h = latent_dim
@@ -53,12 +59,12 @@ class Sampler(torch.nn.Module, PyTorchModelHubMixin):
             # only the ConvGRU is a true recurrence; its T outputs then travel as ONE time-major batch [T*B, C, h, w] through
             # the 1x1 conv, the G-block and the upsampling G-block (one launch per conv instead of T), every forecast step
             # keeping its own spectral-norm sigma and BatchNorm batch statistics exactly as the reference's T calls do
-            h = gru.forward_batched(h, init_states[3 - lvl], T, x_shared=(lvl == 0))
-            h = c11(h, calls=T)
-            h = g(h, calls=T)
-            h = upg(h, calls=T)
+            h = gru.forward_batched(h, init_states[3 - lvl], T, x_shared=(lvl == 0), draws=draws, layout=lay)
+            h = c11(h, calls=calls, layout=lay)
+            h = g(h, calls=calls, layout=lay)
+            h = upg(h, calls=calls, layout=lay)
         # relu(bn(h)) folded into the 1x1 conv's operand load; PixelShuffle + stack in one layout pass
-        h = self.conv_1x1(h, bn=self.bn.prepare(h, T), calls=T)
+        h = self.conv_1x1(h, bn=self.bn.prepare(h, calls, lay), calls=calls, layout=lay)
         return ops.d2s_frames(h, T)
 
 
@@ -72,9 +78,31 @@ class Generator(torch.nn.Module, PyTorchModelHubMixin):
         self.sampler = sampler
 
     def forward(self, x: torch.Tensor):
+        return self.forward_draws(x, 1)
+
+    def forward_draws(self, x: torch.Tensor, draws: int, reverse: bool = False, zs=None) -> torch.Tensor:
+        """`draws` forward calls of the reference on the same frames x as ONE batch -> [draws * B, T, C, H, W], draw-major.
+
+        Train mode: identical to calling `forward(x)` `draws` times in a row (each call draws its own latent z from the CPU
+        generator in that order, and advances every spectral-norm u / v and BatchNorm running statistic once per call of the
+        module) - the per-step kernels just see `draws` times more rows.  `reverse=True` assigns the state sequence as if the
+        calls had been made last-draw-first, which is what activation checkpointing's recompute does (dgmr/dgmr.py:176).
+        Eval mode: ensemble sampling - the context stack runs once (its result does not depend on the draw), the sampler on all draws.
+        `zs`: latent draws to use ([draws, 8, h/32, w/32]) instead of drawing them here.
+        """
+        if zs is None:
+            zs = torch.cat([self.latent_stack.draw(x) for _ in range(draws)], dim=0)
+        elif zs.shape[0] != draws:
+            raise RuntimeError(f"forward_draws: {zs.shape[0]} latent draws given for draws={draws}")
         # every spectral-norm power iteration of this forward is data-independent: after the first (traced) call they are all
         # drawn up front in three launches
-        with SNScope(self, (tuple(x.shape), getattr(self.sampler, "forecast_steps", 0))):
-            conditioning_states = self.conditioning_stack(x)
-            latent_dim = self.latent_stack(x)
-            return self.sampler(conditioning_states, latent_dim)
+        with SNScope(self, (tuple(x.shape), getattr(self.sampler, "forecast_steps", 0), draws, reverse)):
+            per_call = self.training and (draws > 1 or reverse)
+            if per_call:
+                conditioning_states = self.conditioning_stack(x, draws=draws, reverse=reverse)
+            else:
+                conditioning_states = self.conditioning_stack(x)
+                if draws > 1:
+                    conditioning_states = [ops.repeat_batch(c, draws) for c in conditioning_states]
+            latent_dim = self.latent_stack.forward_latent(zs, reverse=reverse and self.training)
+            return self.sampler(conditioning_states, latent_dim, draws=draws, reverse=reverse and self.training)

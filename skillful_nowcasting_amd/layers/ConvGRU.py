@@ -40,16 +40,19 @@ class ConvGRU(torch.nn.Module):
         super().__init__()
         self.cell = ConvGRUCell(input_channels, output_channels, kernel_size, sn_eps)
 
-    def forward_batched(self, x_all: torch.Tensor, hidden_state: torch.Tensor, steps: int, x_shared: bool = False) -> torch.Tensor:
+    def forward_batched(self, x_all: torch.Tensor, hidden_state: torch.Tensor, steps: int, x_shared: bool = False, draws: int = 1,
+                        layout=None) -> torch.Tensor:
         """All `steps` inputs as one time-major batch [steps*B, C, h, w] -> all outputs [steps*B, C_out, h, w].
 
-        x_shared: x_all is a single map [1, C, h, w] fed to every sample at every step (the sampler's `[latent] * T`)."""
+        x_shared: x_all is a single map [1, C, h, w] fed to every sample at every step (the sampler's `[latent] * T`).
+        draws > 1: B = draws * B' samples per step, draw-major; `layout` = CallLayout(draws, steps, time_major=True, ...) tells
+        which of the steps * draws calls of the reference each (step, draw) group is; a shared x is one map per draw."""
         cell = self.cell
         convs = (cell.read_gate_conv, cell.update_gate_conv, cell.output_conv)
-        # the spectral-norm iterations of the three convs do not depend on the data: all `steps` calls are drawn up front
-        seqs = tuple(c._sigma(steps) for c in convs)
+        # the spectral-norm iterations of the three convs do not depend on the data: all calls are drawn up front
+        seqs = tuple(c._sigma(steps * draws, layout) for c in convs)
         params = tuple(p for c in convs for p in (c.weight_orig, c.bias))
-        return ops.conv_gru(x_all, hidden_state, params, seqs, steps, x_shared)
+        return ops.conv_gru(x_all, hidden_state, params, seqs, steps, x_shared, draws)
 
     def forward_list(self, x, hidden_state=None) -> List[torch.Tensor]:
         steps = len(x)

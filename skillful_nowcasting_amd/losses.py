@@ -24,17 +24,29 @@ class GridCellLoss(nn.Module):
     ``||(g - y) * w||_1 / T * H * W`` with ``w = max(y + 1, cap)`` (dgmr/dgmr.py:33)."""
 
     def __init__(self, weight_fn=None, precip_weight_cap=24.0):
+        """`weight_fn(targets, precip_weight_cap)`: dgmr.dgmr.weight_fn (the default of DGMR) is evaluated inside the loss kernel;
+        any other callable is called on the targets and its result handed to the kernel as explicit weights.  None is rejected:
+        the reference's module cannot run without one either (losses.py:171 wraps it in a lambda that is never None, so
+        `difference * None` raises on the first call)."""
         super().__init__()
+        if weight_fn is None:
+            raise ValueError("GridCellLoss needs a weight_fn (the reference's forward fails without one, dgmr/losses.py:171,187-190)")
         self.precip_weight_cap = precip_weight_cap
         self.weight_fn = weight_fn
 
+    def _weights(self, targets):
+        if getattr(self.weight_fn, "fused_in_kernel", False):
+            return None
+        with torch.no_grad():
+            return self.weight_fn(targets, self.precip_weight_cap)
+
     def forward(self, generated_images, targets):
         """`generated_images`: the mean prediction [B,T,C,H,W]."""
-        return ops.GridCellFn.apply(generated_images.unsqueeze(0), targets, self.precip_weight_cap)
+        return ops.GridCellFn.apply(generated_images.unsqueeze(0), targets, self.precip_weight_cap, self._weights(targets))
 
     def forward_stacked(self, stacked_predictions, targets):
         """Mean over the K stacked draws and the loss in one pass: `stacked_predictions` is [K,B,T,C,H,W]."""
-        return ops.GridCellFn.apply(stacked_predictions, targets, self.precip_weight_cap)
+        return ops.GridCellFn.apply(stacked_predictions, targets, self.precip_weight_cap, self._weights(targets))
 
 
 class NowcastingLoss(nn.Module):

@@ -23,9 +23,10 @@ from .ops import BNState, ConvSpec
 class SNPlan:
     """Every spectral-norm call sequence of one forward, drawn in three launches (dgmr_spectral_sigma_seq_multi).
 
-    `entries`: [(module, calls)] in first-use order, each module at most once.  The descriptor table (static pointers to
-    W, W W^T, u, v and offsets into a per-run output arena) is uploaded once; `run()` refreshes stale Gram matrices, allocates
-    the arena and returns {id(module): SNCall} whose tensors are views into it.
+    `entries`: [(module, calls, layout)] in first-use order, each module at most once; `layout` (ops.CallLayout or None) says
+    which group of the consuming batch each call of the sequence belongs to.  The descriptor table (static pointers to W, W W^T,
+    u, v, the call -> group map and offsets into a per-run output arena) is uploaded once; `run()` refreshes stale Gram matrices,
+    allocates the arena and returns {id(module): SNCall} whose tensors are views into it, in GROUP order.
     """
 
     def __init__(self, entries):
@@ -40,10 +41,13 @@ class SNPlan:
         self.layout = []
         self.max_cout = 1
         self.ptrs = []
+        self.perms = []  # keeps the device call -> group maps alive
         dev = None
-        for i, (m, calls) in enumerate(self.entries):
+        for i, (m, calls, layout) in enumerate(self.entries):
             w = m.weight_orig
             dev = w.device
+            perm = ops.call_slots(layout, dev)
+            self.perms.append(perm)
             vec = getattr(m.parametrizations.weight, "0")
             cout, cin = w.shape[0], w.shape[1]
             taps = w.numel() // (cout * cin)
@@ -51,6 +55,7 @@ class SNPlan:
             gram = m._gram_buffer()
             d = descs[i]
             d.w, d.gram, d.u, d.v = w.data_ptr(), gram.data_ptr(), vec._u.data_ptr(), vec._v.data_ptr()
+            d.perm = perm.data_ptr() if perm is not None else None
             d.inv_sigma_off = off
             d.u_hist_off = off + calls
             d.v_hist_off = d.u_hist_off + calls * cout
@@ -70,24 +75,24 @@ class SNPlan:
         self.device = dev
 
     def valid(self) -> bool:
-        for (m, _), ptrs in zip(self.entries, self.ptrs):
+        for (m, _, _), ptrs in zip(self.entries, self.ptrs):
             vec = getattr(m.parametrizations.weight, "0")
             if (m.weight_orig.data_ptr(), vec._u.data_ptr(), vec._v.data_ptr(), m._gram_buffer().data_ptr()) != ptrs:
                 return False
         return True
 
     def run(self):
-        for m, _ in self.entries:
+        for m, _, _ in self.entries:
             m._gram()  # refresh W W^T in place if the optimiser moved W
         arena = torch.empty(self.total, device=self.device, dtype=torch.float32)
         ops.call("dgmr_spectral_sigma_seq_multi", self.descs_dev.data_ptr(), len(self.entries), self.rows, self.cols, self.max_cout,
                  arena.data_ptr(), ops._stream())
         out = {}
-        for (m, calls), (off, _, cout, k) in zip(self.entries, self.layout):
+        for (m, calls, lay), (off, _, cout, k) in zip(self.entries, self.layout):
             inv_sigma = arena[off:off + calls]
             u = arena[off + calls:off + calls + calls * cout].view(calls, cout)
             v = arena[off + calls + calls * cout:off + calls + calls * cout + calls * k].view(calls, k)
-            out[id(m)] = ops.SNCall(inv_sigma, u, v, calls)
+            out[id(m)] = (ops.SNCall(inv_sigma, u, v, calls), lay)
         return out
 
 
@@ -128,20 +133,20 @@ class SNScope:
             return False
         SNScope._active = self.prev
         if self.trace is not None and exc[0] is None:
-            seen = {id(m) for m, _ in self.trace}
+            seen = {id(m) for m, _, _ in self.trace}
             if self.trace and len(seen) == len(self.trace):  # a module requested twice cannot be planned (dependent sequences)
                 import weakref
 
                 SNScope._plans[self.key] = (weakref.ref(self.owner), SNPlan(self.trace))
         return False
 
-    def take(self, module, calls):
+    def take(self, module, calls, layout=None):
         if self.records is None:
             return None
         rec = self.records.get(id(module))
-        if rec is not None and rec.groups == calls:
+        if rec is not None and rec[0].groups == calls and rec[1] == layout:
             del self.records[id(module)]
-            return rec
+            return rec[0]
         return None
 
 
@@ -159,6 +164,16 @@ def _conv_init(out_channels: int, in_channels: int, ks):
     return w, b
 
 
+def _relayout_hook(module, incompatible_keys=None):
+    """load_state_dict post-hook: conv weights go back to channels-last storage (load_state_dict(assign=True) swaps in the
+    checkpoint's NCHW-contiguous tensors) and every cache keyed on the weights is invalidated."""
+    for name in ("original", "weight"):
+        p = module._parameters.get(name)
+        if p is not None and p.dim() in (4, 5) and not p.is_contiguous(memory_format=_mf(p.dim())):
+            p.data = p.data.contiguous(memory_format=_mf(p.dim()))
+    ops.bump_weights_epoch()
+
+
 class _SNVectors(nn.Module):
     def __init__(self, u, v):
         super().__init__()
@@ -171,6 +186,7 @@ class _SNWeight(nn.Module):
         super().__init__()
         self.original = nn.Parameter(weight)
         self.add_module("0", _SNVectors(u, v))
+        self.register_load_state_dict_post_hook(_relayout_hook)
 
 
 class _Parametrizations(nn.Module):
@@ -221,18 +237,29 @@ class _SpectralNormBase(nn.Module):
             self._gram_tag = tag
         return buf
 
-    def _sigma(self, calls: int = 1) -> ops.SNCall:
-        """Spectral-norm record of `calls` consecutive calls of this module (train: one power iteration per call)."""
+    def _sigma(self, calls: int = 1, layout: Optional[ops.CallLayout] = None) -> ops.SNCall:
+        """Spectral-norm record of `calls` consecutive calls of this module (train: one power iteration per call), indexed by the
+        GROUP of the consuming batch that each call belongs to (`layout`; default: group q == call q)."""
+        if layout is not None:
+            if layout.is_identity():
+                layout = None
+            elif layout.calls != calls:
+                raise RuntimeError(f"spectral norm: {calls} calls requested but the call layout describes {layout.calls}")
         vec = getattr(self.parametrizations.weight, "0")
         scope = SNScope._active
         if scope is not None and self.training:
-            rec = scope.take(self, calls)
+            rec = scope.take(self, calls, layout)
             if rec is not None:
                 return rec
             if scope.trace is not None:
-                scope.trace.append((self, calls))
+                scope.trace.append((self, calls, layout))
         if calls > 1 and self.training:
-            return ops.spectral_sigma_seq(self.weight_orig, self._gram(), vec._u, vec._v, self._scratch, self.eps, calls)
+            # outside a planned forward (first, traced call; stand-alone blocks): a one-module plan, cached on the module
+            plans = self.__dict__.setdefault("_solo_plans", {})
+            plan = plans.get((calls, layout))
+            if plan is None or not plan.valid():
+                plan = plans[(calls, layout)] = SNPlan([(self, calls, layout)])
+            return plan.run()[id(self)][0]
         # one call, or eval mode (no iteration: every call sees the same sigma)
         return ops.spectral_sigma(self.weight_orig, vec._u, vec._v, self._scratch, self.eps, self.training)
 
@@ -247,11 +274,15 @@ class SNConv(_SpectralNormBase):
         self._init_sn(w, b, eps)
 
     def forward(self, x, *, pre_relu: bool = False, bn: Optional[BNState] = None, upsample: bool = False, residual=None,
-                act_relu: bool = False, calls: int = 1, sn: Optional[ops.SNCall] = None, residual_up: bool = False):
-        """`calls` > 1: x is a batch of `calls` groups (forecast steps / frames), each group being one call of this module in
-        the reference (own power iteration, own sigma).  `sn`: a record drawn earlier with `_sigma` (ConvGRU steps)."""
+                act_relu: bool = False, calls: int = 1, sn: Optional[ops.SNCall] = None, residual_up: bool = False,
+                layout: Optional[ops.CallLayout] = None):
+        """`calls` > 1: x is a batch of `calls` groups (forecast steps / frames [x generator draws]), each group being one call of
+        this module in the reference (own power iteration, own sigma); `layout`: which call each group is (ops.CallLayout).
+        `sn`: a record drawn earlier with `_sigma` (ConvGRU steps)."""
+        if layout is not None:
+            calls = layout.calls
         if sn is None:
-            sn = self._sigma(calls)
+            sn = self._sigma(calls, layout)
         spec = ConvSpec(upsample=upsample, pre_relu=pre_relu, bn=bn, sn=sn, act_relu=act_relu, residual_up=residual_up)
         return ops.conv(x, self.weight_orig, self.bias, sn.inv_sigma, residual, spec)
 
@@ -269,8 +300,10 @@ class SNLinear1(_SpectralNormBase):
         nn.init.uniform_(b, -bound, bound)
         self._init_sn(w, b, eps)
 
-    def forward(self, x, calls: int = 1):
-        sn = self._sigma(calls)
+    def forward(self, x, calls: int = 1, layout: Optional[ops.CallLayout] = None):
+        if layout is not None:
+            calls = layout.calls
+        sn = self._sigma(calls, layout)
         return ops.SNLinear1Fn.apply(x, self.weight_orig, self.bias, sn)
 
 
@@ -289,6 +322,7 @@ class Conv(nn.Module):
             self.bias = nn.Parameter(b)
         else:
             self.register_parameter("bias", None)
+        self.register_load_state_dict_post_hook(_relayout_hook)
 
     def forward(self, x, *, pre_relu: bool = False, residual=None, scale=None, gamma_scale: bool = False):
         spec = ConvSpec(pre_relu=pre_relu, gamma_scale=gamma_scale)
@@ -305,15 +339,21 @@ class BatchNorm(nn.BatchNorm2d):
     def forward(self, x):  # pragma: no cover - guard
         raise RuntimeError("BatchNorm is fused into the following conv; call .prepare(x) and pass bn= to the conv")
 
-    def prepare(self, x, groups: int = 1) -> BNState:
+    def prepare(self, x, groups: int = 1, layout: Optional[ops.CallLayout] = None) -> BNState:
+        """`groups` > 1: x holds that many calls of the reference's module, each with its own batch statistics; `layout` gives the
+        order in which the reference made them (= the order of the running-statistics updates)."""
+        if layout is not None:
+            groups = layout.calls
         return ops.bn_prepare(x, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked, self.eps,
-                              self.momentum, self.training, groups)
+                              self.momentum, self.training, groups, layout)
 
 
 class BatchNorm1d(nn.BatchNorm1d):
     """BatchNorm1d over [N, C] through the HIP kernels (discriminator heads)."""
 
-    def forward(self, x, groups: int = 1):
+    def forward(self, x, groups: int = 1, layout: Optional[ops.CallLayout] = None):
         """`groups` > 1: x is [groups*N, C]; each group is one call of the reference's module (own batch statistics)."""
+        if layout is not None:
+            groups = layout.calls
         return ops.BatchNorm1dFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked,
-                                       self.eps, self.momentum, self.training, groups)
+                                       self.eps, self.momentum, self.training, groups, layout)

@@ -90,6 +90,19 @@ def require_hip(t: torch.Tensor, what: str = "input"):
         raise RuntimeError(f"skillful_nowcasting_amd: {what} must be float32, got {t.dtype}")
 
 
+def require_weight_layout(w: torch.Tensor, what: str = "conv weight"):
+    """The kernels index conv weights as O[D]HWI storage (an OIHW parameter in channels_last memory format).  A parameter that
+    was replaced by an NCHW-contiguous tensor (load_state_dict(assign=True), `p.data = ...`) would be read with the wrong
+    strides: refuse it instead of computing garbage (nn.SNConv / nn.Conv re-layout such tensors when a state_dict is loaded)."""
+    if w.dim() in (4, 5):
+        mf = torch.channels_last if w.dim() == 4 else torch.channels_last_3d
+        if not w.is_contiguous(memory_format=mf):
+            raise RuntimeError(
+                f"skillful_nowcasting_amd: {what} of shape {tuple(w.shape)} has strides {tuple(w.stride())}; the HIP kernels need "
+                f"channels-last (O[D]HWI) storage. Use `p.data = p.data.contiguous(memory_format=torch.channels_last[_3d])` "
+                "and ops.bump_weights_epoch() after writing a parameter out of band.")
+
+
 def to_cl(x: torch.Tensor) -> torch.Tensor:
     """Channels-last contiguous view/copy of a 4-D or 5-D activation (no-op on the hot path)."""
     if x.dim() == 4:
@@ -118,6 +131,62 @@ def grad_buffer(p: torch.Tensor) -> torch.Tensor:
     if p.grad is None:
         p.grad = torch.zeros_like(p)  # preserve_format: same strides as the parameter
     return p.grad
+
+
+# ---------------------------------------------------------------------------------------------------
+# call groups: which reference CALL of a module each group of a batched launch stands for
+# ---------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class CallLayout:
+    """`outer * inner` consecutive calls of one module, run as the groups of ONE batched launch.
+
+    The reference calls a sampler / discriminator module once per forecast step (or frame) inside every generator draw (or
+    discriminator call): call number  c = d' * inner + i  for draw position d' and step i.  State that moves per call - the
+    spectral-norm power iteration (u, v, sigma) and BatchNorm's running statistics - must follow THAT order, while the batch that
+    carries all calls at once is laid out for the kernels:
+
+      time_major   groups [inner][outer]  (the ConvGRU needs every draw's samples of one step contiguous), or
+      draw-major   groups [outer][inner]  (context stack: the four context frames of one draw together);
+      reverse      the reference visits the draws last-to-first: activation checkpointing recomputes the generator forwards of a
+                   step in reverse order during the backward pass (dgmr/dgmr.py:176, torch.utils.checkpoint), and that recompute
+                   is what the gradients (and the second advance of u / v / running statistics) come from.
+    """
+
+    outer: int = 1
+    inner: int = 1
+    time_major: bool = True
+    reverse: bool = False
+
+    @property
+    def calls(self) -> int:
+        return self.outer * self.inner
+
+    def slots(self) -> List[int]:
+        """slots()[c] = group of the batch that call c of the reference's sequence belongs to."""
+        out = []
+        for c in range(self.calls):
+            dpos, i = divmod(c, self.inner)
+            d = self.outer - 1 - dpos if self.reverse else dpos
+            out.append(i * self.outer + d if self.time_major else d * self.inner + i)
+        return out
+
+    def is_identity(self) -> bool:
+        return self.slots() == list(range(self.calls))
+
+
+_SLOT_CACHE = {}
+
+
+def call_slots(layout: Optional[CallLayout], device) -> Optional[torch.Tensor]:
+    """Device int32 array of `layout.slots()` (None for the identity order), cached per (layout, device)."""
+    if layout is None or layout.is_identity():
+        return None
+    key = (layout, str(device))
+    t = _SLOT_CACHE.get(key)
+    if t is None:
+        t = torch.tensor(layout.slots(), dtype=torch.int32).to(device)
+        _SLOT_CACHE[key] = t
+    return t
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -198,11 +267,12 @@ class BNState:
 
 
 def bn_prepare(x: torch.Tensor, gamma, beta, running_mean, running_var, num_batches_tracked, eps: float, momentum: float,
-               train: bool, groups: int = 1) -> BNState:
+               train: bool, groups: int = 1, layout: Optional[CallLayout] = None) -> BNState:
     """BatchNorm statistics of x (train) or running statistics (eval) folded to y = a*x + b.
 
     torch.nn.BatchNorm2d semantics (dgmr/common.py:38-39,108-109; generators.py:113): biased batch variance
-    for normalisation, unbiased for the running estimate, momentum 0.1, one running update per group in order.
+    for normalisation, unbiased for the running estimate, momentum 0.1, one running update per group, applied in the
+    reference's call order (`layout`, see CallLayout; default: group order).
     """
     require_hip(x)
     x = to_cl(x)
@@ -219,11 +289,13 @@ def bn_prepare(x: torch.Tensor, gamma, beta, running_mean, running_var, num_batc
     if train:
         sums = torch.zeros(groups * 2 * c, device=dev, dtype=torch.float64)
         call("dgmr_bn_stats", _p(x), _p(sums), groups, r, c, _stream())
+        if layout is not None and layout.calls != groups:
+            raise RuntimeError(f"batch norm: {groups} call groups but the call layout describes {layout.calls}")
         call("dgmr_bn_finalize", _p(sums), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(num_batches_tracked),
-             _p(a), _p(b), _p(mean), _p(rstd), groups, r, c, float(eps), float(momentum), _stream())
+             _p(a), _p(b), _p(mean), _p(rstd), groups, r, c, float(eps), float(momentum), _p(call_slots(layout, dev)), _stream())
     else:
         call("dgmr_bn_finalize", None, _p(gamma), _p(beta), _p(running_mean), _p(running_var), None, _p(a), _p(b), _p(mean),
-             _p(rstd), 1, r, c, float(eps), float(momentum), _stream())
+             _p(rstd), 1, r, c, float(eps), float(momentum), None, _stream())
     return BNState(a, b, mean, rstd, gamma, beta, train, groups, n // groups)
 
 
@@ -343,6 +415,7 @@ class ConvFn(Function):
             h, wd = 2 * h, 2 * wd
         cout = w.shape[0]
         kd, kh, kw = _kdims(w)
+        require_weight_layout(w)
         if w.shape[1] != cin:
             raise RuntimeError(f"conv: input has {cin} channels, weight expects {w.shape[1]}")
         oshape = (n, cout, h, wd) if x.dim() == 4 else (n, cout, d, h, wd)
@@ -519,33 +592,39 @@ class FramesS2DFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, frames, idx, pool: bool, frame_major: bool, as_3d: bool):
+    def forward(ctx, frames, idx, pool: bool, frame_major: bool, as_3d: bool, idx_group: int = 0):
         require_hip(frames)
         frames = frames.contiguous()
         b, t, c, h, w = frames.shape
-        f = t if idx is None else idx.numel()
+        if idx is not None and idx.dim() == 2:  # [calls][F]: one row of frame indices per group of idx_group samples
+            if idx_group < 1 or b % idx_group or idx.shape[0] != b // idx_group:
+                raise RuntimeError(f"frames_s2d: {tuple(idx.shape)} index rows do not fit {b} samples in groups of {idx_group}")
+            f = idx.shape[1]
+        else:
+            idx_group = 0
+            f = t if idx is None else idx.numel()
         p = 2 if pool else 1
         ho, wo = h // (2 * p), w // (2 * p)
         if as_3d:
             out = empty_cl((b, 4 * c, f, ho, wo), frames)
         else:
             out = empty_cl((b * f, 4 * c, ho, wo), frames)
-        call("dgmr_frames_s2d", _p(frames), _p(idx), _p(out), b, t, c, h, w, f, int(pool), int(frame_major), _stream())
-        ctx.geom = (b, t, c, h, w, f, int(pool), int(frame_major))
+        call("dgmr_frames_s2d", _p(frames), _p(idx), _p(out), b, t, c, h, w, f, int(pool), int(frame_major), idx_group, _stream())
+        ctx.geom = (b, t, c, h, w, f, int(pool), int(frame_major), idx_group)
         ctx.idx = idx
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        b, t, c, h, w, f, pool, fm = ctx.geom
+        b, t, c, h, w, f, pool, fm, idx_group = ctx.geom
         dout = to_cl(dout)
         dfr = torch.zeros(b, t, c, h, w, device=dout.device, dtype=torch.float32)
-        call("dgmr_frames_s2d_bwd", _p(dout), _p(ctx.idx), _p(dfr), b, t, c, h, w, f, pool, fm, _stream())
-        return dfr, None, None, None, None
+        call("dgmr_frames_s2d_bwd", _p(dout), _p(ctx.idx), _p(dfr), b, t, c, h, w, f, pool, fm, idx_group, _stream())
+        return dfr, None, None, None, None, None
 
 
-def frames_s2d(frames, idx=None, pool=False, frame_major=False, as_3d=False):
-    return FramesS2DFn.apply(frames, idx, pool, frame_major, as_3d)
+def frames_s2d(frames, idx=None, pool=False, frame_major=False, as_3d=False, idx_group: int = 0):
+    return FramesS2DFn.apply(frames, idx, pool, frame_major, as_3d, idx_group)
 
 
 class D2SFramesFn(Function):
@@ -627,14 +706,13 @@ def cat_channels(xs: Sequence[torch.Tensor], interleave: bool = False):
 
 
 class RepeatBatchFn(Function):
-    """einops 'b c h w -> (repeat b) c h w' for b == 1 (generators.py:146-148)."""
+    """einops 'b c h w -> (repeat b) c h w' (generators.py:146-148 at b == 1): the whole batch tiled `repeat` times."""
 
     @staticmethod
     def forward(ctx, x, repeat: int):
         require_hip(x)
         x = to_cl(x)
-        assert x.shape[0] == 1
-        out = empty_cl((repeat,) + tuple(x.shape[1:]), x)
+        out = empty_cl((repeat * x.shape[0],) + tuple(x.shape[1:]), x)
         call("dgmr_repeat_rows", _p(x), _p(out), x.numel(), repeat, _stream())
         ctx.repeat = repeat
         return out
@@ -643,7 +721,7 @@ class RepeatBatchFn(Function):
     def backward(ctx, dout):
         dout = to_cl(dout)
         n = dout.numel() // ctx.repeat
-        dx = empty_cl((1,) + tuple(dout.shape[1:]), dout)
+        dx = empty_cl((dout.shape[0] // ctx.repeat,) + tuple(dout.shape[1:]), dout)
         tmp = torch.empty(2 * n, device=dout.device, dtype=torch.float64)
         call("dgmr_colsum", _p(dout), _p(dx), _p(tmp), ctx.repeat, n, 0, _stream())
         return dx, None
@@ -713,21 +791,28 @@ class ConvGRUFn(Function):
     `[repeat(latent, B)] * T`, generators.py:146-149).  Its x parts are then three convs of a single 8x8 map instead of T*B
     identical ones; the backward sums the gate gradients over the samples first (convolution is linear), so the x-part data
     and weight gradients run on T maps instead of T*B.
+
+    draws: the batch holds `draws` generator draws (forward calls of the reference), draw-major inside every step: step tensors are
+    [draws * B', ...], the spectral-norm records carry steps * draws call groups in [step][draw] order (CallLayout time-major), and
+    a shared x is one map PER DRAW ([draws, Cx, h, w]: every draw has its own latent).
     """
 
     @staticmethod
-    def forward(ctx, x_all, h0, params, seqs, steps: int, x_shared: bool = False):
+    def forward(ctx, x_all, h0, params, seqs, steps: int, x_shared: bool = False, draws: int = 1):
         require_hip(x_all)
         require_hip(h0, "initial state")
         x_all, h0 = to_cl(x_all), to_cl(h0)
         wr, br, wu, bu, wc, bc = params
+        for w_ in (wr, wu, wc):
+            require_weight_layout(w_, "ConvGRU weight")
         T = steps
         nx, cx, hh, ww = x_all.shape
         b, ch = h0.shape[0], h0.shape[1]
         tb = T * b
-        if nx != (1 if x_shared else tb) or wr.shape[1] != cx + ch or wr.shape[0] != ch:
-            raise RuntimeError(f"ConvGRU: x {tuple(x_all.shape)} / h0 {tuple(h0.shape)} / weight {tuple(wr.shape)} do not fit T={T}"
-                               f"{' (shared x)' if x_shared else ''}")
+        if nx != (draws if x_shared else tb) or b % draws or wr.shape[1] != cx + ch or wr.shape[0] != ch:
+            raise RuntimeError(f"ConvGRU: x {tuple(x_all.shape)} / h0 {tuple(h0.shape)} / weight {tuple(wr.shape)} do not fit T={T}, "
+                               f"draws={draws}{' (shared x)' if x_shared else ''}")
+        bs = b // draws  # samples per draw = samples per spectral-norm call group within a step
         kh, kw = wr.shape[2], wr.shape[3]
         dev = x_all.device
         n_step = b * ch * hh * ww  # floats per step tensor
@@ -736,8 +821,11 @@ class ConvGRUFn(Function):
         def step_ptr(t_: torch.Tensor, t: int) -> int:
             return t_.data_ptr() + 4 * n_step * t
 
-        def scale_ptr(sn: SNCall, t: int) -> int:
-            return sn.inv_sigma.data_ptr() + (4 * t if sn.groups > 1 else 0)
+        def scale_ptr(sn: SNCall, t: int) -> int:  # the `draws` sigmas of step t are consecutive (groups in [step][draw] order)
+            return sn.inv_sigma.data_ptr() + (4 * t * draws if sn.groups > 1 else 0)
+
+        def sgroup(sn: SNCall) -> int:
+            return bs if sn.groups > 1 else b
 
         # x parts of the three convs for every step: raw sums (scale and bias are applied with the h part)
         xparts = []
@@ -745,9 +833,9 @@ class ConvGRUFn(Function):
             xp = empty_cl((nx, ch, hh, ww), x_all)
             _launch_conv(x_all, _p(w), None, None, xp, nx, 1, hh, ww, cx, ch, 1, kh, kw, w_cin=ct, w_coff=0,
                          w_split=_split_planes(w, False, 0, cx))
-            if x_shared:  # one map for everybody: B copies, read by every step
+            if x_shared:  # one map per draw: a copy for each of its samples, read by every step
                 x1, xp = xp, empty_cl((b, ch, hh, ww), x_all)
-                call("dgmr_repeat_rows", _p(x1), _p(xp), n_step // b, b, _stream())
+                call("dgmr_repeat_interleave", _p(x1), _p(xp), draws, n_step // b, bs, _stream())
             xparts.append(xp)
         xr, xu, xc = xparts
         if x_shared:
@@ -763,14 +851,15 @@ class ConvGRUFn(Function):
         for t in range(T):
             hp, out = step_ptr(buf, t), step_ptr(buf, t + 1)
             _launch_conv(hp, _p(wr), br, scale_ptr(sr, t), step_ptr(rh, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
-                         addend=x_ptr(xr, t), epi_mode=EPI_GRU_GATE, gru_h=hp, pre_out=step_ptr(pr, t), device=dev, w_split=spr)
+                         addend=x_ptr(xr, t), epi_mode=EPI_GRU_GATE, gru_h=hp, pre_out=step_ptr(pr, t), device=dev, w_split=spr,
+                         scale_group=sgroup(sr))
             _launch_conv(hp, _p(wu), bu, scale_ptr(su, t), step_ptr(pu, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
-                         addend=x_ptr(xu, t), device=dev, w_split=spu)
+                         addend=x_ptr(xu, t), device=dev, w_split=spu, scale_group=sgroup(su))
             _launch_conv(step_ptr(rh, t), _p(wc), bc, scale_ptr(sc, t), out, b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
                          addend=x_ptr(xc, t), epi_mode=EPI_GRU_BLEND, gru_h=hp, gru_pu=step_ptr(pu, t), pre_out=step_ptr(pc, t),
-                         device=dev, w_split=spc)
+                         device=dev, w_split=spc, scale_group=sgroup(sc))
         ctx.params = params
-        ctx.geom = (T, b, cx, ch, hh, ww, kh, kw)
+        ctx.geom = (T, b, cx, ch, hh, ww, kh, kw, draws)
         ctx.x_shared = x_shared
         ctx.groups = tuple(q.groups for q in seqs)
         ctx.save_for_backward(x_all, buf, pr, pu, pc, rh, sr.inv_sigma, sr.u, sr.v, su.inv_sigma, su.u, su.v, sc.inv_sigma, sc.u, sc.v)
@@ -780,7 +869,8 @@ class ConvGRUFn(Function):
     def backward(ctx, dout_all):
         (x_all, buf, pr, pu, pc, rh, isr, ur, vr, isu, uu, vu, isc, uc, vc) = ctx.saved_tensors
         wr, br, wu, bu, wc, bc = ctx.params
-        T, b, cx, ch, hh, ww, kh, kw = ctx.geom
+        T, b, cx, ch, hh, ww, kh, kw, draws = ctx.geom
+        bs = b // draws
         gr, gu, gc = ctx.groups
         dout_all = to_cl(dout_all)
         dev = dout_all.device
@@ -794,7 +884,10 @@ class ConvGRUFn(Function):
             return t_.data_ptr() + 4 * n_step * t
 
         def scale_ptr(inv_sigma: torch.Tensor, groups: int, t: int) -> int:
-            return inv_sigma.data_ptr() + (4 * t if groups > 1 else 0)
+            return inv_sigma.data_ptr() + (4 * t * draws if groups > 1 else 0)
+
+        def sgroup(groups: int) -> int:
+            return bs if groups > 1 else b
 
         dpr, dpu, dpc = (empty_cl((tb, ch, hh, ww), dout_all) for _ in range(3))
         # scratch of one step each
@@ -813,13 +906,13 @@ class ConvGRUFn(Function):
             call("dgmr_gru_blend_bwd", d, step_ptr(pu, t), hp, step_ptr(pc, t), step_ptr(dpu, t), _p(dh_a), step_ptr(dpc, t), n_step, st)
             # through the candidate conv to r*h, then through the read gate
             _launch_conv(step_ptr(dpc, t), _p(wt_ch), None, scale_ptr(isc, gc, t), d_rh, b, 1, hh, ww, ch, ch, 1, kh, kw, device=dev,
-                         w_split=sp_ch)
+                         w_split=sp_ch, scale_group=sgroup(gc))
             call("dgmr_gru_gate_bwd", _p(d_rh), step_ptr(pr, t), hp, step_ptr(dpr, t), _p(dh_b), n_step, st)
             # dh = dh_a + dh_b + convT(dpr / sigma_r, W_rh) + convT(dpu / sigma_u, W_uh)
             _launch_conv(step_ptr(dpr, t), _p(wt_rh), None, scale_ptr(isr, gr, t), c1, b, 1, hh, ww, ch, ch, 1, kh, kw, residual=dh_a,
-                         device=dev, w_split=sp_rh)
+                         device=dev, w_split=sp_rh, scale_group=sgroup(gr))
             _launch_conv(step_ptr(dpu, t), _p(wt_uh), None, scale_ptr(isu, gu, t), c2, b, 1, hh, ww, ch, ch, 1, kh, kw, residual=c1,
-                         device=dev, w_split=sp_uh)
+                         device=dev, w_split=sp_uh, scale_group=sgroup(gu))
             call("dgmr_axpby", _p(c2), _p(dh_b), _p(dh_next), 1.0, 1.0, n_step, st)
             have_next = True
         dh0 = None
@@ -828,26 +921,29 @@ class ConvGRUFn(Function):
             _copy(_p(dh_next), _p(dh0), n_step)
         x_shared = ctx.x_shared
         n_img = ch * hh * ww
+        TD = T * draws
         if x_shared:
-            # every sample of a step shares x: sum the gate gradients over the B samples of each step first -> [T, ch, h, w]
+            # the samples of a (step, draw) share x: sum their gate gradients first -> [T * draws, ch, h, w]
             dsum = []
             for dp in (dpr, dpu, dpc):
-                ds = empty_cl((T, ch, hh, ww), dout_all)
-                call("dgmr_group_rowsum", _p(dp), None, _p(ds), T, b, n_img, 1, st)
+                ds = empty_cl((TD, ch, hh, ww), dout_all)
+                call("dgmr_group_rowsum", _p(dp), None, _p(ds), TD, bs, n_img, 1, 1, st)
                 dsum.append(ds)
-            x_rep = empty_cl((T, cx, hh, ww), dout_all)  # the shared map once per step, as the weight gradient's "input"
-            call("dgmr_repeat_rows", _p(x_all), _p(x_rep), cx * hh * ww, T, st)
+            x_rep = empty_cl((TD, cx, hh, ww), dout_all)  # the shared maps once per step, as the weight gradient's "input"
+            call("dgmr_repeat_rows", _p(x_all), _p(x_rep), draws * cx * hh * ww, T, st)
         # ---- x-part data gradient, batched over the T steps (each step with its own 1/sigma) ----
         dx_all = None
         if ctx.needs_input_grad[0] and x_shared:
-            # dx = sum_k convT_k( sum_t dsum_k[t] / sigma_k[t] ): three convs of ONE map
-            dx_all = empty_cl((1, cx, hh, ww), dout_all)
-            tmp = empty_cl((1, cx, hh, ww), dout_all)
+            # dx[d] = sum_k convT_k( sum_t dsum_k[t][d] / sigma_k[t][d] ): three convs of ONE map per draw
+            dx_all = empty_cl((draws, cx, hh, ww), dout_all)
+            tmp = empty_cl((draws, cx, hh, ww), dout_all)
             chain = ((dsum[0], wr, isr, gr, None, tmp), (dsum[1], wu, isu, gu, tmp, dx_all), (dsum[2], wc, isc, gc, dx_all, tmp))
             for ds, w, inv_s, g_, res, dst in chain:
-                wsum = empty_cl((1, ch, hh, ww), dout_all)
-                call("dgmr_group_rowsum", _p(ds), _p(inv_s), _p(wsum), 1, T, n_img, T // g_, st)
-                _launch_conv(wsum, _p(_flipped_weight(w, 0, cx)), None, None, dst, 1, 1, hh, ww, ch, cx, 1, kh, kw, residual=res,
+                wsum = empty_cl((draws, ch, hh, ww), dout_all)
+                # train: one 1/sigma per (step, draw) = weight [row t][column block d]; eval: a single 1/sigma
+                call("dgmr_group_rowsum", _p(ds), _p(inv_s), _p(wsum), 1, T, draws * n_img, 1 if g_ > 1 else T,
+                     draws if g_ > 1 else 1, st)
+                _launch_conv(wsum, _p(_flipped_weight(w, 0, cx)), None, None, dst, draws, 1, hh, ww, ch, cx, 1, kh, kw, residual=res,
                              w_split=_split_planes(w, True, 0, cx))
             dx_all = tmp
         elif ctx.needs_input_grad[0]:
@@ -873,7 +969,7 @@ class ConvGRUFn(Function):
             g = torch.empty(ch * taps * ct, device=dev, dtype=torch.float32)
             dot = torch.zeros(g_, device=dev, dtype=torch.float32)
             # x half: T*B maps, or (shared x) the T per-step sums against T copies of the one map; h half: always T*B maps
-            x_half = (x_rep, dsum[ki], T, cx, 0) if x_shared else (x_all, dp, tb, cx, 0)
+            x_half = (x_rep, dsum[ki], TD, cx, 0) if x_shared else (x_all, dp, tb, cx, 0)
             for src, dy, nimg, cin, coff in (x_half, (hsrc, dp, tb, ch, cx)):
                 k = taps * cin
                 wa = WgradArgs()
@@ -889,11 +985,11 @@ class ConvGRUFn(Function):
                 call("dgmr_conv_wgrad", ctypes.byref(wa), st)
                 call("dgmr_wgrad_reduce_slice", _p(partial), ns, g_, ch, taps, cin, ct, coff, _p(w), _p(inv_s), _p(g), _p(dot), st)
             call("dgmr_sn_wgrad_finalize", _p(g), _p(grad_buffer(w)), _p(dot), _p(inv_s), _p(u_), _p(v_), ch, ct, taps, g_, 1, st)
-        return dx_all, dh0, None, None, None, None
+        return dx_all, dh0, None, None, None, None, None
 
 
-def conv_gru(x_all, h0, params, seqs, steps: int, x_shared: bool = False):
-    return ConvGRUFn.apply(x_all, h0, params, seqs, steps, x_shared)
+def conv_gru(x_all, h0, params, seqs, steps: int, x_shared: bool = False, draws: int = 1):
+    return ConvGRUFn.apply(x_all, h0, params, seqs, steps, x_shared, draws)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -968,11 +1064,11 @@ class BatchNorm1dFn(Function):
     """torch.nn.BatchNorm1d on [N, C] (discriminators.py:102,129,194,218), batch statistics in train mode."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, eps, momentum, train, groups=1):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, eps, momentum, train, groups=1, layout=None):
         require_hip(x)
         x = x.contiguous()
         n, c = x.shape
-        st = bn_prepare(x.view(n, c, 1, 1), gamma, beta, running_mean, running_var, nbt, eps, momentum, train, groups)
+        st = bn_prepare(x.view(n, c, 1, 1), gamma, beta, running_mean, running_var, nbt, eps, momentum, train, groups, layout)
         y = torch.empty_like(x)
         if st.groups > 1:
             call("dgmr_affine", _p(x), _p(st.a), _p(st.b), _p(y), st.groups, n // st.groups, c, 0, _stream())
@@ -996,7 +1092,7 @@ class BatchNorm1dFn(Function):
         dbet = grad_buffer(st.beta) if st.beta.requires_grad else None
         call("dgmr_bn_bwd_apply", _p(dy), _p(x), _p(mean), _p(rstd), _p(st.gamma), _p(sums), None, _p(dx), _p(dgam), _p(dbet),
              gq, n // gq, c, int(st.train), _stream())
-        return dx, None, None, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None, None, None
 
 
 class SNLinear1Fn(Function):
@@ -1118,31 +1214,36 @@ class TimeToChannelsFn(Function):
     (common.py:423) read straight from the batched D-block output."""
 
     @staticmethod
-    def forward(ctx, x, t: int):
+    def forward(ctx, x, t: int, outer: int = 1):
+        """outer > 1: x is [outer][T][B] (several generator draws, draw-major) -> [outer * B, C*T, h, w]."""
         require_hip(x)
         x = to_cl(x)
-        tb, c, h, w = x.shape
-        b = tb // t
-        out = empty_cl((b, c * t, h, w), x)
+        otb, c, h, w = x.shape
+        b = otb // (t * outer)
+        out = empty_cl((outer * b, c * t, h, w), x)
         r = b * h * w
-        for i in range(t):
-            call("dgmr_copy_channels", x.data_ptr() + 4 * r * c * i, _p(out), r, c, c, 0, 1, c * t, i, t, 0, _stream())
-        ctx.geom = (t, b, c, h, w)
+        for o in range(outer):
+            for i in range(t):
+                call("dgmr_copy_channels", x.data_ptr() + 4 * r * c * (o * t + i), out.data_ptr() + 4 * r * c * t * o, r, c, c, 0, 1,
+                     c * t, i, t, 0, _stream())
+        ctx.geom = (t, b, c, h, w, outer)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        t, b, c, h, w = ctx.geom
+        t, b, c, h, w, outer = ctx.geom
         dout = to_cl(dout)
-        dx = empty_cl((t * b, c, h, w), dout)
+        dx = empty_cl((outer * t * b, c, h, w), dout)
         r = b * h * w
-        for i in range(t):
-            call("dgmr_copy_channels", _p(dout), dx.data_ptr() + 4 * r * c * i, r, c, c * t, i, t, c, 0, 1, 0, _stream())
-        return dx, None
+        for o in range(outer):
+            for i in range(t):
+                call("dgmr_copy_channels", dout.data_ptr() + 4 * r * c * t * o, dx.data_ptr() + 4 * r * c * (o * t + i), r, c, c * t, i,
+                     t, c, 0, 1, 0, _stream())
+        return dx, None, None
 
 
-def time_to_channels(x, t: int):
-    return TimeToChannelsFn.apply(x, t)
+def time_to_channels(x, t: int, outer: int = 1):
+    return TimeToChannelsFn.apply(x, t, outer)
 
 
 class FramesToBatchFn(Function):
@@ -1248,16 +1349,21 @@ class GridCellFn(Function):
     """GridCellLoss on the mean of K stacked predictions: || (mean_k g_k - y) * max(y+1, cap) ||_1 / T * H * W."""
 
     @staticmethod
-    def forward(ctx, preds, targets, cap: float):
+    def forward(ctx, preds, targets, cap: float, weights=None):
+        """`weights`: explicit per-element weights (a caller-supplied weight_fn evaluated on the targets); None = the reference's
+        default max(y + 1, cap), evaluated inside the kernel."""
         require_hip(preds)
         preds, targets = preds.contiguous(), targets.contiguous()
+        if weights is not None:
+            weights = weights.expand_as(targets).contiguous().float()
         k = preds.shape[0]
         n = targets.numel()
         mult = float(targets.size(3) * targets.size(4)) / float(targets.size(1))
         loss = torch.empty((), device=preds.device, dtype=torch.float32)
         acc = torch.zeros(1, device=preds.device, dtype=torch.float64)
         dweight = torch.empty_like(targets)
-        call("dgmr_grid_cell_loss", _p(preds), k, n, _p(targets), float(cap), _p(acc), _p(loss), mult, _p(dweight), n, _stream())
+        call("dgmr_grid_cell_loss", _p(preds), k, n, _p(targets), _p(weights), float(cap), _p(acc), _p(loss), mult, _p(dweight), n,
+             _stream())
         ctx.save_for_backward(dweight)
         ctx.k, ctx.mult = k, mult
         return loss
@@ -1268,7 +1374,7 @@ class GridCellFn(Function):
         n = dweight.numel()
         g1 = torch.empty_like(dweight)
         call("dgmr_scale_by_dev", _p(dweight), _p(gl.contiguous()), ctx.mult, _p(g1), n, _stream())
-        return g1.unsqueeze(0).expand(ctx.k, *dweight.shape), None, None
+        return g1.unsqueeze(0).expand(ctx.k, *dweight.shape), None, None, None
 
 
 class AxpbyFn(Function):

@@ -1,0 +1,254 @@
+"""Three consecutive `DGMR.training_step`s with a VISIBLE adversarial path, and `validation_step`, against goldens produced by the
+unmodified reference (oracle/gen_golden.py::training_steps_adv_golden / validation_step_golden).
+
+What this pins that tests/test_training_step.py cannot:
+  * the chain  loss_hinge_gen -> discriminator data gradient (6 x D input gradient) -> generator  (grid_lambda = 0: the
+    generator's gradient is purely adversarial; every hinge stays active over all six D updates);
+  * Adam beyond its first step with beta1 != 0 (first moment, both bias corrections; D reaches step 6, G step 3);
+  * state evolution across optimiser updates: W W^T / flipped / split-plane caches, spectral-norm plans, BatchNorm statistics,
+    the CPU RNG stream (z draws, frame indices) over 3 steps = 51 generator and 24 discriminator forwards.
+
+Tolerances.  Losses at every backward: 1e-3 relative (north-star bound).  Gradients at the LAST optimiser step of each network
+(i.e. after the state has evolved through the previous updates): the cotangent is well conditioned here (no sign() term), so
+every compared tensor - generator included - is held to 1e-3 of its max magnitude in f32 (5e-3 in bf16x3: ~2^-16 per product,
+amplified through three updates of both networks) and cosine >= 0.9999.  Parameters after the three steps are compared through
+their UPDATE (post - initial): Adam's normalised step m^/(sqrt(v^)+eps) is O(lr) for every element, including those whose gradient
+is rounding noise, so elementwise equality is not defined for noise elements; required: cosine(update, reference update) >= 0.98 and
+no element further than the largest possible disagreement (2.2 * lr * updates).  Buffers (u / v / running statistics): 1e-3 of max.
+"""
+import json
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def _golden(name):
+    rec, meta = load_golden(name)
+    return rec, json.loads(meta["keys"]), json.loads(meta["kw"])
+
+
+def _is_param(k):
+    return not k.endswith(("._u", "._v", "running_mean", "running_var", "num_batches_tracked"))
+
+
+def _checksums(sd, keys):
+    vals = torch.zeros(len(keys), 4, dtype=torch.float64)
+    for i, k in enumerate(keys):
+        t = sd[k].detach().double().flatten().cpu()
+        vals[i, 0], vals[i, 1], vals[i, 2], vals[i, 3] = t.sum(), t.abs().sum(), t[0], t[-1]
+    return vals
+
+
+def _model_kwargs(kw):
+    return {k: v for k, v in kw.items()}
+
+
+def _check_losses(got, ref, what):
+    assert len(got) == len(ref), (what, got, ref)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert abs(g - r) <= 1e-4 + 1e-3 * abs(r), f"{what}[{i}]: {g} vs {r}  (all: {got} vs {ref})"
+
+
+def _check_grads(grads, rec, tol):
+    n = 0
+    for k, ref in rec.items():
+        if not k.startswith("grad."):
+            continue
+        assert k[5:] in grads, f"{k}: parameter received no gradient"
+        got = grads[k[5:]].detach().cpu().float().reshape(ref.shape)
+        scale = ref.abs().max().item()
+        err = (got - ref).abs().max().item()
+        assert err <= tol * scale + 1e-9, f"{k}: grad abs err {err:.3e} at scale {scale:.3e} (tol {tol})"
+        if scale > 0 and ref.numel() > 1:
+            cos = torch.nn.functional.cosine_similarity(got.flatten().double(), ref.flatten().double(), dim=0).item()
+            assert cos >= 0.9999, f"{k}: cosine {cos}"
+        n += 1
+    assert n >= 15, n
+
+
+def _check_post(sd0, sd1, rec, keys, kw, steps):
+    lr = {"generator.": kw["gen_lr"], "discriminator.": kw["disc_lr"]}
+    updates = {"generator.": steps, "discriminator.": 2 * steps}
+    for k, ref in rec.items():
+        if not k.startswith("post."):
+            continue
+        name = k[5:]
+        got = sd1[name].detach().cpu().float()
+        if _is_param(name):
+            net = "generator." if name.startswith("generator.") else "discriminator."
+            d_ref, d_got = (ref - sd0[name]).double().flatten(), (got - sd0[name]).double().flatten()
+            cos = torch.nn.functional.cosine_similarity(d_got, d_ref, dim=0).item()
+            assert cos >= 0.98, f"{k}: update cosine {cos}"
+            assert (d_got - d_ref).abs().max().item() <= 2.2 * lr[net] * updates[net], k
+        else:
+            scale = ref.abs().max().item()
+            assert (got - ref).abs().max().item() <= 1e-3 * scale + 1e-6, k
+    # fingerprints of every tensor: abs-sum within what the updates can move it (parameters) / 2e-3 (buffers)
+    cs, ref = _checksums(sd1, keys), rec["cs1"]
+    for i, k in enumerate(keys):
+        if _is_param(k):
+            net = "generator." if k.startswith("generator.") else "discriminator."
+            tol = 0.05 * 2.2 * lr[net] * updates[net] * sd1[k].numel() + 1e-4 * ref[i, 1].item() + 1e-6
+        else:
+            tol = 2e-3 * ref[i, 1].item() + 1e-5
+        assert abs(cs[i, 1].item() - ref[i, 1].item()) <= tol, f"{k}: abs-sum {cs[i, 1].item()} vs {ref[i, 1].item()}"
+
+
+def _oracle_hp(kw):
+    return dict(forecast_steps=kw["forecast_steps"], generation_steps=kw["generation_steps"], grid_lambda=kw.get("grid_lambda", 20.0),
+                gen_lr=kw.get("gen_lr", 5e-5), disc_lr=kw.get("disc_lr", 2e-4), beta1=kw.get("beta1", 0.0), beta2=0.999,
+                precip_weight_cap=24.0, latent_shape=(8, 4, 4), num_spatial_frames=8)
+
+
+def test_oracle_training_steps_adv_match_reference():
+    """Pins oracle.training_step over several steps with beta1 != 0 and an active adversarial term."""
+    import skillful_nowcasting_amd as S
+    from oracle import dgmr_oracle as O
+
+    rec, keys, kw = _golden("training_steps_adv")
+    torch.manual_seed(42)
+    model = S.DGMR(**_model_kwargs(kw))
+    full = model.state_dict()
+    assert torch.equal(_checksums(full, keys), rec["cs0"])
+    sd0 = {k: v.detach().clone() for k, v in full.items()}
+    sd = {k: v.detach().clone().contiguous() for k, v in full.items() if k.startswith(("generator.", "discriminator."))}
+    opt = {"step": {}, "m": {}, "v": {}}
+    torch.manual_seed(44)
+    got = []
+    for _ in range(rec["losses"].shape[0]):
+        got.append(O.training_step(sd, rec["images"], rec["future"], _oracle_hp(kw), opt))
+    ref = rec["losses"].tolist()
+    for (d, g, grid), r in zip(got, ref):
+        _check_losses([d, g, grid], r, "logged")
+    sd1 = {k: sd.get(k, sd.get("generator." + k)) for k in keys}
+    _check_post(sd0, sd1, rec, keys, kw, len(ref))
+
+
+def test_oracle_validation_step_matches_reference():
+    import skillful_nowcasting_amd as S
+    from oracle import dgmr_oracle as O
+
+    rec, keys, kw = _golden("validation_step")
+    for mode in ("eval", "train"):
+        torch.manual_seed(42)
+        model = S.DGMR(**kw)
+        full = model.state_dict()
+        sd = {k: v.detach().clone().contiguous() for k, v in full.items() if k.startswith(("generator.", "discriminator."))}
+        torch.manual_seed(45)
+        got = O.validation_step(sd, rec["images"], rec["future"], _oracle_hp(kw), train=(mode == "train"))
+        _check_losses(list(got), rec[f"{mode}.losses"].tolist(), f"validation[{mode}]")
+        if mode == "train":
+            sd1 = {k: sd.get(k, sd.get("generator." + k)) for k in keys}
+            cs, ref = _checksums(sd1, keys), rec["train.cs1"]
+            for i, k in enumerate(keys):
+                if not _is_param(k):
+                    assert abs(cs[i, 1].item() - ref[i, 1].item()) <= 2e-3 * ref[i, 1].item() + 1e-5, k
+
+
+def _snapshot_grads(opt, named, prefix, store, want_call):
+    orig = opt.step
+    n = {"calls": 0}
+
+    def step(*a, **k):
+        n["calls"] += 1
+        if n["calls"] == want_call:
+            for kk, p in named.items():
+                if kk.startswith(prefix) and p.grad is not None:
+                    store[kk] = p.grad.detach().clone()
+        return orig(*a, **k)
+
+    opt.step = step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,grad_tol", [("f32", 1e-3), ("bf16x3", 5e-3)])
+def test_hip_training_steps_adv_match_reference(precision, grad_tol):
+    import skillful_nowcasting_amd as S
+
+    rec, keys, kw = _golden("training_steps_adv")
+    steps = rec["losses"].shape[0]
+    S.set_precision(precision)
+    try:
+        torch.manual_seed(42)
+        model = S.DGMR(**_model_kwargs(kw))
+        sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model = model.to("cuda")
+        bw = []
+        orig = model.manual_backward
+        model.manual_backward = lambda loss: (bw.append(loss.detach()), orig(loss))
+        grads = {}
+        named = {("generator." + k if not k.startswith("discriminator.") else k): p for k, p in model.named_parameters()}
+        g_opt, d_opt = model.optimizers()
+        _snapshot_grads(g_opt, named, "generator.", grads, steps)
+        _snapshot_grads(d_opt, named, "discriminator.", grads, 2 * steps)
+        torch.manual_seed(44)
+        outs = []
+        for i in range(steps):
+            outs.append(model.training_step((rec["images"].cuda(), rec["future"].cuda()), i))
+        torch.cuda.synchronize()
+    finally:
+        S.set_precision("f32")
+    _check_losses([float(x) for x in bw], rec["backward_losses"].tolist(), "backward losses")
+    for o, r in zip(outs, rec["losses"].tolist()):
+        _check_losses([float(o["d_loss"]), float(o["g_loss"]), float(o["grid_loss"])], r, "returned losses")
+    _check_grads(grads, rec, grad_tol)
+    _check_post(sd0, model.state_dict(), rec, keys, kw, steps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_hip_validation_step_matches_reference(mode):
+    """dgmr/dgmr.py:220-290: the logged validation losses (eval mode = how Lightning validates; train mode additionally moves the
+    buffers, whose fingerprints are compared)."""
+    import skillful_nowcasting_amd as S
+
+    rec, keys, kw = _golden("validation_step")
+    torch.manual_seed(42)
+    model = S.DGMR(**kw).to("cuda")
+    model.train(mode == "train")
+    torch.manual_seed(45)
+    out = model.validation_step((rec["images"].cuda(), rec["future"].cuda()), 0)
+    torch.cuda.synchronize()
+    _check_losses([float(out["d_loss"]), float(out["g_loss"]), float(out["grid_loss"])], rec[f"{mode}.losses"].tolist(), f"validation[{mode}]")
+    logged = {k: float(v) for k, v in model.logged_metrics.items()} if hasattr(model, "logged_metrics") else None
+    if logged is not None:
+        assert set(logged) == {"val/d_loss", "val/g_loss", "val/grid_loss"}
+    cs, ref = _checksums(model.state_dict(), keys), rec[f"{mode}.cs1"]
+    for i, k in enumerate(keys):
+        if not _is_param(k):
+            assert abs(cs[i, 1].item() - ref[i, 1].item()) <= 2e-3 * ref[i, 1].item() + 1e-5, k
+        else:  # validation never touches a parameter
+            assert cs[i, 1].item() == pytest.approx(ref[i, 1].item(), rel=1e-6, abs=1e-6), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("betas", [(0.0, 0.999), (0.5, 0.999), (0.9, 0.99)])
+def test_fused_adam_matches_torch_adam(betas):
+    """optim.FusedAdam / adam_kernel vs torch.optim.Adam (the optimiser the reference constructs, dgmr/dgmr.py:292-300) over six
+    steps with changing gradients: first and second moments, both bias corrections, eps placement."""
+    from skillful_nowcasting_amd.optim import FusedAdam
+
+    torch.manual_seed(7)
+    shapes = [(33,), (8, 4, 3, 3), (5, 7)]
+    p_ref = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+    p_ref[1].data = p_ref[1].data.contiguous(memory_format=torch.channels_last)
+    p_got = [p.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for p in p_ref]
+    ref = torch.optim.Adam(p_ref, lr=3e-3, betas=betas)
+    got = FusedAdam(p_got, lr=3e-3, betas=betas)
+    for step in range(6):
+        for a, b in zip(p_ref, p_got):
+            g = torch.randn_like(a) * (10.0 ** (step % 3 - 1))
+            if step == 2:
+                g = g * (torch.rand_like(g) > 0.5)  # exact zeros in the gradient
+            a.grad, b.grad = g.clone(memory_format=torch.preserve_format), g.clone(memory_format=torch.preserve_format)
+        ref.step()
+        got.step()
+        for a, b in zip(p_ref, p_got):
+            assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item()), (betas, step)
+    for a, b in zip(p_ref, p_got):
+        sa, sb = ref.state[a], got.state[b]
+        assert int(sa["step"]) == sb["step"]
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-9)
