@@ -119,7 +119,66 @@ def test_tune_and_small_op_argument_checks(lib):
     assert lib.dgmr_conv_tune(-1, -1, -1, -1) == 0
     buf = (ctypes.c_float * 8)()
     assert lib.dgmr_repeat_rows(buf, buf, 6, 2, None) < 0 and b"multiple of 4" in lib.dgmr_last_error()
-    assert lib.dgmr_group_rowsum(buf, None, buf, 1, 2, 6, 1, None) < 0 and b"multiple of 4" in lib.dgmr_last_error()
+    assert lib.dgmr_group_rowsum(buf, None, buf, 1, 2, 6, 1, 1, None) < 0 and b"multiple of 4" in lib.dgmr_last_error()
+    assert lib.dgmr_repeat_interleave(buf, buf, 2, 6, 2, None) < 0 and b"multiple of 4" in lib.dgmr_last_error()
+
+
+def test_wgrad_plan_with_batched_draw_groups(lib):
+    """6 generator draws x 18 forecast steps = 108 call groups per launch (the batched generator pass): at least one slab per
+    group, for the window kernel and for the im2col kernels."""
+    from skillful_nowcasting_amd._lib import WgradArgs
+
+    try:
+        for prec in (0, 1):
+            assert lib.dgmr_set_precision(prec) == 0
+            for (n, h, w, cin, cout, k) in [(1728, 128, 128, 96, 96, 3), (1728, 8, 8, 768, 768, 3), (1728, 64, 64, 96, 192, 1),
+                                            (108, 8, 8, 768, 384, 3)]:
+                a = WgradArgs()
+                a.N, a.D, a.H, a.W, a.Cin, a.Cout = n, 1, h, w, cin, cout
+                a.KD, a.KH, a.KW = 1, k, k
+                a.groups, a.pre_group = 108, 1
+                assert lib.dgmr_conv_wgrad_plan(ctypes.byref(a)) == 0
+                assert a.nsplit >= 108 and a.nsplit % 108 == 0 and a.nsplit <= 4096, (prec, n, h, w, cin, cout, k, a.nsplit)
+    finally:
+        lib.dgmr_set_precision(0)
+
+
+def test_lds_dma_stages_are_drained_before_their_barrier(lib, tmp_path):
+    """conv_win_glds.h publishes every weight stage written by global_load_lds (an LDS write tracked only by the issuing wave's
+    vmcnt) with `s_waitcnt vmcnt(0)` + barrier.  The wait is explicit in the source (dma_drain); this checks the BINARY: walking
+    back from every s_barrier of every conv3x3_glds_kernel instantiation, an s_waitcnt with vmcnt(0) must come before any
+    global_load_lds is met (a compiler or flag change that dropped or moved the wait would race silently)."""
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    from skillful_nowcasting_amd import _lib
+
+    so = tmp_path / "libdgmr_hip.so"
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], check=True, cwd=tmp_path, capture_output=True)
+    bundles = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert bundles, os.listdir(tmp_path)
+    checked = 0
+    for bname in bundles:
+        asm = subprocess.run([objdump, "-d", str(tmp_path / bname)], check=True, capture_output=True, text=True).stdout.split("\n")
+        heads = [i for i, l in enumerate(asm) if l.endswith(">:")]
+        for hi, start in enumerate(heads):
+            if "conv3x3_glds_kernel" not in asm[start]:
+                continue
+            body = asm[start:heads[hi + 1] if hi + 1 < len(heads) else len(asm)]
+            assert any("global_load_lds_dwordx4" in l for l in body), asm[start]
+            for b in [i for i, l in enumerate(body) if "s_barrier" in l]:
+                j = b - 1
+                while j >= 0 and "s_barrier" not in body[j]:
+                    assert "global_load_lds" not in body[j], f"{asm[start]}: LDS-DMA reaches the barrier at +{b} without vmcnt(0)"
+                    if re.search(r"s_waitcnt.*vmcnt\(0\)", body[j]):
+                        break
+                    j -= 1
+                checked += 1
+    assert checked >= 30, checked  # three instantiations x (1 + 9 + 1) barriers
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -8,7 +8,11 @@ def _modules():
     from skillful_nowcasting_amd.nn import SNConv, SNLinear1
 
     torch.manual_seed(0)
-    return [(SNConv(8, 16, 3), 4), (SNConv(16, 8, 1), 1), (SNLinear1(32), 3), (SNConv(4, 12, 3, ndim=3), 2)]
+    from skillful_nowcasting_amd.ops import CallLayout
+
+    # (module, calls, call layout): the first stands for a sampler conv under 2 batched generator draws x 2 forecast steps
+    return [(SNConv(8, 16, 3), 4, CallLayout(2, 2, time_major=True)), (SNConv(16, 8, 1), 1, None), (SNLinear1(32), 3, None),
+            (SNConv(4, 12, 3, ndim=3), 2, None)]
 
 
 def test_plan_layout_is_disjoint_and_complete():
@@ -21,7 +25,9 @@ def test_plan_layout_is_disjoint_and_complete():
     descs = (SNDesc * len(entries)).from_buffer_copy(raw)
     used = []
     rows = cols = 0
-    for d, (m, calls) in zip(descs, entries):
+    assert descs[0].perm == plan.perms[0].data_ptr() and plan.perms[0].tolist() == [0, 2, 1, 3]
+    assert all(d.perm is None for d in descs[1:])
+    for d, (m, calls, _) in zip(descs, entries):
         w = m.weight_orig
         cout, cin = w.shape[0], w.shape[1]
         taps = w.numel() // (cout * cin)
@@ -67,3 +73,19 @@ def test_scope_is_noop_in_eval_and_traces_in_train():
     with SNScope(owner, "k") as sc:
         assert not sc.noop and SNScope._active is sc and sc.trace == []
     assert SNScope._active is None
+
+
+def test_call_layout_slots():
+    """ops.CallLayout: which group of a batched launch each call of the reference's sequence is."""
+    from skillful_nowcasting_amd.ops import CallLayout
+
+    # 3 draws x 2 steps, groups [step][draw]; reference order: draw-major
+    assert CallLayout(3, 2, time_major=True).slots() == [0, 3, 1, 4, 2, 5]
+    # checkpoint recompute: draws visited last-to-first
+    assert CallLayout(3, 2, time_major=True, reverse=True).slots() == [2, 5, 1, 4, 0, 3]
+    # context stack: groups [draw][step] are already in call order
+    assert CallLayout(3, 2, time_major=False).is_identity()
+    assert CallLayout(3, 2, time_major=False, reverse=True).slots() == [4, 5, 2, 3, 0, 1]
+    assert CallLayout(1, 5).is_identity() and CallLayout(4, 1).is_identity() and CallLayout(1, 5, reverse=True).is_identity()
+    for lay in (CallLayout(6, 18), CallLayout(6, 18, reverse=True), CallLayout(6, 4, time_major=False, reverse=True)):
+        assert sorted(lay.slots()) == list(range(lay.calls))

@@ -14,7 +14,7 @@ rocm-smi --showproductname 2>/dev/null | head -8 > "$OUT/device.txt"
 nproc > "$OUT/host_cores.txt"; lscpu | grep -E "Model name|^CPU\(s\)" >> "$OUT/host_cores.txt"
 
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 1200 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+  timeout 1500 python -m pytest tests -m gpu ${PYTEST_FLAGS:--x -q} > "$OUT/pytest_gpu.log" 2>&1
   echo "pytest rc=$?" | tee -a "$OUT/pytest_gpu.log"
   tail -5 "$OUT/pytest_gpu.log"
 fi
