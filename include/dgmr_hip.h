@@ -331,7 +331,9 @@ int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_stride, const fl
 /* ------------------------------------------------------------------------------------------------
  * Adam — torch.optim.Adam as constructed at dgmr/dgmr.py:292-300 (eps 1e-8, no weight decay, no amsgrad).
  * ---------------------------------------------------------------------------------------------- */
-int dgmr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+/* Hyper-parameters travel as doubles: torch forms 1 - beta, lr / (1 - beta1^step) and sqrt(1 - beta2^step) in double and rounds
+ * each to float once; the kernel does the same (lerp for the first moment, as torch's foreach implementation). */
+int dgmr_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
               int step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -252,26 +252,21 @@ def training_step_golden():
 
 ADV_HP = dict(grid_lambda=0.0, beta1=0.5, disc_lr=2e-6, gen_lr=5e-6)
 ADV_STEPS = 3
+ADV_BATCH = 2
 
 
-def training_steps_adv_golden():
-    """THREE consecutive `DGMR.training_step`s with a visible adversarial path (dgmr/dgmr.py:137-218).
-
-    In the default-hyper-parameter golden above, 20 * grid_cell_reg ~ 1e11 swamps loss_hinge_gen by ten orders of magnitude and the
-    second D pass saturates the hinge, so the chain  hinge_gen -> discriminator data gradient -> generator  is invisible there.
-    Here grid_lambda = 0 (the generator's gradient is purely adversarial and well conditioned: no sign() cotangent), the learning
-    rates are small enough that every hinge stays active over all six D updates, and beta1 = 0.5 with three steps exercises Adam's
-    first moment, both bias corrections (step 2..6 for D, 2..3 for G) and every weight-derived cache across optimiser updates.
-    """
+def _adv_run():
+    """One run of the 3-step adversarial schedule on the reference -> dict of tensors (see training_steps_adv_golden)."""
     from dgmr import DGMR
 
     torch.manual_seed(42)
     model = DGMR(**TS_KW, **ADV_HP)
     keys0, cs0 = checksums(model.state_dict())
     torch.manual_seed(43)
-    images, future = torch.rand(2, 4, 1, 128, 128), torch.rand(2, 2, 1, 128, 128)
+    images, future = torch.rand(ADV_BATCH, 4, 1, 128, 128), torch.rand(ADV_BATCH, 2, 1, 128, 128)
     logged = []
-    model.log_dict = lambda d, **k: logged.append([float(d["train/d_loss"]), float(d["train/g_loss"]), float(d["train/grid_loss"])])
+    model.log_dict = lambda d, **k: logged.append([float(d["train/d_loss"].detach()), float(d["train/g_loss"].detach()),
+                                                   float(d["train/grid_loss"].detach())])
     bw = []
     model.manual_backward = lambda loss: (bw.append(float(loss.detach())), loss.backward())
     g_opt, d_opt = model.optimizers()
@@ -315,11 +310,48 @@ def training_steps_adv_golden():
               "discriminator.temporal_discriminator.d1.first_conv_3x3.parametrizations.weight.original",
               "discriminator.spatial_discriminator.bn.running_var"]:
         rec["post." + k] = sd1[k].detach().clone().contiguous()
+    return rec, keys0
+
+
+def training_steps_adv_golden():
+    """THREE consecutive `DGMR.training_step`s with a visible adversarial path (dgmr/dgmr.py:137-218).
+
+    In the default-hyper-parameter golden above, 20 * grid_cell_reg ~ 1e11 swamps loss_hinge_gen by ten orders of magnitude and the
+    second D pass saturates the hinge, so the chain  hinge_gen -> discriminator data gradient -> generator  is invisible there.
+    Here grid_lambda = 0 (the generator's gradient is purely adversarial), the learning rates are small enough that every hinge stays
+    active over all six D updates, and beta1 = 0.5 with three steps exercises Adam's first moment, both bias corrections (step 2..6
+    for D, 2..3 for G) and every weight-derived cache across optimiser updates.
+
+    The reference's OWN reproducibility is recorded next to the values: the same run is repeated with 4 and 1 CPU threads (only the
+    fp32 summation order inside torch's kernels changes) and `noise.<key>` = the largest deviation from the stored run, relative to
+    the tensor's max magnitude (for `backward_losses`: relative per entry).  After three steps of both networks that band is 1e-3
+    ... 2e-2 for the discriminator's gradients and 5e-2 ... 3e-1 for the generator's deep layers (the adversarial gradient through
+    batch-statistics BatchNorm on 2-4 samples and ~1e5 ReLU boundaries is chaotic in fp32), so a test can only ask for agreement
+    within a multiple of it; the well-conditioned comparison of that chain is tests/test_gpu_adversarial.py (float64 anchor).
+    """
+    default_threads = torch.get_num_threads()
+    rec, keys0 = _adv_run()
+    noise = {}
+    for threads in (4, 1):
+        torch.set_num_threads(threads)
+        other, _ = _adv_run()
+        for k, r in rec.items():
+            if k.startswith("grad.") or k == "backward_losses":
+                if k == "backward_losses":
+                    dev = ((other[k] - r).abs() / r.abs()).max().item()
+                else:
+                    dev = (other[k] - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+                noise[k] = max(noise.get(k, 0.0), dev)
+    torch.set_num_threads(default_threads)
+    for k, v in noise.items():
+        rec["noise." + k] = torch.tensor(v, dtype=torch.float64)
+        print(f"  reference run-to-run band  {k:100s} {v:.2e}")
     hp = dict(TS_KW)
     hp.update(ADV_HP)
     save_file(rec, os.path.join(OUT, "training_steps_adv.safetensors"),
-              metadata={"keys": json.dumps(keys0), "kw": json.dumps(hp), "seeds": "[42, 43, 44]", "steps": str(ADV_STEPS)})
-    print("training_steps_adv golden: backward losses", bw)
+              metadata={"keys": json.dumps(keys0), "kw": json.dumps(hp), "seeds": "[42, 43, 44]", "steps": str(ADV_STEPS),
+                        "threads": str(default_threads)})
+    print("training_steps_adv golden: backward losses", rec["backward_losses"].tolist())
 
 
 def validation_step_golden():

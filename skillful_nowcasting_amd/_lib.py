@@ -100,7 +100,7 @@ SIGNATURES = {
     "dgmr_linear1_bwd": [P, P, P, P, P, P, P, i, i, i, P],
     "dgmr_hinge_disc": [P, P, P, P, P, i, i, P],
     "dgmr_grid_cell_loss": [P, i, L, P, P, f, P, P, f, P, L, P],
-    "dgmr_adam": [P, P, P, P, L, f, f, f, f, i, P],
+    "dgmr_adam": [P, P, P, P, L, c_double, c_double, c_double, c_double, i, P],
     "dgmr_split_weights": [P, P, L, i, i, i, P],
     "dgmr_set_precision": [i],
     "dgmr_get_precision": [],

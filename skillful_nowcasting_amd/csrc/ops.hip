@@ -1003,15 +1003,21 @@ __global__ void grid_cell_finish_kernel(double* __restrict__ acc, float* __restr
     acc[0] = 0.0;
 }
 
+// torch.optim.Adam's update, scalar for scalar (torch/optim/adam.py, _multi_tensor_adam): exp_avg.lerp_(grad, 1 - beta1);
+// exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2); denom = sqrt(exp_avg_sq) / sqrt(bias_correction2) + eps;
+// param.addcdiv_(exp_avg, denom, value = -lr / bias_correction1).  The scalars are formed in double on the host and rounded to
+// float once, as torch does (1 - 0.999 in float arithmetic is 4.7e-5 off).
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                            float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt) {
+                            float w1 /* 1 - beta1 */, float beta2, float w2 /* 1 - beta2 */, float eps, float step_size,
+                            float bc2_sqrt) {
     GRID_STRIDE(i, n) {
-        const float gi = g[i];
-        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        const float gi = g[i], m0 = m[i];
+        const float diff = gi - m0;
+        const float mi = w1 < 0.5f ? fmaf(w1, diff, m0) : gi - diff * (1.f - w1);  // at::lerp
+        const float vi = fmaf(w2 * gi, gi, beta2 * v[i]);
         m[i] = mi;
         v[i] = vi;
-        p[i] -= step_size * mi / (sqrtf(vi) * inv_bc2_sqrt + eps);
+        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
     }
 }
 
@@ -1381,15 +1387,14 @@ extern "C" int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_strid
     return 0;
 }
 
-extern "C" int dgmr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+extern "C" int dgmr_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                          int step, void* stream) {
     DGMR_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "dgmr_adam: bad args");
-    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float inv_bc2_sqrt = (float)(1.0 / std::sqrt(bc2));
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, p, g, m, v, n, beta1, beta2, eps, step_size,
-                       inv_bc2_sqrt);
+    DGMR_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "dgmr_adam: betas (%g, %g) out of [0, 1)", beta1, beta2);
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc2 = 1.0 - std::pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)std::sqrt(bc2));
     DGMR_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,87 @@
+"""The adversarial gradient path of the generator pass, isolated and float64-anchored (dgmr/dgmr.py:174-199 with grid_lambda = 0):
+
+    K generator draws -> K discriminator calls on cat(real, draw_k) -> loss_hinge_gen = -mean(scores of the generated halves)
+    -> backward through the discriminator's DATA gradient (6 x D dgrad in the paper step) into every generator weight.
+
+In the reference's default step this term is ten orders of magnitude below 20 * grid_cell_reg, and after a few optimiser steps the
+generator's deep-layer adversarial gradient is not even reproducible by the reference itself (tests/golden/training_steps_adv:
+`noise.*`, 5e-2 ... 3e-1 between runs that differ only in CPU thread count).  From ONE fixed state, against the float64 oracle, it is
+a well-posed comparison: the HIP result must be as close to the float64 gradient as the fp32 oracle is (conftest.band_check).
+"""
+import pytest
+import torch
+
+from conftest import band_check
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(forecast_steps=2, output_shape=128, latent_channels=384, context_channels=192, generation_steps=2, grid_lambda=0.0)
+G_KEYS = ["sampler.conv_1x1.bias", "sampler.bn.weight", "sampler.conv_1x1.parametrizations.weight.original",
+          "sampler.up_g4.first_conv_3x3.parametrizations.weight.original",
+          "sampler.up_g2.last_conv_3x3.parametrizations.weight.original",
+          "sampler.convGRU4.cell.output_conv.parametrizations.weight.original",
+          "sampler.convGRU1.cell.read_gate_conv.parametrizations.weight.original",
+          "sampler.gru_conv_1x1_3.parametrizations.weight.original", "sampler.g2.bn1.weight",
+          "latent_stack.conv_3x3.parametrizations.weight.original", "latent_stack.l_block1.first_conv_3x3.weight",
+          "latent_stack.att_block.gamma", "conditioning_stack.d1.first_conv_3x3.parametrizations.weight.original",
+          "conditioning_stack.conv1.parametrizations.weight.original"]
+
+
+def _oracle(O, sd_cpu, images, future, dt, k, seeds):
+    sd = {n: v.clone().to(dt) if v.is_floating_point() else v.clone() for n, v in sd_cpu.items()
+          if n.startswith(("generator.", "discriminator."))}
+    for n in G_KEYS:
+        sd["generator." + n].requires_grad_(True)
+    x, y = images.to(dt), future.to(dt)
+    b, T = x.shape[0], y.shape[1]
+    torch.manual_seed(seeds[0])
+    preds = [O.generator(sd, "generator.", x, O.draw_latent((8, 4, 4)).to(dt), T, True) for _ in range(k)]
+    real = torch.cat([x, y], dim=1)
+    torch.manual_seed(seeds[1])
+    scores = []
+    for p_ in preds:
+        idxs = torch.randint(low=0, high=4 + T, size=(8,)).tolist()
+        out = O.discriminator(sd, "discriminator.", torch.cat([real, torch.cat([x, p_], dim=1)], dim=0), idxs, True)
+        scores.append(out[b:])
+    loss = O.loss_hinge_gen(torch.cat(scores, dim=0))
+    loss.backward()
+    return loss.detach(), torch.cat(preds, 0).detach(), {n: sd["generator." + n].grad.clone() for n in G_KEYS}
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-3), ("bf16x3", 3e-3)])
+def test_hinge_gen_gradient_reaches_the_generator(precision, tol):
+    import skillful_nowcasting_amd as S
+    from oracle import dgmr_oracle as O
+
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    k, b = 2, 4
+    torch.manual_seed(42)
+    model = S.DGMR(strict_reference_semantics=False, **KW)  # no checkpointing: one forward graph, as the oracle builds it
+    with torch.no_grad():
+        model.generator.latent_stack.att_block.gamma.fill_(0.3)
+    sd_cpu = {n: v.detach().clone() for n, v in model.state_dict().items()}
+    torch.manual_seed(43)
+    images, future = torch.rand(b, 4, 1, 128, 128), torch.rand(b, 2, 1, 128, 128)
+    seeds = (51, 52)
+    l32, p32, g32 = _oracle(O, sd_cpu, images, future, torch.float32, k, seeds)
+    l64, p64, g64 = _oracle(O, sd_cpu, images, future, torch.float64, k, seeds)
+    model = model.to("cuda").train()
+    for p in model.discriminator.parameters():
+        p.requires_grad_(False)  # as in the generator pass of training_step
+    S.set_precision(precision)
+    try:
+        torch.manual_seed(seeds[0])
+        preds = model._generate(images.cuda(), k, grad=True)
+        torch.manual_seed(seeds[1])
+        loss, grid = model._gen_losses(images.cuda(), future.cuda(), preds)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        S.set_precision("f32")
+    named = dict(model.generator.named_parameters())
+    rows = {"predictions": (preds.detach().cpu(), p32, p64), "loss_hinge_gen": (loss.detach().cpu(), l32, l64)}
+    for n in G_KEYS:
+        assert named[n].grad is not None, n
+        rows["grad " + n] = (named[n].grad.detach().cpu().float().reshape(g64[n].shape), g32[n], g64[n])
+    assert float(grid) > 0  # computed, weighted by grid_lambda = 0
+    band_check("hinge_gen -> D data gradient -> generator", precision, tol, rows)

@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-KW = dict(forecast_steps=3, output_shape=64, latent_channels=128, context_channels=64, generation_steps=2)
+KW = dict(forecast_steps=3, output_shape=64, latent_channels=256, context_channels=128, generation_steps=2)
 BUF = ("._u", "._v", "running_mean", "running_var", "num_batches_tracked")
 
 

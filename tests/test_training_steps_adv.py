@@ -8,13 +8,18 @@ What this pins that tests/test_training_step.py cannot:
   * state evolution across optimiser updates: W W^T / flipped / split-plane caches, spectral-norm plans, BatchNorm statistics,
     the CPU RNG stream (z draws, frame indices) over 3 steps = 51 generator and 24 discriminator forwards.
 
-Tolerances.  Losses at every backward: 1e-3 relative (north-star bound).  Gradients at the LAST optimiser step of each network
-(i.e. after the state has evolved through the previous updates): the cotangent is well conditioned here (no sign() term), so
-every compared tensor - generator included - is held to 1e-3 of its max magnitude in f32 (5e-3 in bf16x3: ~2^-16 per product,
-amplified through three updates of both networks) and cosine >= 0.9999.  Parameters after the three steps are compared through
-their UPDATE (post - initial): Adam's normalised step m^/(sqrt(v^)+eps) is O(lr) for every element, including those whose gradient
-is rounding noise, so elementwise equality is not defined for noise elements; required: cosine(update, reference update) >= 0.98 and
-no element further than the largest possible disagreement (2.2 * lr * updates).  Buffers (u / v / running statistics): 1e-3 of max.
+Tolerances.  Losses at every backward: 1e-3 relative (north-star bound; the reference's own run-to-run band is 5e-4, see below).
+Gradients at the LAST optimiser step of each network: after three steps of both networks the reference cannot reproduce its own
+gradients to 1e-3 - the golden stores, per tensor, the largest deviation between runs of the UNMODIFIED reference that differ only in
+the CPU thread count (`noise.*`, oracle/gen_golden.py): 7e-4 ... 2e-2 for the discriminator's gradients, 2.5e-3 ... 1.4e-2 for the
+generator's last layer and 6e-2 ... 3.5e-1 for its deep layers (the adversarial gradient through batch-statistics BatchNorm and ~1e5
+ReLU boundaries is chaotic in fp32 once the trajectories have separated by rounding).  Each tensor is therefore held to
+max(1e-3, 3 x its reference band) of its max magnitude, and tensors whose band exceeds 5e-2 to a cosine >= 0.9 only; the
+well-conditioned test of the adversarial chain is tests/test_gpu_adversarial.py (float64 anchor, one backward from a fixed state).
+Parameters after the three steps are compared through their UPDATE (post - initial): Adam's normalised step m^/(sqrt(v^)+eps) is
+O(lr) for every element, including those whose gradient is rounding noise, so elementwise equality is not defined for noise
+elements; required: cosine(update, reference update) >= 0.98 and no element further than the largest possible disagreement
+(2.2 * lr * updates).  Buffers (u / v / running statistics): 1e-3 of max.
 """
 import json
 
@@ -52,20 +57,31 @@ def _check_losses(got, ref, what):
 
 
 def _check_grads(grads, rec, tol):
-    n = 0
+    """tol: floor of the relative bound; per tensor the bound is max(tol, 3 x the reference's own run-to-run band)."""
+    table, bad, n = [], [], 0
     for k, ref in rec.items():
         if not k.startswith("grad."):
             continue
         assert k[5:] in grads, f"{k}: parameter received no gradient"
         got = grads[k[5:]].detach().cpu().float().reshape(ref.shape)
         scale = ref.abs().max().item()
-        err = (got - ref).abs().max().item()
-        assert err <= tol * scale + 1e-9, f"{k}: grad abs err {err:.3e} at scale {scale:.3e} (tol {tol})"
-        if scale > 0 and ref.numel() > 1:
-            cos = torch.nn.functional.cosine_similarity(got.flatten().double(), ref.flatten().double(), dim=0).item()
-            assert cos >= 0.9999, f"{k}: cosine {cos}"
+        band = float(rec["noise." + k]) if "noise." + k in rec else 0.0
+        err = (got - ref).abs().max().item() / max(scale, 1e-30)
+        cos = torch.nn.functional.cosine_similarity(got.flatten().double(), ref.flatten().double(), dim=0).item() if ref.numel() > 1 else 1.0
+        if scale == 0.0:
+            ok = got.abs().max().item() <= 1e-6
+        elif band > 5e-2:  # the reference does not reproduce this tensor itself: direction only
+            ok = cos >= 0.9 or ref.numel() == 1
+        else:
+            ok = err <= max(tol, 3.0 * band) and 1.0 - cos <= max(1e-4, 30.0 * band * band)
+        table.append(f"  {k[5:]:96s} err {err:.2e}  reference band {band:.2e}  1-cos {1 - cos:.1e}  {'ok' if ok else 'FAIL'}")
+        if not ok:
+            bad.append(k)
         n += 1
+    msg = "\n".join(table)
+    print("\ngradients at the last optimiser step vs the reference golden:\n" + msg)
     assert n >= 15, n
+    assert not bad, f"beyond the bound: {bad}\n{msg}"
 
 
 def _check_post(sd0, sd1, rec, keys, kw, steps):

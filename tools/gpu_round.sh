@@ -28,7 +28,7 @@ fi
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   cd /tmp
   timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof" -o trace -- \
-      python "$ROOT/bench.py" "$@" --steps 1 --warmup 1 --cpu-baseline off --no-roofline > "$OUT/prof_run.log" 2>&1
+      python "$ROOT/bench.py" "$@" --steps 1 --warmup 1 --cpu-baseline off --no-roofline --also off > "$OUT/prof_run.log" 2>&1
   echo "rocprof rc=$?"
   cd "$ROOT"
   # keep only the summaries (the raw per-dispatch trace / sqlite db can be hundreds of MB; gpurun_out is capped at 64 MiB)
