@@ -211,7 +211,7 @@ def test_discriminator_fwd_bwd_paper_config(setup, precision, tol):
               if k.startswith("discriminator.")}
         for k in D_GRAD_KEYS:
             sd[k].requires_grad_(True)
-        s_ = seq.to(dt).requires_grad_(True)
+        s_ = seq.detach().clone().to(dt).requires_grad_(True)
         o = O.discriminator(sd, "", s_, idxs, True)
         (o * cot.to(dt)).sum().backward()
         ref[dt] = (o.detach(), {k: sd[k].grad.clone() for k in D_GRAD_KEYS}, s_.grad.clone())
@@ -220,7 +220,7 @@ def test_discriminator_fwd_bwd_paper_config(setup, precision, tol):
     model.train()
     for p in model.parameters():
         p.grad = None
-    seq_dev = seq.cuda().requires_grad_(True)
+    seq_dev = seq.detach().clone().cuda().requires_grad_(True)
     S.set_precision(precision)
     try:
         torch.manual_seed(3)
@@ -290,7 +290,7 @@ def test_generator_forward_cfg5_512(setup):
     x = torch.rand(1, 4, 1, 512, 512)
     torch.manual_seed(1)
     z = O.draw_latent((8, 16, 16))
-    ref = O.generator(sd_cpu, "", x, z, 18, True)
+    ref = O.generator({k: v.clone() for k, v in sd_cpu.items()}, "", x, z, 18, True)  # (the oracle advances u / v / BN in its dict)
     for precision in ("f32", "bf16x3"):
         model.load_state_dict({**model.state_dict(), **{"generator." + k: v for k, v in sd_cpu.items()}}, strict=False)
         S.ops.bump_weights_epoch()
@@ -325,7 +325,7 @@ def test_cfg2_bf16_forward_and_step():
     x, y = torch.rand(2, 4, 1, 256, 256), torch.rand(2, 4, 1, 256, 256)
     torch.manual_seed(1)
     z = O.draw_latent((8, 8, 8))
-    ref = O.generator(sd_cpu, "", x, z, 4, True)
+    ref = O.generator({k: v.clone() for k, v in sd_cpu.items()}, "", x, z, 4, True)
     losses = {}
     for precision in ("bf16", "f32"):
         model.load_state_dict(sd0)

@@ -1,7 +1,7 @@
 """Stage-by-stage parity of the generator forward against the oracle at the 512 x 512 stress configuration (BASELINE.json
 configs[4]) and at the paper configuration: context stack (4 scales), latent stack, and inside the sampler every ConvGRU / 1x1 /
 G-block / upsampling G-block output of the four levels.  A whole-model bound cannot say WHERE a size-dependent kernel path goes
-wrong; this one does (every stage's error is listed in the failure message).  Exact f32 arithmetic, 1e-3 of each stage's max.
+wrong; this one does (every stage's error is listed in the failure message).  Exact f32 and bf16x3 arithmetic: 1e-3 of each stage's max.
 """
 import pytest
 import torch
@@ -65,8 +65,11 @@ def _hip_stages(gen, x, z, T):
     return st
 
 
-@pytest.mark.parametrize("size,T", [(512, 18), (256, 18)])
-def test_generator_stages_match_oracle(size, T):
+@pytest.mark.parametrize("size,T,precision,tol", [(512, 18, "f32", 1e-3), (256, 18, "f32", 1e-3), (256, 18, "bf16x3", 1e-3),
+                                                  (512, 18, "bf16x3", 1e-3), (256, 18, "bf16", 3e-1)])
+def test_generator_stages_match_oracle(size, T, precision, tol):
+    """`bf16` (operands rounded to 8 mantissa bits) is listed to show HOW its error grows through the stack (smoothly, ~1.3x per
+    stage - precision, not a defect of one kernel path); its bound is what that growth reaches at the output."""
     import skillful_nowcasting_amd as S
     from oracle import dgmr_oracle as O
 
@@ -80,16 +83,21 @@ def test_generator_stages_match_oracle(size, T):
     x = torch.rand(1, 4, 1, size, size)
     torch.manual_seed(1)
     z = O.draw_latent((8, size // 32, size // 32))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
     with torch.no_grad():
         ref = _oracle_stages(O, sd, x, z, T)
-        got = _hip_stages(model.generator, x.cuda(), z.cuda(), T)
-    torch.cuda.synchronize()
+        S.set_precision(precision)
+        try:
+            got = _hip_stages(model.generator, x.cuda(), z.cuda(), T)
+            torch.cuda.synchronize()
+        finally:
+            S.set_precision("f32")
     errs = {}
     for k, r in ref.items():
         g = got[k].detach().float().cpu()
         assert tuple(g.shape) == tuple(r.shape), (k, g.shape, r.shape)
         errs[k] = (g - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
     table = "\n".join(f"  {k:18s} {e:.3e}" for k, e in errs.items())
-    print(f"\nstage errors at {size}x{size}:\n{table}")
-    bad = {k: e for k, e in errs.items() if not e <= 1e-3}
-    assert not bad, f"stages beyond 1e-3 at {size}x{size}:\n{table}"
+    print(f"\nstage errors at {size}x{size} [{precision}]:\n{table}")
+    bad = {k: e for k, e in errs.items() if not e <= tol}
+    assert not bad, f"stages beyond {tol} at {size}x{size} [{precision}]:\n{table}"

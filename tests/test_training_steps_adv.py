@@ -14,7 +14,8 @@ gradients to 1e-3 - the golden stores, per tensor, the largest deviation between
 the CPU thread count (`noise.*`, oracle/gen_golden.py): 7e-4 ... 2e-2 for the discriminator's gradients, 2.5e-3 ... 1.4e-2 for the
 generator's last layer and 6e-2 ... 3.5e-1 for its deep layers (the adversarial gradient through batch-statistics BatchNorm and ~1e5
 ReLU boundaries is chaotic in fp32 once the trajectories have separated by rounding).  Each tensor is therefore held to
-max(1e-3, 3 x its reference band) of its max magnitude, and tensors whose band exceeds 5e-2 to a cosine >= 0.9 only; the
+max(1e-3, 3 x its reference band) of its max magnitude (bf16x3: 10 x), and tensors whose band exceeds 5e-2 to a cosine >= 0.9
+(0.8) only; the
 well-conditioned test of the adversarial chain is tests/test_gpu_adversarial.py (float64 anchor, one backward from a fixed state).
 Parameters after the three steps are compared through their UPDATE (post - initial): Adam's normalised step m^/(sqrt(v^)+eps) is
 O(lr) for every element, including those whose gradient is rounding noise, so elementwise equality is not defined for noise
@@ -56,8 +57,8 @@ def _check_losses(got, ref, what):
         assert abs(g - r) <= 1e-4 + 1e-3 * abs(r), f"{what}[{i}]: {g} vs {r}  (all: {got} vs {ref})"
 
 
-def _check_grads(grads, rec, tol):
-    """tol: floor of the relative bound; per tensor the bound is max(tol, 3 x the reference's own run-to-run band)."""
+def _check_grads(grads, rec, tol, factor=3.0, chaotic_cos=0.9):
+    """tol: floor of the relative bound; per tensor the bound is max(tol, factor x the reference's own run-to-run band)."""
     table, bad, n = [], [], 0
     for k, ref in rec.items():
         if not k.startswith("grad."):
@@ -71,9 +72,9 @@ def _check_grads(grads, rec, tol):
         if scale == 0.0:
             ok = got.abs().max().item() <= 1e-6
         elif band > 5e-2:  # the reference does not reproduce this tensor itself: direction only
-            ok = cos >= 0.9 or ref.numel() == 1
+            ok = cos >= chaotic_cos or ref.numel() == 1
         else:
-            ok = err <= max(tol, 3.0 * band) and 1.0 - cos <= max(1e-4, 30.0 * band * band)
+            ok = err <= max(tol, factor * band) and 1.0 - cos <= max(1e-4, 10.0 * factor * band * band)
         table.append(f"  {k[5:]:96s} err {err:.2e}  reference band {band:.2e}  1-cos {1 - cos:.1e}  {'ok' if ok else 'FAIL'}")
         if not ok:
             bad.append(k)
@@ -209,7 +210,8 @@ def test_hip_training_steps_adv_match_reference(precision, grad_tol):
     _check_losses([float(x) for x in bw], rec["backward_losses"].tolist(), "backward losses")
     for o, r in zip(outs, rec["losses"].tolist()):
         _check_losses([float(o["d_loss"]), float(o["g_loss"]), float(o["grid_loss"])], r, "returned losses")
-    _check_grads(grads, rec, grad_tol)
+    # bf16x3: 16-bit products; measured 1.5 ... 6 x the reference's own band (f32: 0.6 ... 1.6 x), see conftest.band_check
+    _check_grads(grads, rec, grad_tol, *((3.0, 0.9) if precision == "f32" else (10.0, 0.8)))
     _check_post(sd0, model.state_dict(), rec, keys, kw, steps)
 
 

@@ -28,15 +28,18 @@ fi
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   cd /tmp
   timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof" -o trace -- \
-      python "$ROOT/bench.py" "$@" --steps 1 --warmup 1 --cpu-baseline off --no-roofline --also off > "$OUT/prof_run.log" 2>&1
+      python "$ROOT/bench.py" "$@" --steps 1 --warmup 2 --cpu-baseline off --no-roofline --also off > "$OUT/prof_run.log" 2>&1
   echo "rocprof rc=$?"
   cd "$ROOT"
   # keep only the summaries (the raw per-dispatch trace / sqlite db can be hundreds of MB; gpurun_out is capped at 64 MiB)
   mkdir -p "$OUT/prof_keep"
   find "$OUT/prof" -name '*stats*.csv' -exec cp {} "$OUT/prof_keep/" \;
   KT=$(find "$OUT/prof" -name '*kernel_trace.csv' | head -1)
-  [ -n "$KT" ] && python tools/trace_by_grid.py "$KT" "$OUT/prof_keep/kernel_by_grid.csv" && head -3 "$KT" > "$OUT/prof_keep/kernel_trace_head.csv"
-  [ -n "$KT" ] && python tools/trace_gaps.py "$KT" "$OUT/prof_keep/kernel_gaps.txt" 20 ${GAPS_LAST_MS:-0}
+  # steady state = the last step of the run: window = its ms_per_step as bench.py reported it under the profiler (+2 %)
+  LAST_MS=${GAPS_LAST_MS:-$(python -c "import json,sys; print(1.02*json.loads([l for l in open('$OUT/prof_run.log') if l.startswith('{')][-1])['ms_per_step'])" 2>/dev/null || echo 0)}
+  echo "steady-state window: $LAST_MS ms"
+  [ -n "$KT" ] && python tools/trace_by_grid.py "$KT" "$OUT/prof_keep/kernel_by_grid.csv" $LAST_MS "$OUT/prof_keep/kernel_stats_last_step.csv" && head -3 "$KT" > "$OUT/prof_keep/kernel_trace_head.csv"
+  [ -n "$KT" ] && python tools/trace_gaps.py "$KT" "$OUT/prof_keep/kernel_gaps.txt" 20 $LAST_MS
   rm -rf "$OUT/prof"
   ls -la "$OUT/prof_keep"
 fi
