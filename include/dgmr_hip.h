@@ -178,8 +178,9 @@ int dgmr_spectral_sigma_seq(const float* w, const float* gram, float* u, float* 
 /* The same for many modules at once: every spectral-norm call sequence of one generator / discriminator forward in three
  * launches (the iterations do not depend on activations; the chains of all modules run concurrently, one workgroup each).
  * descs: DEVICE array of n descriptors.  Outputs live in one caller-allocated float arena (offsets in floats):
- * inv_sigma[T], u_hist[T][Cout], v_hist[T][K], tmp[Cout + T].  row_block0 / col_block0: exclusive prefix sums of Cout and of
- * ceil(K/64) over the descriptors; the totals are passed alongside.  max_cout: largest Cout (sizes the chain kernel's LDS). */
+ * inv_sigma[T], u_hist[T][Cout], v_hist[T][K], tmp[3*Cout + T].  row_block0 / col_block0 / iter_block0: exclusive prefix sums of
+ * Cout, of ceil(K/64) and of ceil(Cout/32) over the descriptors; the totals are passed alongside.  max_cout: largest Cout (sizes
+ * the iteration kernel's LDS), max_T: largest T (the chain runs as max_T + 1 launches, one power iteration of every module each). */
 typedef struct dgmr_sn_desc {
     const float* w;
     const float* gram;
@@ -191,15 +192,15 @@ typedef struct dgmr_sn_desc {
     int64_t tmp_off;
     int32_t Cout, Cin, taps, T;
     float eps;
-    int32_t row_block0, col_block0, reserved;
+    int32_t row_block0, col_block0, iter_block0;
     /* perm[t] (DEVICE array of T ints, or NULL = identity): the group ("slot") of the batched launch that the t-th call of the
      * sequence belongs to.  inv_sigma / u_hist / v_hist are written at slot perm[t]; the module's u, v end at the LAST call's.
      * Batched generator draws run the calls (draw d, step t) as groups [t][d] of one batch while the reference's call order is
      * draw-major (and draw-reversed in the activation-checkpoint recompute, dgmr/dgmr.py:176). */
     const int32_t* perm;
 } dgmr_sn_desc;
-int dgmr_spectral_sigma_seq_multi(const dgmr_sn_desc* descs_dev, int n, int total_row_blocks, int total_col_blocks, int max_cout,
-                                  float* arena, void* stream);
+int dgmr_spectral_sigma_seq_multi(const dgmr_sn_desc* descs_dev, int n, int total_row_blocks, int total_col_blocks,
+                                  int total_iter_blocks, int max_cout, int max_T, float* arena, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-channel reductions / BatchNorm — torch.nn.BatchNorm2d (common.py:38-39,108-109; generators.py:113)

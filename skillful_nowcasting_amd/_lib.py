@@ -49,7 +49,7 @@ class SNDesc(Structure):
         ("w", P), ("gram", P), ("u", P), ("v", P),
         ("inv_sigma_off", c_int64), ("u_hist_off", c_int64), ("v_hist_off", c_int64), ("tmp_off", c_int64),
         ("Cout", c_int32), ("Cin", c_int32), ("taps", c_int32), ("T", c_int32), ("eps", c_float),
-        ("row_block0", c_int32), ("col_block0", c_int32), ("reserved", c_int32), ("perm", P),
+        ("row_block0", c_int32), ("col_block0", c_int32), ("iter_block0", c_int32), ("perm", P),
     ]
 
 
@@ -66,7 +66,7 @@ SIGNATURES = {
     "dgmr_sn_wgrad_finalize": [P, P, P, P, P, P, i, i, i, i, i, P],
     "dgmr_spectral_sigma": [P, P, P, P, P, P, P, P, i, i, i, f, i, P],
     "dgmr_spectral_sigma_seq": [P, P, P, P, P, P, P, P, P, i, i, i, f, i, P],
-    "dgmr_spectral_sigma_seq_multi": [P, i, i, i, i, P, P],
+    "dgmr_spectral_sigma_seq_multi": [P, i, i, i, i, i, i, P, P],
     "dgmr_bn_stats": [P, P, i, L, i, P],
     "dgmr_bn_finalize": [P, P, P, P, P, P, P, P, P, P, i, L, i, f, f, P, P],
     "dgmr_bn_bwd_reduce": [P, P, P, P, P, i, L, i, P],

@@ -584,8 +584,8 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     // an even number of samples so that a tile never straddles two groups
     const bool small8 = p.H == 8 && p.W == 8 && p.D == 1 && !p.upsample && p.N % 2 == 0 && (!p.scale || p.scale_group % 2 == 0) &&
                         (!p.pre_a || p.pre_group % 2 == 0) && (!p.mask_a || p.mask_group % 2 == 0);
-    // the LDS-DMA kernel (bf16x3) also takes 3x3x3 convs, plane by plane
-    const bool glds_ok = g_precision == 1 && (g_tune_window < 0 || g_tune_window == 3);
+    // the LDS-DMA kernel (both bf16 modes) also takes 3x3x3 convs, plane by plane
+    const bool glds_ok = g_precision != 0 && (g_tune_window < 0 || g_tune_window == 3);
     const bool is3d = p.KD == 3 && p.D > 1 && glds_ok && !p.upsample && !p.residual_up;
     if (g_precision != 0 && p.w_split && ((p.KD == 1 && p.D == 1) || is3d) && p.KH == 3 && p.KW == 3 && p.Cin % 8 == 0 &&
         (p.W == 16 || p.W % 32 == 0 || small8) &&
@@ -612,12 +612,17 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
             // bf16x3: weight stages by LDS-DMA (conv_win_glds.h; measured +4..17 %
             // over the register-staged kernel below, bit-identical results)
             if (glds_ok && !big) {
-                if (bnw == 128)
-                    hipLaunchKernelGGL((conv3x3_glds_kernel<128, 2, 2, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
-                else if (bnw == 96)
-                    hipLaunchKernelGGL((conv3x3_glds_kernel<96, 4, 1, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
-                else
-                    hipLaunchKernelGGL((conv3x3_glds_kernel<64, 4, 1, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
+#define DGMR_GLDS(BN_, WM_, WN_)                                                                                                      \
+    do {                                                                                                                              \
+        if (g_precision == 1)                                                                                                         \
+            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
+    } while (0)
+                if (bnw == 128) DGMR_GLDS(128, 2, 2);
+                else if (bnw == 96) DGMR_GLDS(96, 4, 1);
+                else DGMR_GLDS(64, 4, 1);
+#undef DGMR_GLDS
             }
             else if (bnw == 128) {
                 // bf16x3: one weight stage + halo fetched at the chunk boundary = 53 KB of LDS and <= 168 VGPRs -> three workgroups per CU

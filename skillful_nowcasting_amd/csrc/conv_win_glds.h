@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
     constexpr int AMAX = 6 * 34;
     constexpr int APASS = (AMAX * 8 + 255) / 256;
     constexpr int BUNITS = BN * 4 * NP;  // 16-byte units of one weight stage
-    constexpr int BPASS = BUNITS / 256;
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BUNITS % 256 == 0, "bad tile");
+    constexpr int BPASS = (BUNITS + 255) / 256;  // plain bf16 at 96 channels: 384 units = one full pass + waves 0, 1 of a second
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BUNITS % 64 == 0, "bad tile");
 
     __shared__ __attribute__((aligned(16))) uint32_t smem[NP * AMAX * ROW + 2 * NP * BN * ROW];
     uint32_t* As = smem;                     // [plane][pixel][ROW]
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
     const int c_last = (nchunks - 1) * CK;
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
-        const int u = tid + i * 256;
+        const int u = min(tid + i * 256, BUNITS - 1);  // (lanes of a wave beyond the stage never issue: see dma_b)
         const int plane = u / (BN * 4);
         const int r = (u >> 2) % BN;
         const int ch = ((u ^ (r >> 2)) & 3) * 8;  // first channel (inside a chunk) of the logical k-slot held by physical slot u & 3
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
         const uint16_t* base = p.w_split + ((size_t)tap * p.Cin + (tail ? 0 : chunk * CK));
 #pragma unroll
         for (int i = 0; i < BPASS; ++i)
-            lds_dma16(base + (tail ? b_tail[i] : b_off[i]), Bs + stage * NP * BN * ROW + (i * 256 + wid * 64) * 4);
+            if (i * 256 + wid * 64 < BUNITS)  // wave-uniform: a wave fills 64 consecutive units
+                lds_dma16(base + (tail ? b_tail[i] : b_off[i]), Bs + stage * NP * BN * ROW + (i * 256 + wid * 64) * 4);
     };
 
     f32x16 acc[TM][TN];

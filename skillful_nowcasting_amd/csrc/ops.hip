@@ -240,80 +240,100 @@ __global__ void sn_rows_multi_kernel(const dgmr_sn_desc* __restrict__ descs, int
     if (threadIdx.x == 0) arena[d.tmp_off + i] = s;
 }
 
-__global__ __launch_bounds__(1024) void sn_chain_multi_kernel(const dgmr_sn_desc* __restrict__ descs, float* __restrict__ arena) {
-    extern __shared__ float sh[];  // ucur[Cmax] | y[Cmax] | red[64]
-    const dgmr_sn_desc d = descs[blockIdx.x];
+// One power iteration of EVERY module per launch.  The chain u_{t+1} ~ (W W^T) u_t is sequential in t, but one workgroup per module
+// (the round-1 design) read a 1536 x 1536 Gram matrix through a single CU at ~30 GB/s: 0.3 ms per iteration, 1.4 ms per
+// discriminator forward, all on the step's critical path.  Here launch t computes y_t = A u_t for all modules with 32 rows of A per
+// workgroup (hundreds of workgroups, every A from L2 at full rate); the quantities that need the WHOLE vector - ||y||, u^T y - are
+// recomputed at the start of launch t+1 by every workgroup of the module from y_{t-1} and u_{t-1} (a few thousand fmas, identical
+// in every workgroup: same data, same reduction order), so no cross-workgroup hand-off exists inside a launch and the stream
+// order is the only synchronisation.  ~6 us per launch instead of 80 ... 300 us per iteration.
+//   t = 0:        u_0 = t0 / max(||t0||, eps)                               (t0 = W v, sn_rows_multi_kernel)
+//   0 < t < T:    finish call t-1 (dnorm, 1/sigma) from (u_{t-1}, y_{t-1}); u_t = (y/d) / max(||y||/d, eps)
+//   t = T:        finish call T-1; module's u <- u_{T-1}
+// tmp region of a module: t0[Cout] | dnorm[T] | y[2][Cout] (double-buffered: launch t still reads y_{t-1} while writing y_t).
+constexpr int SN_RB = 32;
+
+__device__ __forceinline__ int sn_find_iter(const dgmr_sn_desc* __restrict__ d, int n, int blk) {
+    int m = 0;
+    while (m + 1 < n && blk >= d[m + 1].iter_block0) ++m;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void sn_iter_multi_kernel(const dgmr_sn_desc* __restrict__ descs, int n, float* __restrict__ arena,
+                                                            int t) {
+    extern __shared__ float sh[];  // u[Cout] | red[64]
+    const int m = sn_find_iter(descs, n, blockIdx.x);
+    const dgmr_sn_desc d = descs[m];
     const int Cout = d.Cout, T = d.T;
+    if (t > T) return;
+    const int rb = blockIdx.x - d.iter_block0;
     const float eps = d.eps;
-    const float* __restrict__ A = d.gram;
-    const float* t0 = arena + d.tmp_off;
-    float* dnorm = arena + d.tmp_off + Cout;
+    float* tmp = arena + d.tmp_off;
+    const float* t0 = tmp;
+    float* dnorm = tmp + Cout;
+    float* Y = tmp + Cout + T;
     float* u_hist = arena + d.u_hist_off;
     float* inv_sigma = arena + d.inv_sigma_off;
-    float* ucur = sh;
-    float* y = sh + Cout;
-    float* red = sh + 2 * Cout;
+    float* u = sh;
+    float* red = sh + Cout;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    {
+    if (t == 0) {
         float q = 0.f;
         for (int i = threadIdx.x; i < Cout; i += blockDim.x) q = fmaf(t0[i], t0[i], q);
         q = block_sum(q, red);
         const float inv = 1.f / fmaxf(sqrtf(q), eps);
-        for (int i = threadIdx.x; i < Cout; i += blockDim.x) ucur[i] = t0[i] * inv;
+        for (int i = threadIdx.x; i < Cout; i += blockDim.x) u[i] = t0[i] * inv;
+    } else {
+        const int sp = d.perm ? d.perm[t - 1] : t - 1;
+        const float* __restrict__ y = Y + ((t - 1) & 1) * Cout;
+        const float* __restrict__ up = u_hist + (size_t)sp * Cout;
+        float a = 0.f, b = 0.f;
+        for (int i = threadIdx.x; i < Cout; i += blockDim.x) {
+            const float yi = y[i];
+            a = fmaf(up[i], yi, a);
+            b = fmaf(yi, yi, b);
+        }
+        const float n2 = block_sum(a, red);
+        const float y2 = block_sum(b, red + 32);
+        const float dd = fmaxf(sqrtf(fmaxf(n2, 0.f)), eps);
+        if (rb == 0 && threadIdx.x == 0) {
+            dnorm[t - 1] = dd;
+            inv_sigma[sp] = dd / n2;
+        }
+        if (t == T) {
+            if (rb == 0)
+                for (int i = threadIdx.x; i < Cout; i += blockDim.x) d.u[i] = up[i];
+            return;
+        }
+        const float invd = 1.f / dd;
+        const float inv = invd / fmaxf(sqrtf(y2) * invd, eps);
+        for (int i = threadIdx.x; i < Cout; i += blockDim.x) u[i] = y[i] * inv;
     }
     __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        float part = 0.f, part2 = 0.f;
-        // each wave takes rows wid, wid+nw, ...; four rows in flight per wave to cover the L2 latency
-        for (int i0 = wid; i0 < Cout; i0 += 4 * nw) {
-            float s[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int j = lane; j < Cout; j += 64) {
-                const float uj = ucur[j];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = i0 + r * nw;
-                    if (i < Cout) s[r] = fmaf(A[(size_t)i * Cout + j], uj, s[r]);
-                }
-            }
+    const int st = d.perm ? d.perm[t] : t;
+    if (rb == 0)
+        for (int i = threadIdx.x; i < Cout; i += blockDim.x) u_hist[(size_t)st * Cout + i] = u[i];
+    // y_t[rows of this workgroup] = A[rows] . u_t : each wave takes rows r0 + wid, + nw, ...; four rows in flight per wave
+    const float* __restrict__ A = d.gram;
+    float* yo = Y + (t & 1) * Cout;
+    const int r0 = rb * SN_RB, r1 = min(Cout, r0 + SN_RB);
+    for (int i0 = r0 + wid; i0 < r1; i0 += 4 * nw) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = lane; j < Cout; j += 64) {
+            const float uj = u[j];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + r * nw;
-                const float v = wave_sum(s[r]);
-                if (lane == 0 && i < Cout) {
-                    y[i] = v;
-                    part = fmaf(ucur[i], v, part);
-                    part2 = fmaf(v, v, part2);
-                }
+                if (i < r1) s[r] = fmaf(A[(size_t)i * Cout + j], uj, s[r]);
             }
         }
-        __syncthreads();
-        if (lane == 0) {
-            red[wid] = part;
-            red[16 + wid] = part2;
-        }
-        __syncthreads();
-        float n2 = 0.f, y2 = 0.f;
-        for (int k = 0; k < nw; ++k) {
-            n2 += red[k];
-            y2 += red[16 + k];
-        }
-        const float dd = fmaxf(sqrtf(fmaxf(n2, 0.f)), eps);
-        // call t of the sequence belongs to group `slot` of the batched launch that consumes it (perm == NULL: slot == t)
-        const int slot = d.perm ? d.perm[t] : t;
-        for (int i = threadIdx.x; i < Cout; i += blockDim.x) u_hist[(size_t)slot * Cout + i] = ucur[i];
-        if (threadIdx.x == 0) {
-            dnorm[t] = dd;
-            inv_sigma[slot] = dd / n2;
-        }
-        __syncthreads();
-        if (t + 1 < T) {
-            const float invd = 1.f / dd;
-            const float inv = invd / fmaxf(sqrtf(y2) * invd, eps);
-            for (int i = threadIdx.x; i < Cout; i += blockDim.x) ucur[i] = y[i] * inv;
-            __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + r * nw;
+            const float v = wave_sum(s[r]);
+            if (lane == 0 && i < r1) yo[i] = v;
         }
     }
-    for (int i = threadIdx.x; i < Cout; i += blockDim.x) d.u[i] = ucur[i];
 }
 
 __global__ void sn_cols_multi_kernel(const dgmr_sn_desc* __restrict__ descs, int n, float* __restrict__ arena) {
@@ -1069,11 +1089,15 @@ extern "C" int dgmr_spectral_sigma_seq(const float* w, const float* gram, float*
 }
 
 extern "C" int dgmr_spectral_sigma_seq_multi(const dgmr_sn_desc* descs_dev, int n, int total_row_blocks, int total_col_blocks,
-                                             int max_cout, float* arena, void* stream) {
-    DGMR_CHECK_ARG(descs_dev && arena && n > 0 && total_row_blocks > 0 && total_col_blocks > 0, "dgmr_spectral_sigma_seq_multi: bad args");
+                                             int total_iter_blocks, int max_cout, int max_T, float* arena, void* stream) {
+    DGMR_CHECK_ARG(descs_dev && arena && n > 0 && total_row_blocks > 0 && total_col_blocks > 0 && total_iter_blocks > 0,
+                   "dgmr_spectral_sigma_seq_multi: bad args");
     DGMR_CHECK_ARG(max_cout > 0 && max_cout <= 8192, "dgmr_spectral_sigma_seq_multi: max_cout=%d", max_cout);
+    DGMR_CHECK_ARG(max_T >= 1 && max_T <= 4096, "dgmr_spectral_sigma_seq_multi: max_T=%d", max_T);
     hipLaunchKernelGGL(sn_rows_multi_kernel, dim3(total_row_blocks), dim3(256), 0, ST, descs_dev, n, arena);
-    hipLaunchKernelGGL(sn_chain_multi_kernel, dim3(n), dim3(1024), (2 * max_cout + 64) * sizeof(float), ST, descs_dev, arena);
+    for (int t = 0; t <= max_T; ++t)  // launch t: iteration t of every module that has one (t == T: its bookkeeping only)
+        hipLaunchKernelGGL(sn_iter_multi_kernel, dim3(total_iter_blocks), dim3(256), (max_cout + 64) * sizeof(float), ST, descs_dev, n,
+                           arena, t);
     hipLaunchKernelGGL(sn_cols_multi_kernel, dim3(total_col_blocks), dim3(256), 0, ST, descs_dev, n, arena);
     DGMR_CHECK_LAUNCH();
     return 0;

@@ -37,7 +37,8 @@ class SNPlan:
         self.entries = list(entries)
         n = len(self.entries)
         descs = (SNDesc * n)()
-        off = row0 = col0 = 0
+        off = row0 = col0 = it0 = 0
+        self.max_calls = 1
         self.layout = []
         self.max_cout = 1
         self.ptrs = []
@@ -61,15 +62,17 @@ class SNPlan:
             d.v_hist_off = d.u_hist_off + calls * cout
             d.tmp_off = d.v_hist_off + calls * k
             self.layout.append((off, calls, cout, k))
-            off = d.tmp_off + cout + calls
+            off = d.tmp_off + 3 * cout + calls  # t0[Cout] | dnorm[calls] | y[2][Cout]
             off = (off + 3) // 4 * 4
             d.Cout, d.Cin, d.taps, d.T, d.eps = cout, cin, taps, calls, float(m.eps)
-            d.row_block0, d.col_block0 = row0, col0
+            d.row_block0, d.col_block0, d.iter_block0 = row0, col0, it0
             row0 += cout
             col0 += (k + 63) // 64
+            it0 += (cout + 31) // 32
             self.max_cout = max(self.max_cout, cout)
+            self.max_calls = max(self.max_calls, calls)
             self.ptrs.append((w.data_ptr(), vec._u.data_ptr(), vec._v.data_ptr(), gram.data_ptr()))
-        self.total, self.rows, self.cols = off, row0, col0
+        self.total, self.rows, self.cols, self.iters = off, row0, col0, it0
         raw = bytes(ctypes.string_at(ctypes.addressof(descs), ctypes.sizeof(descs)))
         self.descs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.device = dev
@@ -85,8 +88,8 @@ class SNPlan:
         for m, _, _ in self.entries:
             m._gram()  # refresh W W^T in place if the optimiser moved W
         arena = torch.empty(self.total, device=self.device, dtype=torch.float32)
-        ops.call("dgmr_spectral_sigma_seq_multi", self.descs_dev.data_ptr(), len(self.entries), self.rows, self.cols, self.max_cout,
-                 arena.data_ptr(), ops._stream())
+        ops.call("dgmr_spectral_sigma_seq_multi", self.descs_dev.data_ptr(), len(self.entries), self.rows, self.cols, self.iters,
+                 self.max_cout, self.max_calls, arena.data_ptr(), ops._stream())
         out = {}
         for (m, calls, lay), (off, _, cout, k) in zip(self.entries, self.layout):
             inv_sigma = arena[off:off + calls]

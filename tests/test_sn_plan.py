@@ -24,7 +24,7 @@ def test_plan_layout_is_disjoint_and_complete():
     raw = bytes(plan.descs_dev.cpu().numpy().tobytes())
     descs = (SNDesc * len(entries)).from_buffer_copy(raw)
     used = []
-    rows = cols = 0
+    rows = cols = its = 0
     assert descs[0].perm == plan.perms[0].data_ptr() and plan.perms[0].tolist() == [0, 2, 1, 3]
     assert all(d.perm is None for d in descs[1:])
     for d, (m, calls, _) in zip(descs, entries):
@@ -35,15 +35,16 @@ def test_plan_layout_is_disjoint_and_complete():
         assert (d.Cout, d.Cin, d.taps, d.T) == (cout, cin, taps, calls)
         assert d.w == w.data_ptr() and d.gram == m._gram_buffer().data_ptr()
         assert abs(d.eps - m.eps) <= 1e-12 * max(1.0, m.eps) or d.eps == ctypes.c_float(m.eps).value
-        assert d.row_block0 == rows and d.col_block0 == cols
+        assert d.row_block0 == rows and d.col_block0 == cols and d.iter_block0 == its
         rows += cout
         cols += (k + 63) // 64
-        # arena regions: inv_sigma[T] | u_hist[T*Cout] | v_hist[T*K] | tmp[Cout + T]
-        regions = [(d.inv_sigma_off, calls), (d.u_hist_off, calls * cout), (d.v_hist_off, calls * k), (d.tmp_off, cout + calls)]
+        its += (cout + 31) // 32
+        # arena regions: inv_sigma[T] | u_hist[T*Cout] | v_hist[T*K] | tmp[3*Cout + T]
+        regions = [(d.inv_sigma_off, calls), (d.u_hist_off, calls * cout), (d.v_hist_off, calls * k), (d.tmp_off, 3 * cout + calls)]
         for off, n in regions:
             assert off >= 0 and off + n <= plan.total
             used.append((off, off + n))
-    assert (rows, cols) == (plan.rows, plan.cols)
+    assert (rows, cols, its) == (plan.rows, plan.cols, plan.iters) and plan.max_calls == 4
     used.sort()
     for (a0, a1), (b0, b1) in zip(used, used[1:]):
         assert a1 <= b0, "arena regions overlap"
