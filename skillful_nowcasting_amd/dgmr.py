@@ -48,6 +48,22 @@ except Exception:  # pragma: no cover - depends on the environment
                 self._optimizers = self.configure_optimizers()[0]
             return self._optimizers
 
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict: bool = True, **overrides):
+            """Lightning `.ckpt` files (`{"state_dict": ..., "hyper_parameters": ...}`) without Lightning installed: the model is
+            built from the stored hyper-parameters (keyword overrides win) and the state dict loaded into it."""
+            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+            if "state_dict" not in ckpt:
+                raise KeyError(f"{checkpoint_path}: not a Lightning checkpoint (no 'state_dict' entry)")
+            import inspect
+
+            accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+            hp = {k: v for k, v in dict(ckpt.get("hyper_parameters", {})).items() if k in accepted}
+            hp.update(overrides)
+            model = cls(**hp)
+            model.load_state_dict(ckpt["state_dict"], strict=strict)
+            return model
+
 
 def weight_fn(y, precip_weight_cap=24.0):
     """w(y) = max(y + 1, cap) (dgmr/dgmr.py:20-33); GridCellLoss evaluates this one inside its kernel."""
@@ -283,12 +299,50 @@ class DGMR(
         opt_d = FusedAdam(self.discriminator.parameters(), lr=self.disc_lr, betas=(b1, b2))
         return [opt_g, opt_d], []
 
-    def visualize_step(self, x, y, y_hat, batch_idx, step):  # pragma: no cover - needs torchvision + a logger
-        """TensorBoard image grids (dgmr/dgmr.py:302-327); off the hot path, requires torchvision."""
-        import torchvision
-
+    def visualize_step(self, x, y, y_hat, batch_idx, step):
+        """TensorBoard image grids (dgmr/dgmr.py:302-327): for every INPUT frame index i the input, target and generated frame i of
+        the first sample, each as a grid of its channels.  ONE device->host copy of the three stacks (the reference does the same
+        three `.cpu()` calls); torchvision is optional - `make_grid` below reproduces `torchvision.utils.make_grid`."""
+        try:
+            from torchvision.utils import make_grid as grid_fn
+        except Exception:
+            grid_fn = make_grid
         tensorboard = self.logger.experiment[0]
-        for name, seq in (("Input_Image_Stack", x[0]), ("Target_Image", y[0]), ("Generated_Image", y_hat[0])):
-            for i, t in enumerate(seq.cpu().detach()):
-                grid = torchvision.utils.make_grid([torch.unsqueeze(img, dim=0) for img in t], nrow=self.input_channels)
+        images, future_images, generated_images = x[0].detach().cpu(), y[0].detach().cpu(), y_hat[0].detach().cpu()
+        for i, t in enumerate(images):  # the reference indexes the target / generated stacks with the INPUT frame index
+            for name, frame in (("Input_Image_Stack", t), ("Target_Image", future_images[i]), ("Generated_Image", generated_images[i])):
+                grid = grid_fn([torch.unsqueeze(img, dim=0) for img in frame], nrow=self.input_channels)
                 tensorboard.add_image(f"{step}/{name}_Frame_{i}", grid, global_step=batch_idx)
+
+
+def make_grid(tensor, nrow: int = 8, padding: int = 2, pad_value: float = 0.0):
+    """torchvision.utils.make_grid for the arguments visualize_step uses (no normalisation): a list of [1, H, W] / [3, H, W] images ->
+    one [3, ...] image, `nrow` images per row, `padding` pixels of `pad_value` between them; a single image is returned as is
+    (grey images replicated to three channels)."""
+    import math
+
+    if isinstance(tensor, (list, tuple)):
+        tensor = torch.stack(list(tensor), dim=0)
+    if tensor.dim() == 2:
+        tensor = tensor.unsqueeze(0)
+    if tensor.dim() == 3:
+        if tensor.size(0) == 1:
+            tensor = torch.cat((tensor, tensor, tensor), 0)
+        tensor = tensor.unsqueeze(0)
+    if tensor.dim() == 4 and tensor.size(1) == 1:
+        tensor = torch.cat((tensor, tensor, tensor), 1)
+    if tensor.size(0) == 1:
+        return tensor.squeeze(0)
+    nmaps = tensor.size(0)
+    xmaps = min(nrow, nmaps)
+    ymaps = int(math.ceil(float(nmaps) / xmaps))
+    height, width = int(tensor.size(2) + padding), int(tensor.size(3) + padding)
+    grid = tensor.new_full((tensor.size(1), height * ymaps + padding, width * xmaps + padding), pad_value)
+    k = 0
+    for yy in range(ymaps):
+        for xx in range(xmaps):
+            if k >= nmaps:
+                break
+            grid.narrow(1, yy * height + padding, height - padding).narrow(2, xx * width + padding, width - padding).copy_(tensor[k])
+            k += 1
+    return grid

@@ -339,8 +339,15 @@ class BatchNorm(nn.BatchNorm2d):
     applies (with the ReLU) while loading its operand: the normalised tensor is never written to HBM.
     """
 
-    def forward(self, x):  # pragma: no cover - guard
-        raise RuntimeError("BatchNorm is fused into the following conv; call .prepare(x) and pass bn= to the conv")
+    def forward(self, x):
+        """Stand-alone torch.nn.BatchNorm2d semantics (module-level drop-in: the reference's tests call `sampler.bn(h)` directly,
+        tests/test_model.py:211).  The model's own forward never comes here: it folds the affine into the next conv (`prepare`)."""
+        ops.require_hip(x)
+        xc = ops.to_cl(x)
+        n, c, h, w = xc.shape
+        y = ops.BatchNorm1dFn.apply(xc.permute(0, 2, 3, 1).reshape(n * h * w, c), self.weight, self.bias, self.running_mean,
+                                    self.running_var, self.num_batches_tracked, self.eps, self.momentum, self.training, 1, None)
+        return y.view(n, h, w, c).permute(0, 3, 1, 2)
 
     def prepare(self, x, groups: int = 1, layout: Optional[ops.CallLayout] = None) -> BNState:
         """`groups` > 1: x holds that many calls of the reference's module, each with its own batch statistics; `layout` gives the
