@@ -177,6 +177,27 @@ def _relayout_hook(module, incompatible_keys=None):
     ops.bump_weights_epoch()
 
 
+def _export_hook(module, state_dict, prefix, local_metadata):
+    """state_dict post-hook: conv weights leave in the standard contiguous (OIHW) layout, like the reference's, so that
+    safetensors / torch.save files interchange with it (safetensors refuses non-contiguous tensors outright).  The parameter itself
+    stays channels-last (what the kernels index).  One copy per parameter and call: DGMR lists its generator parts twice
+    (`sampler.*` and `generator.sampler.*`), both names must keep pointing at ONE tensor or a checkpoint would store it twice."""
+    import weakref
+
+    for name in ("original", "weight"):
+        key = prefix + name
+        t = state_dict.get(key)
+        if t is None or t.dim() not in (4, 5) or t.is_contiguous():
+            continue
+        cache = module.__dict__.setdefault("_export_refs", {})
+        hit = cache.get(name)
+        copy = hit[1]() if hit is not None and hit[0] == (t._version, t.data_ptr()) else None
+        if copy is None:
+            copy = t.detach().contiguous()
+            cache[name] = ((t._version, t.data_ptr()), weakref.ref(copy))
+        state_dict[key] = copy
+
+
 class _SNVectors(nn.Module):
     def __init__(self, u, v):
         super().__init__()
@@ -190,6 +211,7 @@ class _SNWeight(nn.Module):
         self.original = nn.Parameter(weight)
         self.add_module("0", _SNVectors(u, v))
         self.register_load_state_dict_post_hook(_relayout_hook)
+        self.register_state_dict_post_hook(_export_hook)
 
 
 class _Parametrizations(nn.Module):
@@ -326,6 +348,7 @@ class Conv(nn.Module):
         else:
             self.register_parameter("bias", None)
         self.register_load_state_dict_post_hook(_relayout_hook)
+        self.register_state_dict_post_hook(_export_hook)
 
     def forward(self, x, *, pre_relu: bool = False, residual=None, scale=None, gamma_scale: bool = False):
         spec = ConvSpec(pre_relu=pre_relu, gamma_scale=gamma_scale)

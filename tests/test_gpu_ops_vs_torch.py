@@ -1,0 +1,162 @@
+"""Single operators of the HIP path against torch's own CPU ops in float64, forward AND backward, at the awkward shapes of the
+paper-size discriminators: odd numbers of call groups (5 temporal frames), 40-image batches, 8x8 ... 2x2 maps with 384 ... 1536
+channels (split-K territory), 1x1 / 3x3 / 3x3x3 kernels, ReLU-on-load, residuals, pooling with an odd depth.  The golden fixtures
+are small by necessity; this is where a size- or divisibility-dependent slip in one kernel shows, isolated from the rest.
+
+Spectral norm is emulated exactly: y_q = conv(pre(x_q), W / (u_q^T W v_q)) with constant u_q, v_q per call group q - autograd on
+that expression IS the chain rule of torch's parametrization (torch/nn/utils/parametrizations.py:515-521) the kernels implement.
+Exact f32 arithmetic; 2e-5 of each tensor's max magnitude (fp32 summation over up to 13 824 terms against float64).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(got, ref, what, tol=2e-5):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale + 1e-12, f"{what}: abs err {err:.3e} at scale {scale:.3e} ({err / max(scale, 1e-300):.2e} rel)"
+
+
+# n, spatial dims, cin, cout, k, groups, pre_relu, residual
+CONV_SHAPES = [
+    (40, (4, 4), 384, 768, 3, 5, True, False),     # temporal D intermediate_dblocks.2.first_conv_3x3 (5 frames x 8 samples)
+    (40, (4, 4), 768, 768, 3, 5, True, False),     # ... last_conv_3x3
+    (40, (4, 4), 384, 768, 1, 5, False, False),    # ... conv_1x1
+    (40, (8, 8), 192, 384, 3, 5, True, False),     # intermediate_dblocks.1
+    (40, (8, 8), 384, 384, 3, 5, True, False),
+    (40, (2, 2), 768, 768, 3, 5, True, True),      # d_last (keep_same_output: residual add)
+    (64, (2, 2), 768, 768, 3, 8, True, True),      # spatial d6
+    (24, (16, 16), 96, 192, 3, 3, True, False),
+    (10, (16, 16), 48, 96, 1, 5, False, False),
+    (6, (5, 16, 16), 48, 96, 3, 3, True, False),   # 3-D block, odd depth
+    (4, (11, 32, 32), 4, 48, 3, 2, False, False),  # temporal d1.first_conv_3x3 (no ReLU on the frames)
+]
+
+
+@pytest.mark.parametrize("n,dims,cin,cout,k,groups,relu,res", CONV_SHAPES)
+def test_sn_conv_fwd_bwd_vs_torch(n, dims, cin, cout, k, groups, relu, res):
+    from skillful_nowcasting_amd import ops
+
+    torch.manual_seed(hash((n, dims, cin, cout, k)) % 1000)
+    nd = len(dims)
+    ks = (k,) * nd
+    x = torch.randn(n, cin, *dims, dtype=torch.float64)
+    w = torch.randn(cout, cin, *ks, dtype=torch.float64) * (cin * k ** nd) ** -0.5
+    b = torch.randn(cout, dtype=torch.float64)
+    kk = cin * k ** nd
+    u = F.normalize(torch.randn(groups, cout, dtype=torch.float64), dim=1)
+    v = F.normalize(torch.randn(groups, kk, dtype=torch.float64), dim=1)
+    r = torch.randn(n, cout, *dims, dtype=torch.float64) if res else None
+    cot = torch.randn(n, cout, *dims, dtype=torch.float64)
+    # ---- float64 reference ----
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    conv = F.conv2d if nd == 2 else F.conv3d
+    ys, sig = [], []
+    per = n // groups
+    for q in range(groups):
+        sigma = torch.dot(u[q], wr.flatten(1) @ v[q])
+        sig.append(sigma.detach())
+        xin = xr[q * per:(q + 1) * per]
+        ys.append(conv(F.relu(xin) if relu else xin, wr / sigma, br, padding=k // 2))
+    yref = torch.cat(ys, 0)
+    if res:
+        yref = yref + rr
+    (yref * cot).sum().backward()
+    # ---- HIP ----
+    mf = torch.channels_last if nd == 2 else torch.channels_last_3d
+    xd = x.float().to(DEV).contiguous(memory_format=mf).requires_grad_(True)
+    wd = torch.nn.Parameter(w.float().to(DEV).contiguous(memory_format=mf))
+    bd = torch.nn.Parameter(b.float().to(DEV))
+    rd = r.float().to(DEV).contiguous(memory_format=mf).requires_grad_(True) if res else None
+    inv_sigma = (1.0 / torch.stack(sig)).float().to(DEV)
+    sn = ops.SNCall(inv_sigma, u.float().to(DEV), v.float().to(DEV), groups)
+    y = ops.conv(xd, wd, bd, inv_sigma, rd, ops.ConvSpec(pre_relu=relu, sn=sn))
+    (y * cot.float().to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    _close(y, yref, "forward")
+    _close(xd.grad, xr.grad, "input gradient")
+    _close(wd.grad, wr.grad, "weight gradient")
+    _close(bd.grad, br.grad, "bias gradient")
+    if res:
+        _close(rd.grad, rr.grad, "residual gradient")
+
+
+@pytest.mark.parametrize("shape,pd", [((40, 384, 8, 8), 1), ((40, 768, 4, 4), 1), ((6, 48, 11, 32, 32), 2), ((4, 96, 5, 16, 16), 2)])
+def test_pool_add_vs_torch(shape, pd):
+    from skillful_nowcasting_amd import ops
+
+    torch.manual_seed(1)
+    x = torch.randn(*shape, dtype=torch.float64)
+    pool = (lambda t: F.avg_pool2d(t, 2)) if len(shape) == 4 else (lambda t: F.avg_pool3d(t, 2))
+    xr = x.clone().requires_grad_(True)
+    out_ref = pool(xr)
+    add = torch.randn_like(out_ref)
+    ar = add.clone().requires_grad_(True)
+    cot = torch.randn_like(out_ref)
+    ((out_ref + ar) * cot).sum().backward()
+    mf = torch.channels_last if len(shape) == 4 else torch.channels_last_3d
+    xd = x.float().to(DEV).contiguous(memory_format=mf).requires_grad_(True)
+    ad = add.float().to(DEV).contiguous(memory_format=mf).requires_grad_(True)
+    out = ops.avg_pool_add(xd, ad, pd)
+    (out * cot.float().to(DEV)).sum().backward()
+    _close(out, out_ref + ar, "pool + add")
+    _close(xd.grad, xr.grad, "pool input gradient")  # odd depth: the dropped last plane must receive exactly zero
+    _close(ad.grad, ar.grad, "addend gradient")
+
+
+def test_frames_to_batch_and_heads_vs_torch():
+    from skillful_nowcasting_amd import ops
+
+    torch.manual_seed(2)
+    n, c, t, h, w = 8, 96, 5, 16, 16
+    x = torch.randn(n, c, t, h, w, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    ref = xr.permute(2, 0, 1, 3, 4).reshape(t * n, c, h, w)
+    ref_h = F.relu(ref).sum(dim=(2, 3))
+    cot = torch.randn(t * n, c, dtype=torch.float64)
+    (ref_h * cot).sum().backward()
+    xd = x.float().to(DEV).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    rep = ops.frames_to_batch(xd)
+    head = ops.relu_sum_hw(rep)
+    (head * cot.float().to(DEV)).sum().backward()
+    _close(rep, ref, "frames_to_batch")
+    _close(head, ref_h, "relu_sum_hw")
+    _close(xd.grad, xr.grad, "gradient through relu_sum_hw and frames_to_batch")
+
+
+@pytest.mark.parametrize("groups,n,c", [(5, 8, 768), (8, 4, 1536), (30, 32, 768)])
+def test_batchnorm1d_groups_vs_torch(groups, n, c):
+    """The discriminator heads: BatchNorm1d with batch statistics per call group (train mode), running statistics updated once
+    per group in order."""
+    from skillful_nowcasting_amd.nn import BatchNorm1d
+
+    torch.manual_seed(3)
+    x = torch.randn(groups * n, c, dtype=torch.float64) * 3 + 1
+    cot = torch.randn(groups * n, c, dtype=torch.float64)
+    ref_bn = torch.nn.BatchNorm1d(c).double()
+    with torch.no_grad():
+        ref_bn.weight.uniform_(0.5, 1.5)
+        ref_bn.bias.normal_()
+    xr = x.clone().requires_grad_(True)
+    yref = torch.cat([ref_bn(xr[q * n:(q + 1) * n]) for q in range(groups)], 0)
+    (yref * cot).sum().backward()
+    bn = BatchNorm1d(c)
+    with torch.no_grad():
+        bn.weight.copy_(ref_bn.weight.detach().float())
+        bn.bias.copy_(ref_bn.bias.detach().float())
+    bn = bn.to(DEV).train()
+    xd = x.float().to(DEV).requires_grad_(True)
+    y = bn(xd, groups=groups)
+    (y * cot.float().to(DEV)).sum().backward()
+    _close(y, yref, "batchnorm1d", 1e-5)
+    _close(xd.grad, xr.grad, "batchnorm1d input gradient", 1e-4)
+    _close(bn.weight.grad, ref_bn.weight.grad, "gamma gradient", 1e-5)
+    _close(bn.running_mean, ref_bn.running_mean, "running mean", 1e-5)
+    _close(bn.running_var, ref_bn.running_var, "running var", 1e-5)
