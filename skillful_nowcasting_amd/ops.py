@@ -798,7 +798,10 @@ class ConvGRUFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x_all, h0, params, seqs, steps: int, x_shared: bool = False, draws: int = 1):
+    def forward(ctx, x_all, h0, params, seqs, steps: int, x_shared: bool = False, draws: int = 1, anchor=None):
+        """`anchor`: one of the layer's parameters, passed as a tensor argument only so that the output joins the autograd graph when
+        neither x nor h0 requires a gradient (a stand-alone layer fed with data, tests/test_model.py:67-82); parameter gradients
+        themselves are accumulated by the kernels into `param.grad`."""
         require_hip(x_all)
         require_hip(h0, "initial state")
         x_all, h0 = to_cl(x_all), to_cl(h0)
@@ -985,11 +988,11 @@ class ConvGRUFn(Function):
                 call("dgmr_conv_wgrad", ctypes.byref(wa), st)
                 call("dgmr_wgrad_reduce_slice", _p(partial), ns, g_, ch, taps, cin, ct, coff, _p(w), _p(inv_s), _p(g), _p(dot), st)
             call("dgmr_sn_wgrad_finalize", _p(g), _p(grad_buffer(w)), _p(dot), _p(inv_s), _p(u_), _p(v_), ch, ct, taps, g_, 1, st)
-        return dx_all, dh0, None, None, None, None, None
+        return dx_all, dh0, None, None, None, None, None, None
 
 
 def conv_gru(x_all, h0, params, seqs, steps: int, x_shared: bool = False, draws: int = 1):
-    return ConvGRUFn.apply(x_all, h0, params, seqs, steps, x_shared, draws)
+    return ConvGRUFn.apply(x_all, h0, params, seqs, steps, x_shared, draws, params[0])
 
 
 # ---------------------------------------------------------------------------------------------------

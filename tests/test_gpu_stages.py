@@ -101,3 +101,90 @@ def test_generator_stages_match_oracle(size, T, precision, tol):
     print(f"\nstage errors at {size}x{size} [{precision}]:\n{table}")
     bad = {k: e for k, e in errs.items() if not e <= tol}
     assert not bad, f"stages beyond {tol} at {size}x{size} [{precision}]:\n{table}"
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the discriminators' backward, block by block: output and GRADIENT AT THE OUTPUT of every D-block against the float64 oracle
+# ------------------------------------------------------------------------------------------------------------------------------
+def _oracle_temporal(O, sd, x):
+    import torch.nn.functional as F
+
+    p = "temporal_discriminator."
+    st = {}
+
+    def keep(name, t):
+        t.retain_grad()
+        st[name] = t
+        return t
+
+    h = F.avg_pool3d(x, (1, 2, 2), (1, 2, 2))
+    h = F.pixel_unshuffle(h, 2).permute(0, 2, 1, 3, 4)
+    h = keep("d1", O.dblock(sd, p + "d1.", h, True, first_relu=False))
+    h = keep("d2", O.dblock(sd, p + "d2.", h, True))
+    h = h.permute(0, 2, 1, 3, 4)
+    reps = []
+    for t in range(h.shape[1]):
+        rep = h[:, t]
+        for i in range(3):
+            rep = keep(f"intermediate_dblocks.{i}[{t}]", O.dblock(sd, f"{p}intermediate_dblocks.{i}.", rep, True))
+        rep = keep(f"d_last[{t}]", O.dblock(sd, p + "d_last.", rep, True, keep_same_output=True))
+        reps.append(O._d_head(sd, p, rep, True))
+    return torch.sum(torch.stack(reps, dim=1), keepdim=True, dim=1), st
+
+
+def test_temporal_discriminator_backward_stages():
+    """Paper-size temporal discriminator on 8 sequences of 22 frames, exact f32: forward output and the gradient arriving at the
+    output of d1, d2 (3-D blocks) and of every per-frame block, each against the float64 oracle at 1e-4 of its max magnitude."""
+    import skillful_nowcasting_amd as S
+    from oracle import dgmr_oracle as O
+    from skillful_nowcasting_amd.common import DBlock
+
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.manual_seed(0)
+    model = S.DGMR(forecast_steps=18, output_shape=256, latent_channels=768, context_channels=384)
+    sd = {k[len("discriminator."):]: v.detach().clone().double() for k, v in model.state_dict().items() if k.startswith("discriminator.")}
+    torch.manual_seed(31)
+    n = 8
+    seq = torch.rand(n, 22, 1, 256, 256)
+    cot = torch.randn(n, 1, 1)
+    out_ref, st = _oracle_temporal(O, sd, seq.double())
+    (out_ref * cot.double()).sum().backward()
+    td = model.discriminator.temporal_discriminator.to("cuda").train()
+    got = {}
+    hooks = []
+
+    def hook(name):
+        def h(mod, inp, out):
+            got[name + ".out"] = out.detach()
+            out.register_hook(lambda g, nm=name: got.__setitem__(nm + ".dout", g.detach().clone()))
+        return h
+
+    for name, m in td.named_modules():
+        if isinstance(m, DBlock):
+            hooks.append(m.register_forward_hook(hook(name)))
+    out = td(seq.cuda())
+    (out * cot.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    for h in hooks:
+        h.remove()
+    rows = []
+
+    def cmp(name, a, b):
+        a, b = a.double().cpu(), b.double()
+        assert tuple(a.shape) == tuple(b.shape), (name, a.shape, b.shape)
+        rows.append((name, (a - b).abs().max().item() / max(b.abs().max().item(), 1e-300)))
+
+    cmp("scores", out.detach(), out_ref.detach())
+    for name in ("d1", "d2"):  # oracle: [N, C, T, h, w]
+        cmp(name + ".out", got[name + ".out"], st[name].detach())
+        cmp(name + ".dout", got[name + ".dout"], st[name].grad)
+    frames = st["d2"].shape[2]
+    for name in ("intermediate_dblocks.0", "intermediate_dblocks.1", "intermediate_dblocks.2", "d_last"):
+        ref_out = torch.cat([st[f"{name}[{t}]"].detach() for t in range(frames)], 0)  # frame-major, as the HIP batch
+        ref_g = torch.cat([st[f"{name}[{t}]"].grad for t in range(frames)], 0)
+        cmp(name + ".out", got[name + ".out"], ref_out)
+        cmp(name + ".dout", got[name + ".dout"], ref_g)
+    table = "\n".join(f"  {k:34s} {e:.3e}" for k, e in rows)
+    print("\ntemporal discriminator, f32 vs float64 oracle:\n" + table)
+    bad = [k for k, e in rows if not e <= 1e-4]
+    assert not bad, f"beyond 1e-4: {bad}\n{table}"
