@@ -143,6 +143,8 @@ def test_temporal_discriminator_backward_stages():
     torch.manual_seed(0)
     model = S.DGMR(forecast_steps=18, output_shape=256, latent_channels=768, context_channels=384)
     sd = {k[len("discriminator."):]: v.detach().clone().double() for k, v in model.state_dict().items() if k.startswith("discriminator.")}
+    for k in O.param_keys(sd, ""):
+        sd[k].requires_grad_(True)
     torch.manual_seed(31)
     n = 8
     seq = torch.rand(n, 22, 1, 256, 256)
