@@ -171,10 +171,20 @@ def test_temporal_discriminator_backward_stages():
         h.remove()
     rows = []
 
+    detail = []
+
     def cmp(name, a, b):
         a, b = a.double().cpu(), b.double()
         assert tuple(a.shape) == tuple(b.shape), (name, a.shape, b.shape)
-        rows.append((name, (a - b).abs().max().item() / max(b.abs().max().item(), 1e-300)))
+        scale = max(b.abs().max().item(), 1e-300)
+        diff = (a - b).abs()
+        rows.append((name, diff.max().item() / scale))
+        l2 = (diff.pow(2).sum().sqrt() / b.pow(2).sum().sqrt()).item()
+        frac = (diff > 1e-3 * scale).double().mean().item()
+        top = torch.topk(diff.flatten(), 4).indices
+        pos = [tuple(int(v) for v in torch.unravel_index(i, a.shape)) for i in top]
+        detail.append(f"  {name:34s} max {diff.max().item() / scale:.2e}  l2 {l2:.2e}  frac(>1e-3) {frac:.2e}  worst at "
+                      + "; ".join(f"{q}: hip {a[q].item():+.4e} ref {b[q].item():+.4e}" for q in pos))
 
     cmp("scores", out.detach(), out_ref.detach())
     for name in ("d1", "d2"):  # oracle: [N, C, T, h, w]
@@ -187,6 +197,6 @@ def test_temporal_discriminator_backward_stages():
         cmp(name + ".out", got[name + ".out"], ref_out)
         cmp(name + ".dout", got[name + ".dout"], ref_g)
     table = "\n".join(f"  {k:34s} {e:.3e}" for k, e in rows)
-    print("\ntemporal discriminator, f32 vs float64 oracle:\n" + table)
+    print("\ntemporal discriminator, f32 vs float64 oracle:\n" + table + "\n" + "\n".join(detail))
     bad = [k for k, e in rows if not e <= 1e-4]
     assert not bad, f"beyond 1e-4: {bad}\n{table}"
