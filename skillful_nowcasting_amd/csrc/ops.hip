@@ -387,10 +387,14 @@ __global__ void zero_kernel(float* p, int n) {
 // ------------------------------------------------------------------------------------------------
 // per-channel reductions over [G][R][C]
 // ------------------------------------------------------------------------------------------------
-// F: void(int64_t elem_index, int g, int c, float& s0, float& s1)
+// F: void(int64_t elem_index, int g, int c, double& s0, double& s1)
+// Accumulation is in double from the first element on.  Batch variance is formed as E[x^2] - mean^2, which cancels by mean^2 / var:
+// the discriminator heads normalise relu-sum features whose spread across the 8 ... 32 samples of a call is ~1 % of their mean
+// (mean^2 / var ~ 1e4), and float partial sums (6e-8 x 1e4 = 6e-4 on rstd) put a 1e-3 ... 1e-2 error on every gradient behind the
+// head (found by tests/test_gpu_stages.py::test_temporal_discriminator_backward_stages).  These kernels are HBM-bound either way.
 template <class F>
 __device__ __forceinline__ void chan_reduce2(F f, int64_t R, int C, double* __restrict__ out /* [G][2][C] */) {
-    __shared__ float l0[256], l1[256];
+    __shared__ double l0[256], l1[256];
     const int g = blockIdx.y;
     const int64_t rows_per_block = (R + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
@@ -398,7 +402,7 @@ __device__ __forceinline__ void chan_reduce2(F f, int64_t R, int C, double* __re
         const int Wd = min(256, C - cb);
         const int RL = 256 / Wd;
         const int c = cb + threadIdx.x % Wd, rl = threadIdx.x / Wd;
-        float s0 = 0.f, s1 = 0.f;
+        double s0 = 0.0, s1 = 0.0;
         if (rl < RL)
             for (int64_t r = r0 + rl; r < r1; r += RL) f(((int64_t)g * R + r) * C + c, g, c, s0, s1);
         l0[threadIdx.x] = s0;
@@ -419,10 +423,10 @@ __device__ __forceinline__ void chan_reduce2(F f, int64_t R, int C, double* __re
 
 __global__ void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int64_t R, int C) {
     chan_reduce2(
-        [&](int64_t i, int, int, float& s0, float& s1) {
-            const float v = x[i];
+        [&](int64_t i, int, int, double& s0, double& s1) {
+            const double v = (double)x[i];
             s0 += v;
-            s1 = fmaf(v, v, s1);
+            s1 = fma(v, v, s1);
         },
         R, C, sums);
 }
@@ -430,17 +434,17 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, double* __restrict_
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, double* __restrict__ sums, int64_t R, int C) {
     chan_reduce2(
-        [&](int64_t i, int g, int c, float& s0, float& s1) {
+        [&](int64_t i, int g, int c, double& s0, double& s1) {
             const float gv = gy[i];
             const float xh = (x[i] - mean[(size_t)g * C + c]) * rstd[(size_t)g * C + c];
-            s0 += gv;
-            s1 = fmaf(gv, xh, s1);
+            s0 += (double)gv;
+            s1 = fma((double)gv, (double)xh, s1);
         },
         R, C, sums);
 }
 
 __global__ void colsum_kernel(const float* __restrict__ x, double* __restrict__ sums, int64_t R, int C) {
-    chan_reduce2([&](int64_t i, int, int, float& s0, float&) { s0 += x[i]; }, R, C, sums);
+    chan_reduce2([&](int64_t i, int, int, double& s0, double&) { s0 += (double)x[i]; }, R, C, sums);
 }
 
 // out[c] (+)= sum_r x[r][c] for FEW rows and MANY columns (one thread per 4 columns; colsum_kernel is for the opposite shape)
