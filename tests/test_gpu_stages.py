@@ -196,6 +196,10 @@ def test_temporal_discriminator_backward_stages():
         ref_g = torch.cat([st[f"{name}[{t}]"].grad for t in range(frames)], 0)
         cmp(name + ".out", got[name + ".out"], ref_out)
         cmp(name + ".dout", got[name + ".dout"], ref_g)
+    named = dict(td.named_parameters())
+    for k in O.param_keys(sd, "temporal_discriminator."):
+        if sd[k].grad is not None and sd[k].grad.abs().max().item() > 0:
+            cmp("grad " + k[len("temporal_discriminator."):], named[k[len("temporal_discriminator."):]].grad, sd[k].grad)
     table = "\n".join(f"  {k:34s} {e:.3e}" for k, e in rows)
     print("\ntemporal discriminator, f32 vs float64 oracle:\n" + table + "\n" + "\n".join(detail))
     bad = [k for k, e in rows if not e <= 1e-4]
