@@ -181,7 +181,7 @@ def test_temporal_discriminator_backward_stages():
         rows.append((name, diff.max().item() / scale))
         l2 = (diff.pow(2).sum().sqrt() / b.pow(2).sum().sqrt()).item()
         frac = (diff > 1e-3 * scale).double().mean().item()
-        top = torch.topk(diff.flatten(), 4).indices
+        top = torch.topk(diff.flatten(), min(4, diff.numel())).indices
         pos = [tuple(int(v) for v in torch.unravel_index(i, a.shape)) for i in top]
         detail.append(f"  {name:34s} max {diff.max().item() / scale:.2e}  l2 {l2:.2e}  frac(>1e-3) {frac:.2e}  worst at "
                       + "; ".join(f"{q}: hip {a[q].item():+.4e} ref {b[q].item():+.4e}" for q in pos))
