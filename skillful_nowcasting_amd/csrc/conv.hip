@@ -287,6 +287,9 @@ int g_precision = 0;
 // dgmr_conv_tune(): -1 = automatic
 int g_tune_variant = -1, g_tune_ksplit = -1, g_tune_window = -1, g_tune_wgrad_window = -1;
 
+// dgmr_conv_tune(window = 2): the 256-pixel-tile LDS-DMA window kernel wherever the geometry allows (A/B switch)
+static bool glds_tune_big() { return g_precision != 0 && g_tune_window == 2; }
+
 // WM x WN: wave grid of the f32 kernel; WMB x WNB: of the bf16 kernels (two register stages: 128x128 needs 8 waves to fit)
 template <int BM, int BN, int WM, int WN, int WMB = WM, int WNB = WN>
 int launch_conv(const dgmr_conv_args& a, int M, int Ktot, hipStream_t s) {
@@ -593,8 +596,9 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         const int tw_shift = small8 ? 3 : (p.W == 16 ? 4 : 5);
         const int g_shift = small8 ? 1 : 0;
         const int bnw0 = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
-        // 256-pixel tiles (8 x 32): bf16x3 at 96 output channels, whole rows of 32 only
-        const bool big = g_precision == 1 && g_tune_window == 2 && bnw0 == 96 && tw_shift == 5 && p.H % 8 == 0;
+        // 256-pixel tiles (8 x 32 or 16 x 16 pixels of one image), LDS-DMA kernel
+        // (not at 128 output channels: 8 accumulator blocks per wave spill at two workgroups per CU)
+        const bool big = glds_tune_big() && !small8 && bnw0 != 128 && p.H % (256 >> tw_shift) == 0;
         const int TWv = 1 << tw_shift, THv = ((big ? 256 : 128) >> tw_shift) >> g_shift;
         if (p.H % THv == 0) {
             const int tiles_w = p.W / TWv, tiles_hw = tiles_w * (p.H / THv);
@@ -611,7 +615,19 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     } while (0)
             // bf16x3: weight stages by LDS-DMA (conv_win_glds.h; measured +4..17 %
             // over the register-staged kernel below, bit-identical results)
-            if (glds_ok && !big) {
+            if (big) {
+#define DGMR_GLDS_BIG(BN_, WM_, WN_)                                                                                                  \
+    do {                                                                                                                              \
+        if (g_precision == 1)                                                                                                         \
+            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 3, 256>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 1, 256>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
+    } while (0)
+                if (bnw == 96) DGMR_GLDS_BIG(96, 4, 1);
+                else DGMR_GLDS_BIG(64, 4, 1);
+#undef DGMR_GLDS_BIG
+            }
+            else if (glds_ok && !big) {
 #define DGMR_GLDS(BN_, WM_, WN_)                                                                                                      \
     do {                                                                                                                              \
         if (g_precision == 1)                                                                                                         \
@@ -631,8 +647,6 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
                     hipLaunchKernelGGL((conv3x3_win_kernel<128, 2, 2, 3, 1, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
                 else DGMR_WIN(128, 2, 2);
             }
-            else if (bnw == 96 && big)
-                hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 3, 1, true, 256>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
             else if (bnw == 96) {
                 // bf16x3 at 96 channels: ONE weight stage and the halo fetched at the chunk boundary (48 KB of LDS instead of 63, no
                 // spill at 168 VGPRs) let three workgroups share a CU, which is worth more than the saved barrier (measured

@@ -35,15 +35,21 @@ __device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t* lds) {
 // __syncthreads(), but the memory model does not oblige it to; tests/test_abi.py greps the disassembly for it).
 __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift, const int tiles_w,
-                                                              const int tiles_hw, const int g_shift) {
-    constexpr int BM = 128, CK = 32;
+// BM: output pixels per workgroup.  256 (8 x 32 or 16 x 16 pixels of one image) gives every wave twice the pixels per weight
+// fragment: (TM + TN) * planes LDS reads feed TM * TN * terms MFMAs, half the barriers per MFMA, a 1.33x instead of 1.59x halo - at
+// two workgroups per CU instead of three (68 KB of LDS, ~170 registers).
+template <int BN, int WM, int WN, int NS, int BM = 128>
+__global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift,
+                                                                                          const int tiles_w, const int tiles_hw,
+                                                                                          const int g_shift) {
+    constexpr int CK = 32;
+    constexpr int LOG_BM = BM == 256 ? 8 : 7;
+    static_assert(BM == 128 || BM == 256, "BM");
     constexpr int ROW = CK / 2;  // dwords per LDS row
     constexpr int NP = NS == 3 ? 2 : 1;
     constexpr bool SPLIT = NS == 3;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int AMAX = 6 * 34;
+    constexpr int AMAX = BM == 256 ? 10 * 34 : 6 * 34;  // halo pixels: 6 x 34 / 10 x 18 (BM 128), 10 x 34 / 18 x 18 (BM 256)
     constexpr int APASS = (AMAX * 8 + 255) / 256;
     constexpr int BUNITS = BN * 4 * NP;  // 16-byte units of one weight stage
     constexpr int BPASS = (BUNITS + 255) / 256;  // plain bf16 at 96 channels: 384 units = one full pass + waves 0, 1 of a second
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void conv3x3_glds_kernel(co
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int TW = 1 << tw_shift, TH = (BM >> tw_shift) >> g_shift;
-    const int sub_shift = 7 - g_shift;
+    const int sub_shift = LOG_BM - g_shift;
     const int tile = blockIdx.x;
     const int n = g_shift ? (tile << g_shift) : tile / tiles_hw;  // first image of the tile; 3-D: depth plane (sample * D + d)
     const int KD = p.KD;                                           // 1, or 3 (then g_shift == 0)
