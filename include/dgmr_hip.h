@@ -84,7 +84,17 @@ typedef struct dgmr_conv_args {
     int32_t residual_up;     /* 1: residual is [N][H/2][W/2][Cout], added with nearest-2x upsampling (the 1x1 shortcut of an upsampling
                                 G-block evaluated before the upsample: conv1x1(up(x)) == up(conv1x1(x)), common.py:142-143,154) */
     int32_t reserved0;
+    /* -- ABI 6 -- */
+    float* stats_out;        /* NULL, or [dgmr_conv_stats_rows(args)][2][Cout]: per-workgroup-tile partial sums (sum y, sum y^2) of the
+                                OUTPUT, one row per pixel tile - the BatchNorm batch statistics of the next layer taken in this conv's
+                                epilogue instead of by a second pass over y (GBlock: bn2(first_conv(..)), common.py:76-80,145-151).
+                                Rows are ordered like the samples; dgmr_bn_partial_reduce folds them per statistics group. */
 } dgmr_conv_args;
+
+/* Number of partial-sum rows dgmr_conv_fwd writes to stats_out for these arguments (host arithmetic, no launch): 0 when the kernel
+ * the library would dispatch has no fused statistics (only the LDS-window 3x3 kernels of the bf16 modes do), then stats_out must
+ * be NULL and the caller takes the statistics with dgmr_bn_stats. */
+int dgmr_conv_stats_rows(const dgmr_conv_args* a);
 
 #define DGMR_EPI_PLAIN 0
 #define DGMR_EPI_GRU_GATE 1  /* pre_out = v ; y = sigmoid(v) * gru_h                              (ConvGRU.py:69-71,78) */
@@ -216,6 +226,9 @@ int dgmr_bn_stats(const float* x, double* sums, int G, int64_t R, int C, void* s
 int dgmr_bn_finalize(const double* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked, float* a, float* b, float* save_mean, float* save_rstd, int G,
                      int64_t R, int C, float eps, float momentum, const int32_t* order, void* stream);
+/* sums[g][0][c] += sum over the group's rows of partials[row][0][c], sums[g][1][c] likewise: `partials` is what dgmr_conv_fwd wrote to
+ * stats_out ([G * rows_per_group][2][C] floats, fp32 sums over one pixel tile each); double accumulation from here on. */
+int dgmr_bn_partial_reduce(const float* partials, double* sums, int G, int64_t rows_per_group, int C, void* stream);
 /* sums[g][0][c] = sum_r g ; sums[g][1][c] = sum_r g * xhat   with xhat = (x-mean)*rstd  (sums zeroed by caller). */
 int dgmr_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* rstd, double* sums, int G,
                        int64_t R, int C, void* stream);

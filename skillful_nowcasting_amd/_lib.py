@@ -27,7 +27,7 @@ class ConvArgs(Structure):
         ("scale_group", c_int32), ("pre_group", c_int32), ("mask_group", c_int32), ("act_relu", c_int32),
         ("w_cin", c_int32), ("w_coff", c_int32), ("epi_mode", c_int32), ("ksplit", c_int32),
         ("gru_h", P), ("gru_pu", P), ("pre_out", P), ("splitk_ws", P), ("splitk_ws_bytes", c_int64), ("w_split", P),
-        ("residual_up", c_int32), ("reserved0", c_int32),
+        ("residual_up", c_int32), ("reserved0", c_int32), ("stats_out", P),
     ]
 
 
@@ -57,6 +57,8 @@ i, f, L = c_int, c_float, c_int64
 # name -> argtypes (every function returns int except the two noted below); must match include/dgmr_hip.h
 SIGNATURES = {
     "dgmr_conv_fwd": [POINTER(ConvArgs), P],
+    "dgmr_conv_stats_rows": [POINTER(ConvArgs)],
+    "dgmr_bn_partial_reduce": [P, P, i, L, i, P],
     "dgmr_conv_flip_weights": [P, P, i, i, i, i, i, i, i, P],
     "dgmr_conv_wgrad": [POINTER(WgradArgs), P],
     "dgmr_conv_wgrad_nsplit": [i, i, i, i],

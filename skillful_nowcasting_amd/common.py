@@ -34,16 +34,18 @@ class GBlock(torch.nn.Module):
         self.first_conv_3x3 = conv2d(input_channels, input_channels, 3, eps=spectral_normalized_eps)
         self.last_conv_3x3 = conv2d(input_channels, output_channels, 3, eps=spectral_normalized_eps)
 
-    def forward(self, x: torch.Tensor, calls: int = 1, layout=None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, calls: int = 1, layout=None, in_stats=None, out_stats: bool = False):
         """`calls` > 1: x holds `calls` consecutive calls of this block (forecast steps [x generator draws]) as one batch; every
-        call keeps its own BatchNorm batch statistics and spectral-norm sigma; `layout`: ops.CallLayout."""
+        call keeps its own BatchNorm batch statistics and spectral-norm sigma; `layout`: ops.CallLayout.
+        `in_stats`: partial sums of x taken by the conv that produced it; `out_stats=True`: -> (y, partial sums of y) for the next
+        block's first BatchNorm (statistics ride in the producing conv's epilogue instead of a second pass over the tensor)."""
         kw = dict(calls=calls, layout=layout)
         if x.shape[1] != self.output_channels:
             sc = self.conv_1x1(x, **kw)
         else:
             sc = x
-        x2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x, calls, layout), **kw)
-        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls, layout), residual=sc, **kw)
+        x2, st2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x, calls, layout, in_stats), want_stats=True, **kw)
+        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls, layout, st2), residual=sc, want_stats=out_stats, **kw)
 
 
 class UpsampleGBlock(torch.nn.Module):
@@ -62,13 +64,14 @@ class UpsampleGBlock(torch.nn.Module):
         self.first_conv_3x3 = conv2d(input_channels, input_channels, 3, eps=spectral_normalized_eps)
         self.last_conv_3x3 = conv2d(input_channels, output_channels, 3, eps=spectral_normalized_eps)
 
-    def forward(self, x: torch.Tensor, calls: int = 1, layout=None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, calls: int = 1, layout=None, in_stats=None, out_stats: bool = False):
         # shortcut: conv1x1(upsample(x)) == upsample(conv1x1(x)) exactly (a 1x1 conv acts per pixel), so it is evaluated on the
         # low-resolution map (4x fewer FLOPs and bytes) and upsampled inside the last conv's residual add
         kw = dict(calls=calls, layout=layout)
         sc = self.conv_1x1(x, **kw)
-        x2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x, calls, layout), upsample=True, **kw)
-        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls, layout), residual=sc, residual_up=True, **kw)
+        x2, st2 = self.first_conv_3x3(x, bn=self.bn1.prepare(x, calls, layout, in_stats), upsample=True, want_stats=True, **kw)
+        return self.last_conv_3x3(x2, bn=self.bn2.prepare(x2, calls, layout, st2), residual=sc, residual_up=True,
+                                  want_stats=out_stats, **kw)
 
 
 class DBlock(torch.nn.Module):

@@ -287,9 +287,6 @@ int g_precision = 0;
 // dgmr_conv_tune(): -1 = automatic
 int g_tune_variant = -1, g_tune_ksplit = -1, g_tune_window = -1, g_tune_wgrad_window = -1;
 
-// dgmr_conv_tune(window = 2): the 256-pixel-tile LDS-DMA window kernel wherever the geometry allows (A/B switch)
-static bool glds_tune_big() { return g_precision != 0 && g_tune_window == 2; }
-
 // WM x WN: wave grid of the f32 kernel; WMB x WNB: of the bf16 kernels (two register stages: 128x128 needs 8 waves to fit)
 template <int BM, int BN, int WM, int WN, int WMB = WM, int WNB = WN>
 int launch_conv(const dgmr_conv_args& a, int M, int Ktot, hipStream_t s) {
@@ -538,6 +535,62 @@ __global__ void zero_n_kernel(float* p, int n) {
 
 }  // namespace
 
+// Which LDS-window 3x3 kernel (if any) takes a conv, and with which tiling: shared by the launch and by dgmr_conv_stats_rows.
+struct WinPlan {
+    int tw_shift, g_shift, tiles_w, tiles_hw, bnw, grid_x;
+    bool big, glds;  // 256-pixel tiles; LDS-DMA kernel (has the fused output statistics)
+};
+static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
+    const int64_t M64 = (int64_t)p.N * p.D * p.H * p.W;
+    const int C = p.Cout;
+    // 8x8 maps: a tile is two whole images; every per-sample group (1/sigma, BatchNorm statistics, relu mask) must then hold
+    // an even number of samples so that a tile never straddles two groups
+    const bool small8 = p.H == 8 && p.W == 8 && p.D == 1 && !p.upsample && p.N % 2 == 0 && (!p.scale || p.scale_group % 2 == 0) &&
+                        (!p.pre_a || p.pre_group % 2 == 0) && (!p.mask_a || p.mask_group % 2 == 0);
+    // the LDS-DMA kernel (both bf16 modes) also takes 3x3x3 convs, plane by plane
+    const bool glds_ok = g_precision != 0 && (g_tune_window < 0 || g_tune_window == 3);
+    const bool is3d = p.KD == 3 && p.D > 1 && glds_ok && !p.upsample && !p.residual_up;
+    if (!(g_precision != 0 && p.w_split && ((p.KD == 1 && p.D == 1) || is3d) && p.KH == 3 && p.KW == 3 && p.Cin % 8 == 0 &&
+          (p.W == 16 || p.W % 32 == 0 || small8) &&
+          (g_tune_window < 0 ? (M64 / 128) * ((C + 127) / 128) >= 192 : g_tune_window >= 1)))
+        return false;
+    w->tw_shift = small8 ? 3 : (p.W == 16 ? 4 : 5);
+    w->g_shift = small8 ? 1 : 0;
+    w->bnw = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
+    // 256-pixel tiles (8 x 32 or 16 x 16 pixels of one image), LDS-DMA kernel
+    // (not at 128 output channels: 8 accumulator blocks per wave spill at two workgroups per CU).  Measured +2 ... +8 % on the
+    // 96- / 64-channel layers of the sampler at T x B maps (gpurun r2o), -10 ... -20 % on launches of a few hundred workgroups:
+    // automatic only when the 256-pixel tiles still fill the chip four times over
+    const int64_t big_wgs = (M64 / 256) * ((C + w->bnw - 1) / w->bnw);
+    w->big = !small8 && w->bnw != 128 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 &&
+             (g_tune_window == 2 || (g_tune_window < 0 && big_wgs >= 2048));
+    w->glds = glds_ok || w->big;
+    const int TWv = 1 << w->tw_shift, THv = ((w->big ? 256 : 128) >> w->tw_shift) >> w->g_shift;
+    if (p.H % THv != 0) return false;
+    w->tiles_w = p.W / TWv;
+    w->tiles_hw = w->tiles_w * (p.H / THv);
+    w->grid_x = w->g_shift ? p.N >> w->g_shift : p.N * p.D * w->tiles_hw;
+    return true;
+}
+
+static void conv_args_defaults(dgmr_conv_args& p) {
+    if (p.scale_group < 1) p.scale_group = 1;
+    if (p.pre_group < 1) p.pre_group = 1;
+    if (p.mask_group < 1) p.mask_group = 1;
+    if (p.w_cin == 0) {
+        p.w_cin = p.Cin;
+        p.w_coff = 0;
+    }
+}
+
+extern "C" int dgmr_conv_stats_rows(const dgmr_conv_args* a) {
+    if (!a || a->N <= 0 || a->H <= 0 || a->W <= 0 || a->Cout <= 0 || a->epi_mode != DGMR_EPI_PLAIN) return 0;
+    dgmr_conv_args p = *a;
+    conv_args_defaults(p);
+    WinPlan w;
+    return (window_plan(p, &w) && w.glds) ? w.grid_x : 0;
+}
+
 extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     DGMR_CHECK_ARG(a && a->x && a->w && a->y, "dgmr_conv_fwd: null pointer");
     DGMR_CHECK_ARG(a->Cin % 4 == 0 && a->Cin > 0, "dgmr_conv_fwd: Cin=%d must be a positive multiple of 4", a->Cin);
@@ -557,13 +610,7 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     DGMR_CHECK_ARG(a->w_cin == 0 || (a->w_cin >= a->w_coff + a->Cin && a->w_coff >= 0 && a->w_coff % 4 == 0 && a->w_cin % 4 == 0),
                    "dgmr_conv_fwd: weight slice [%d, %d) of %d channels is invalid", a->w_coff, a->w_coff + a->Cin, a->w_cin);
     dgmr_conv_args p = *a;
-    if (p.scale_group < 1) p.scale_group = 1;
-    if (p.pre_group < 1) p.pre_group = 1;
-    if (p.mask_group < 1) p.mask_group = 1;
-    if (p.w_cin == 0) {
-        p.w_cin = p.Cin;
-        p.w_coff = 0;
-    }
+    conv_args_defaults(p);
     const int M = (int)M64, Ktot = a->KD * a->KH * a->KW * a->Cin;
     hipStream_t s = (hipStream_t)stream;
     const int C = a->Cout;
@@ -583,27 +630,14 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     else variant = V_F128x32;
     if (g_tune_variant >= V_F128x128 && g_tune_variant <= V_F128x32) variant = g_tune_variant;
     // 3x3 convs of the big feature maps in the bf16 modes: LDS-window kernel (needs pre-split weights)
-    // 8x8 maps: a tile is two whole images; every per-sample group (1/sigma, BatchNorm statistics, relu mask) must then hold
-    // an even number of samples so that a tile never straddles two groups
-    const bool small8 = p.H == 8 && p.W == 8 && p.D == 1 && !p.upsample && p.N % 2 == 0 && (!p.scale || p.scale_group % 2 == 0) &&
-                        (!p.pre_a || p.pre_group % 2 == 0) && (!p.mask_a || p.mask_group % 2 == 0);
-    // the LDS-DMA kernel (both bf16 modes) also takes 3x3x3 convs, plane by plane
-    const bool glds_ok = g_precision != 0 && (g_tune_window < 0 || g_tune_window == 3);
-    const bool is3d = p.KD == 3 && p.D > 1 && glds_ok && !p.upsample && !p.residual_up;
-    if (g_precision != 0 && p.w_split && ((p.KD == 1 && p.D == 1) || is3d) && p.KH == 3 && p.KW == 3 && p.Cin % 8 == 0 &&
-        (p.W == 16 || p.W % 32 == 0 || small8) &&
-        (g_tune_window < 0 ? (M64 / 128) * ((C + 127) / 128) >= 192 : g_tune_window >= 1)) {
-        const int tw_shift = small8 ? 3 : (p.W == 16 ? 4 : 5);
-        const int g_shift = small8 ? 1 : 0;
-        const int bnw0 = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
-        // 256-pixel tiles (8 x 32 or 16 x 16 pixels of one image), LDS-DMA kernel
-        // (not at 128 output channels: 8 accumulator blocks per wave spill at two workgroups per CU)
-        const bool big = glds_tune_big() && !small8 && bnw0 != 128 && p.H % (256 >> tw_shift) == 0;
-        const int TWv = 1 << tw_shift, THv = ((big ? 256 : 128) >> tw_shift) >> g_shift;
-        if (p.H % THv == 0) {
-            const int tiles_w = p.W / TWv, tiles_hw = tiles_w * (p.H / THv);
-            const int bnw = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
-            const dim3 grid((unsigned)(g_shift ? p.N >> g_shift : p.N * p.D * tiles_hw), (unsigned)((C + bnw - 1) / bnw));
+    WinPlan wp;
+    DGMR_CHECK_ARG(!p.stats_out || (window_plan(p, &wp) && wp.glds && p.epi_mode == DGMR_EPI_PLAIN),
+                   "dgmr_conv_fwd: stats_out given but the dispatched kernel has no fused statistics (ask dgmr_conv_stats_rows first)");
+    if (window_plan(p, &wp)) {
+        {
+            const int tw_shift = wp.tw_shift, g_shift = wp.g_shift, tiles_w = wp.tiles_w, tiles_hw = wp.tiles_hw, bnw = wp.bnw;
+            const bool big = wp.big, glds_ok = wp.glds && !wp.big;
+            const dim3 grid((unsigned)wp.grid_x, (unsigned)((C + bnw - 1) / bnw));
             const int v = bnw == 128 ? V_WIN128 : (bnw == 96 ? V_WIN96 : V_WIN64);
             ProfScope ps(v, flops, s);
 #define DGMR_WIN(BN_, WM_, WN_)                                                                                              \

@@ -280,6 +280,12 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     // dependent loads made a ConvGRU step conv spend as long in its epilogue as in its 18 taps.)
     const int emode = p.epi_mode;
     const int cmax = p.Cout - 1;
+    // BatchNorm statistics of the OUTPUT for the next layer, taken here (stats_out): per column sum y and sum y^2 over this lane's
+    // 16 TM rows, folded over the two lane halves, the WM waves (LDS) and written as ONE row of partials per workgroup tile
+    float st0[TN], st1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) st0[j] = st1[j] = 0.f;
+    const bool want_stats = p.stats_out != nullptr && emode == DGMR_EPI_PLAIN;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -314,6 +320,10 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
                     if (p.residual) o += rs[j];
                     if (p.mask_src) o = fmaf(ms[j], maj[j], mbj[j]) > 0.f ? o : 0.f;
                     if (colj[j] < p.Cout) p.y[mrow + colj[j]] = o;
+                    if (want_stats) {
+                        st0[j] += o;
+                        st1[j] = fmaf(o, o, st1[j]);
+                    }
                 }
             } else {  // ConvGRU step: pre_out = v; gate: y = sigmoid(v) * h; blend: y = s*h + (1-s)*relu(v), s = sigmoid(pu)
                 float hv[TN], pv[TN];
@@ -338,6 +348,27 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
                     }
                 }
             }
+        }
+    }
+    if (want_stats) {  // (wave-uniform; the main loop ended on a barrier, the LDS is free)
+        float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            st0[j] += __shfl_xor(st0[j], 32, 64);
+            st1[j] += __shfl_xor(st1[j], 32, 64);
+            if (lane < 32) {
+                const int cl = wn * TN * 32 + j * 32 + lane;
+                red[(wm * BN + cl) * 2 + 0] = st0[j];
+                red[(wm * BN + cl) * 2 + 1] = st1[j];
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BN * 2; idx += 256) {
+            const int cl = idx >> 1, which = idx & 1;
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < WM; ++q) v += red[(q * BN + cl) * 2 + which];
+            if (n0 + cl < p.Cout) p.stats_out[((size_t)blockIdx.x * 2 + which) * p.Cout + n0 + cl] = v;
         }
     }
 }

@@ -431,6 +431,18 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, double* __restrict_
         R, C, sums);
 }
 
+// sums[g][k][c] += sum_r partials[(g*R + r)][k][c]: blockIdx.y = g, blockIdx.z = slice of the rows; one thread per (k, c)
+__global__ void bn_partial_reduce_kernel(const float* __restrict__ partials, double* __restrict__ sums, int64_t R, int C2) {
+    const int g = blockIdx.y;
+    const int64_t per = (R + gridDim.z - 1) / gridDim.z;
+    const int64_t r0 = blockIdx.z * per, r1 = min(R, r0 + per);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < C2; j += gridDim.x * blockDim.x) {
+        double a = 0.0;
+        for (int64_t r = r0; r < r1; ++r) a += (double)partials[((size_t)g * R + r) * C2 + j];
+        atomicAdd(sums + (size_t)g * C2 + j, a);
+    }
+}
+
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, double* __restrict__ sums, int64_t R, int C) {
     chan_reduce2(
@@ -1117,6 +1129,15 @@ static inline dim3 reduce_grid(int G, int64_t R) {
 extern "C" int dgmr_bn_stats(const float* x, double* sums, int G, int64_t R, int C, void* stream) {
     DGMR_CHECK_ARG(x && sums && G > 0 && R > 0 && C > 0, "dgmr_bn_stats: bad args");
     hipLaunchKernelGGL(bn_stats_kernel, reduce_grid(G, R), dim3(256), 0, ST, x, sums, R, C);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_bn_partial_reduce(const float* partials, double* sums, int G, int64_t rows_per_group, int C, void* stream) {
+    DGMR_CHECK_ARG(partials && sums && G > 0 && rows_per_group > 0 && C > 0, "dgmr_bn_partial_reduce: bad args");
+    const int C2 = 2 * C;
+    int zs = (int)std::min<int64_t>(64, (rows_per_group + 31) / 32);  // >= 32 rows per slice
+    hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C2 + 255) / 256, G, zs), dim3(256), 0, ST, partials, sums, rows_per_group, C2);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

@@ -61,10 +61,14 @@ class Sampler(torch.nn.Module, PyTorchModelHubMixin):
             # keeping its own spectral-norm sigma and BatchNorm batch statistics exactly as the reference's T calls do
             h = gru.forward_batched(h, init_states[3 - lvl], T, x_shared=(lvl == 0), draws=draws, layout=lay)
             h = c11(h, calls=calls, layout=lay)
-            h = g(h, calls=calls, layout=lay)
-            h = upg(h, calls=calls, layout=lay)
+            # BatchNorm batch statistics travel with the tensors: the conv that writes a BatchNorm's input sums it in its epilogue
+            h, st = g(h, calls=calls, layout=lay, out_stats=True)
+            if lvl == 3:
+                h, st = upg(h, calls=calls, layout=lay, in_stats=st, out_stats=True)
+            else:
+                h, st = upg(h, calls=calls, layout=lay, in_stats=st), None
         # relu(bn(h)) folded into the 1x1 conv's operand load; PixelShuffle + stack in one layout pass
-        h = self.conv_1x1(h, bn=self.bn.prepare(h, calls, lay), calls=calls, layout=lay)
+        h = self.conv_1x1(h, bn=self.bn.prepare(h, calls, lay, st), calls=calls, layout=lay)
         return ops.d2s_frames(h, T)
 
 

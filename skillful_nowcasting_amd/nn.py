@@ -300,7 +300,7 @@ class SNConv(_SpectralNormBase):
 
     def forward(self, x, *, pre_relu: bool = False, bn: Optional[BNState] = None, upsample: bool = False, residual=None,
                 act_relu: bool = False, calls: int = 1, sn: Optional[ops.SNCall] = None, residual_up: bool = False,
-                layout: Optional[ops.CallLayout] = None):
+                layout: Optional[ops.CallLayout] = None, want_stats: bool = False):
         """`calls` > 1: x is a batch of `calls` groups (forecast steps / frames [x generator draws]), each group being one call of
         this module in the reference (own power iteration, own sigma); `layout`: which call each group is (ops.CallLayout).
         `sn`: a record drawn earlier with `_sigma` (ConvGRU steps)."""
@@ -308,8 +308,14 @@ class SNConv(_SpectralNormBase):
             calls = layout.calls
         if sn is None:
             sn = self._sigma(calls, layout)
-        spec = ConvSpec(upsample=upsample, pre_relu=pre_relu, bn=bn, sn=sn, act_relu=act_relu, residual_up=residual_up)
-        return ops.conv(x, self.weight_orig, self.bias, sn.inv_sigma, residual, spec)
+        # want_stats: -> (y, partials): per-tile sums of y and y^2 from the conv's epilogue for the BatchNorm that follows (None when
+        # the dispatched kernel has none; BatchNorm.prepare then reads y)
+        spec = ConvSpec(upsample=upsample, pre_relu=pre_relu, bn=bn, sn=sn, act_relu=act_relu, residual_up=residual_up,
+                        want_stats=want_stats and self.training)
+        out = ops.conv(x, self.weight_orig, self.bias, sn.inv_sigma, residual, spec)
+        if want_stats and not spec.want_stats:
+            return out, None
+        return out
 
 
 class SNLinear1(_SpectralNormBase):
@@ -372,13 +378,14 @@ class BatchNorm(nn.BatchNorm2d):
                                     self.running_var, self.num_batches_tracked, self.eps, self.momentum, self.training, 1, None)
         return y.view(n, h, w, c).permute(0, 3, 1, 2)
 
-    def prepare(self, x, groups: int = 1, layout: Optional[ops.CallLayout] = None) -> BNState:
+    def prepare(self, x, groups: int = 1, layout: Optional[ops.CallLayout] = None, partials=None) -> BNState:
         """`groups` > 1: x holds that many calls of the reference's module, each with its own batch statistics; `layout` gives the
-        order in which the reference made them (= the order of the running-statistics updates)."""
+        order in which the reference made them (= the order of the running-statistics updates).  `partials`: per-tile sums of x and
+        x^2 already taken by the conv that produced x (SNConv(..., want_stats=True))."""
         if layout is not None:
             groups = layout.calls
         return ops.bn_prepare(x, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked, self.eps,
-                              self.momentum, self.training, groups, layout)
+                              self.momentum, self.training, groups, layout, partials)
 
 
 class BatchNorm1d(nn.BatchNorm1d):

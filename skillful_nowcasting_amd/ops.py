@@ -267,7 +267,7 @@ class BNState:
 
 
 def bn_prepare(x: torch.Tensor, gamma, beta, running_mean, running_var, num_batches_tracked, eps: float, momentum: float,
-               train: bool, groups: int = 1, layout: Optional[CallLayout] = None) -> BNState:
+               train: bool, groups: int = 1, layout: Optional[CallLayout] = None, partials: Optional[torch.Tensor] = None) -> BNState:
     """BatchNorm statistics of x (train) or running statistics (eval) folded to y = a*x + b.
 
     torch.nn.BatchNorm2d semantics (dgmr/common.py:38-39,108-109; generators.py:113): biased batch variance
@@ -288,7 +288,11 @@ def bn_prepare(x: torch.Tensor, gamma, beta, running_mean, running_var, num_batc
     rstd = torch.empty(groups, c, device=dev)
     if train:
         sums = torch.zeros(groups * 2 * c, device=dev, dtype=torch.float64)
-        call("dgmr_bn_stats", _p(x), _p(sums), groups, r, c, _stream())
+        if partials is not None and partials.shape[0] % groups == 0 and partials.shape[2] == c:
+            # the conv that produced x already summed y and y^2 per pixel tile in its epilogue (`want_stats`): x is not read again
+            call("dgmr_bn_partial_reduce", _p(partials), _p(sums), groups, partials.shape[0] // groups, c, _stream())
+        else:
+            call("dgmr_bn_stats", _p(x), _p(sums), groups, r, c, _stream())
         if layout is not None and layout.calls != groups:
             raise RuntimeError(f"batch norm: {groups} call groups but the call layout describes {layout.calls}")
         call("dgmr_bn_finalize", _p(sums), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(num_batches_tracked),
@@ -313,6 +317,7 @@ class ConvSpec:
     gamma_scale: bool = False  # scale tensor is a learnable scalar parameter (Attention.gamma)
     act_relu: bool = False  # relu on the output (F.relu(conv(..)), common.py:424)
     residual_up: bool = False  # the residual is at half resolution and is added with nearest-2x upsampling
+    want_stats: bool = False  # also return per-tile partial sums (sum y, sum y^2) of the output: the next BatchNorm's batch statistics
 
     @property
     def groups(self) -> int:
@@ -383,7 +388,9 @@ EPI_PLAIN, EPI_GRU_GATE, EPI_GRU_BLEND = 0, 1, 2
 def _launch_conv(x, w_ptr, bias, scale, y, n, d, h, w_, cin, cout, kd, kh, kw, *, upsample=False, pre_relu=False, pre_a=None,
                  pre_b=None, pre_group=1, residual=None, addend=None, mask_src=None, mask_a=None, mask_b=None, mask_group=1,
                  scale_group=None, act_relu=False, w_cin=0, w_coff=0, epi_mode=EPI_PLAIN, gru_h=None, gru_pu=None, pre_out=None,
-                 device=None, w_split=None, residual_up=False):
+                 device=None, w_split=None, residual_up=False, want_stats=False):
+    """`want_stats`: ask for the BatchNorm partial sums of the OUTPUT (dgmr_conv_args.stats_out); returns the [rows, 2, Cout] partials
+    tensor, or None when the kernel the library dispatches for these arguments has no fused statistics."""
     a = ConvArgs()
     a.w_split = _p(w_split)
     a.residual_up = int(bool(residual_up))
@@ -400,7 +407,16 @@ def _launch_conv(x, w_ptr, bias, scale, y, n, d, h, w_, cin, cout, kd, kh, kw, *
     a.scale_group = scale_group if scale_group else n
     a.pre_group, a.mask_group = pre_group, mask_group
     a.act_relu = int(act_relu)
+    partials = None
+    if want_stats:
+        from ._lib import load
+
+        rows = int(load().dgmr_conv_stats_rows(ctypes.byref(a)))
+        if rows > 0:
+            partials = torch.empty(rows, 2, cout, device=y.device, dtype=torch.float32)
+            a.stats_out = partials.data_ptr()
     call("dgmr_conv_fwd", ctypes.byref(a), _stream())
+    return partials
 
 
 class ConvFn(Function):
@@ -429,10 +445,11 @@ class ConvFn(Function):
         groups = spec.groups
         if n % groups:
             raise RuntimeError(f"conv: batch {n} is not divisible into {groups} spectral-norm call groups")
-        _launch_conv(x, _p(w), bias, scale, y, n, d, h, wd, cin, cout, kd, kh, kw, upsample=spec.upsample,
-                     pre_relu=spec.pre_relu, pre_a=bn.a if bn else None, pre_b=bn.b if bn else None,
-                     pre_group=bn.group_size if bn else 1, residual=residual, act_relu=spec.act_relu,
-                     scale_group=n // groups, w_split=_split_planes(w, False), residual_up=spec.residual_up)
+        partials = _launch_conv(x, _p(w), bias, scale, y, n, d, h, wd, cin, cout, kd, kh, kw, upsample=spec.upsample,
+                                pre_relu=spec.pre_relu, pre_a=bn.a if bn else None, pre_b=bn.b if bn else None,
+                                pre_group=bn.group_size if bn else 1, residual=residual, act_relu=spec.act_relu,
+                                scale_group=n // groups, w_split=_split_planes(w, False), residual_up=spec.residual_up,
+                                want_stats=spec.want_stats)
         ctx.spec = spec  # flags only are read from it in backward; its tensors are re-read from saved_tensors
         ctx.has_residual = residual is not None
         # parameters are kept as-is (checkpointing hands back DETACHED copies of saved tensors: .grad must land on the real ones)
@@ -444,10 +461,14 @@ class ConvFn(Function):
         ctx.save_for_backward(x, scale, y if spec.act_relu else None, sn.u if sn else None, sn.v if sn else None,
                               bn.a if bn else None, bn.b if bn else None, bn.mean if bn else None, bn.rstd if bn else None)
         ctx.geom = (n, cin, cout, d, h, wd, kd, kh, kw)
+        if spec.want_stats:
+            if partials is not None:
+                ctx.mark_non_differentiable(partials)
+            return y, partials
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpartials=None):
         spec: ConvSpec = ctx.spec
         x, scale, y_act, sn_u, sn_v, bn_a, bn_b, bn_mean, bn_rstd = ctx.saved_tensors
         w, bias, scale_param = ctx.params

@@ -203,3 +203,63 @@ def test_dblock_calls_vs_oracle(cin, cout, hw, calls, per, keep):
     for k, v in blk.state_dict().items():
         if k.endswith(("._u", "._v")):
             _close(v, sd[k], k, 5e-5)
+
+
+# n, h, w, cin, cout, groups, upsample, residual ("", "same", "up"): the sampler's BatchNorm producers
+STATS_SHAPES = [
+    (8, 32, 32, 96, 96, 4, False, "same"),     # 96-channel tile, residual
+    (8, 16, 16, 192, 192, 2, True, ""),        # upsampling conv, 32-wide output rows, 64-channel tail of 192 = 128 + 64
+    (4, 32, 32, 48, 48, 2, True, "up"),        # 64-wide rows, 64-channel tile (48 used), low-resolution residual
+    (12, 8, 8, 768, 768, 3, False, "same"),    # 8x8 maps: two images per tile, 128-channel tile
+    (128, 64, 64, 96, 96, 16, False, ""),     # enough tiles for the 256-pixel kernel
+    (8, 16, 16, 384, 384, 4, False, "same"),   # 16-wide maps
+]
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("n,h,w,cin,cout,groups,up,res", STATS_SHAPES)
+def test_conv_output_statistics(mode, n, h, w, cin, cout, groups, up, res):
+    """dgmr_conv_args.stats_out: the per-tile (sum y, sum y^2) a window conv leaves for the next BatchNorm reduce to the same batch
+    statistics as a pass over y, the output itself is bit-identical with and without them, and bn_prepare(partials=) produces the
+    same normalisation as bn_prepare reading y."""
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import ops
+
+    torch.manual_seed(n + h + cin)
+    ho, wo = (2 * h, 2 * w) if up else (h, w)
+    mf = torch.channels_last
+    x = (torch.randn(n, cin, h, w) + 0.3).to(DEV).contiguous(memory_format=mf)
+    wt = torch.nn.Parameter((torch.randn(cout, cin, 3, 3) * (cin * 9) ** -0.5).to(DEV).contiguous(memory_format=mf))
+    b = torch.nn.Parameter(torch.randn(cout).to(DEV))
+    rshape = {"": None, "same": (n, cout, ho, wo), "up": (n, cout, ho // 2, wo // 2)}[res]
+    r = torch.randn(*rshape).to(DEV).contiguous(memory_format=mf) if rshape else None
+    inv_sigma = (torch.rand(groups) + 0.5).to(DEV)
+    kk = cin * 9
+    sn = ops.SNCall(inv_sigma, torch.zeros(groups, cout, device=DEV), torch.zeros(groups, kk, device=DEV), groups)
+    S.set_precision(mode)
+    try:
+        with torch.no_grad():
+            spec = dict(pre_relu=True, sn=sn, upsample=up, residual_up=(res == "up"))
+            y0 = ops.conv(x, wt, b, inv_sigma, r, ops.ConvSpec(**spec))
+            y1, partials = ops.conv(x, wt, b, inv_sigma, r, ops.ConvSpec(want_stats=True, **spec))
+            assert partials is not None, "the LDS-DMA window kernel should have taken this conv"
+            assert torch.equal(y0, y1)
+            rows = partials.shape[0]
+            assert rows % groups == 0 and partials.shape[1:] == (2, cout)
+            yd = y1.double().view(groups, n // groups, cout, ho * wo)
+            want = torch.stack([yd.sum((1, 3)), (yd * yd).sum((1, 3))], 1)  # [groups, 2, C]
+            got = partials.double().view(groups, rows // groups, 2, cout).sum(1)
+            _close(got, want, "partial sums", 2e-6)
+            # the BatchNorm that follows: same affine from the partials as from a pass over y
+            g = torch.nn.Parameter(torch.rand(cout, device=DEV) + 0.5)
+            be = torch.nn.Parameter(torch.randn(cout, device=DEV))
+            outs = []
+            for part in (None, partials):
+                rm, rv, nb = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+                st = ops.bn_prepare(y1, g, be, rm, rv, nb, 1e-5, 0.1, True, groups, None, part)
+                outs.append((st.a, st.b, st.mean, st.rstd, rm, rv))
+            for got_t, ref_t, what in zip(outs[1], outs[0], ("a", "b", "mean", "rstd", "running_mean", "running_var")):
+                _close(got_t, ref_t, f"bn {what}", 5e-6)
+    finally:
+        S.set_precision("f32")
+    torch.cuda.synchronize()
