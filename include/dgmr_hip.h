@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGMR_ABI_VERSION 6
+#define DGMR_ABI_VERSION 7
 
 int dgmr_abi_version(void);
 const char* dgmr_last_error(void);
@@ -88,7 +88,9 @@ typedef struct dgmr_conv_args {
     float* stats_out;        /* NULL, or [dgmr_conv_stats_rows(args)][2][Cout]: per-workgroup-tile partial sums (sum y, sum y^2) of the
                                 OUTPUT, one row per pixel tile - the BatchNorm batch statistics of the next layer taken in this conv's
                                 epilogue instead of by a second pass over y (GBlock: bn2(first_conv(..)), common.py:76-80,145-151).
-                                Rows are ordered like the samples; dgmr_bn_partial_reduce folds them per statistics group. */
+                                Rows are ordered like the samples; dgmr_bn_partial_reduce folds them per statistics group.
+                                With mask_src (data gradient through relu(BatchNorm(x))) the second sum is sum y * mask_src instead:
+                                with dgmr_bn_bwd_center the two sums BatchNorm's backward needs (common.py:76,145 backwards). */
 } dgmr_conv_args;
 
 /* Number of partial-sum rows dgmr_conv_fwd writes to stats_out for these arguments (host arithmetic, no launch): 0 when the kernel
@@ -229,6 +231,9 @@ int dgmr_bn_finalize(const double* sums, const float* gamma, const float* beta, 
 /* sums[g][0][c] += sum over the group's rows of partials[row][0][c], sums[g][1][c] likewise: `partials` is what dgmr_conv_fwd wrote to
  * stats_out ([G * rows_per_group][2][C] floats, fp32 sums over one pixel tile each); double accumulation from here on. */
 int dgmr_bn_partial_reduce(const float* partials, double* sums, int G, int64_t rows_per_group, int C, void* stream);
+/* In place: sums[g][1][c] = rstd[g][c] * (sums[g][1][c] - mean[g][c] * sums[g][0][c]): turns (sum g, sum g * x) - folded by
+ * dgmr_bn_partial_reduce from the stats_out rows of a data-gradient conv - into dgmr_bn_bwd_reduce's (sum g, sum g * xhat). */
+int dgmr_bn_bwd_center(double* sums, const float* mean, const float* rstd, int G, int C, void* stream);
 /* sums[g][0][c] = sum_r g ; sums[g][1][c] = sum_r g * xhat   with xhat = (x-mean)*rstd  (sums zeroed by caller). */
 int dgmr_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* rstd, double* sums, int G,
                        int64_t R, int C, void* stream);

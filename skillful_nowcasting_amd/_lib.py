@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdgmr_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 P = c_void_p  # every device pointer and the stream travel as void*
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "dgmr_conv_fwd": [POINTER(ConvArgs), P],
     "dgmr_conv_stats_rows": [POINTER(ConvArgs)],
     "dgmr_bn_partial_reduce": [P, P, i, L, i, P],
+    "dgmr_bn_bwd_center": [P, P, P, i, i, P],
     "dgmr_conv_flip_weights": [P, P, i, i, i, i, i, i, i, P],
     "dgmr_conv_wgrad": [POINTER(WgradArgs), P],
     "dgmr_conv_wgrad_nsplit": [i, i, i, i],

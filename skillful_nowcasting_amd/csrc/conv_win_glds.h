@@ -280,7 +280,8 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     // dependent loads made a ConvGRU step conv spend as long in its epilogue as in its 18 taps.)
     const int emode = p.epi_mode;
     const int cmax = p.Cout - 1;
-    // BatchNorm statistics of the OUTPUT for the next layer, taken here (stats_out): per column sum y and sum y^2 over this lane's
+    // BatchNorm statistics of the OUTPUT for the next layer, taken here (stats_out): per column sum y and sum y^2 (data gradient
+    // through relu(BatchNorm(x)), i.e. with mask_src: sum y and sum y * x, the two sums of BatchNorm's backward) over this lane's
     // 16 TM rows, folded over the two lane halves, the WM waves (LDS) and written as ONE row of partials per workgroup tile
     float st0[TN], st1[TN];
 #pragma unroll
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
                     if (colj[j] < p.Cout) p.y[mrow + colj[j]] = o;
                     if (want_stats) {
                         st0[j] += o;
-                        st1[j] = fmaf(o, o, st1[j]);
+                        st1[j] = fmaf(o, p.mask_src ? ms[j] : o, st1[j]);
                     }
                 }
             } else {  // ConvGRU step: pre_out = v; gate: y = sigmoid(v) * h; blend: y = s*h + (1-s)*relu(v), s = sigmoid(pu)

@@ -443,6 +443,15 @@ __global__ void bn_partial_reduce_kernel(const float* __restrict__ partials, dou
     }
 }
 
+__global__ void bn_bwd_center_kernel(double* __restrict__ sums, const float* __restrict__ mean, const float* __restrict__ rstd, int GC,
+                                     int C) {
+    GRID_STRIDE(i, GC) {
+        const int64_t g = i / C, c = i - g * C;
+        double* s = sums + g * 2 * C;
+        s[C + c] = (double)rstd[i] * (s[C + c] - (double)mean[i] * s[c]);
+    }
+}
+
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, double* __restrict__ sums, int64_t R, int C) {
     chan_reduce2(
@@ -1138,6 +1147,13 @@ extern "C" int dgmr_bn_partial_reduce(const float* partials, double* sums, int G
     const int C2 = 2 * C;
     int zs = (int)std::min<int64_t>(64, (rows_per_group + 31) / 32);  // >= 32 rows per slice
     hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C2 + 255) / 256, G, zs), dim3(256), 0, ST, partials, sums, rows_per_group, C2);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_bn_bwd_center(double* sums, const float* mean, const float* rstd, int G, int C, void* stream) {
+    DGMR_CHECK_ARG(sums && mean && rstd && G > 0 && C > 0, "dgmr_bn_bwd_center: bad args");
+    hipLaunchKernelGGL(bn_bwd_center_kernel, dim3(ew_blocks((int64_t)G * C)), dim3(EW_THREADS), 0, ST, sums, mean, rstd, G * C, C);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

@@ -526,6 +526,7 @@ class ConvFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wt = _flipped_weight(w)
+            g_sums = None
             if spec.upsample:
                 hi = empty_cl((n, cin, h, wd) if x.dim() == 4 else (n, cin, d, h, wd), dy)
                 _launch_conv(dy, _p(wt), None, scale, hi, n, d, h, wd, cout, cin, kd, kh, kw, scale_group=n // groups,
@@ -535,17 +536,22 @@ class ConvFn(Function):
                      _p(bn_a) if bn else None, _p(bn_b) if bn else None, bn.group_size if bn else 1, st)
             else:
                 g = empty_cl(x.shape, dy)
-                _launch_conv(dy, _p(wt), None, scale, g, n, d, h, wd, cout, cin, kd, kh, kw,
-                             mask_src=x if (bn or spec.pre_relu) else None, mask_a=bn_a if bn else None,
-                             mask_b=bn_b if bn else None, mask_group=bn.group_size if bn else 1, scale_group=n // groups,
-                             w_split=_split_planes(w, True))
+                # behind a BatchNorm the epilogue also leaves per-tile (sum g, sum g * x): BatchNorm's backward reduction
+                g_sums = _launch_conv(dy, _p(wt), None, scale, g, n, d, h, wd, cout, cin, kd, kh, kw,
+                                      mask_src=x if (bn or spec.pre_relu) else None, mask_a=bn_a if bn else None,
+                                      mask_b=bn_b if bn else None, mask_group=bn.group_size if bn else 1, scale_group=n // groups,
+                                      w_split=_split_planes(w, True), want_stats=bn is not None)
             if bn is None:
                 dx = g
             else:
                 c = cin
                 r = x.numel() // (c * bn.groups)
                 sums = torch.zeros(bn.groups * 2 * c, device=dev, dtype=torch.float64)
-                call("dgmr_bn_bwd_reduce", _p(g), _p(x), _p(bn_mean), _p(bn_rstd), _p(sums), bn.groups, r, c, st)
+                if g_sums is not None and g_sums.shape[0] % bn.groups == 0:
+                    call("dgmr_bn_partial_reduce", _p(g_sums), _p(sums), bn.groups, g_sums.shape[0] // bn.groups, c, st)
+                    call("dgmr_bn_bwd_center", _p(sums), _p(bn_mean), _p(bn_rstd), bn.groups, c, st)
+                else:
+                    call("dgmr_bn_bwd_reduce", _p(g), _p(x), _p(bn_mean), _p(bn_rstd), _p(sums), bn.groups, r, c, st)
                 dx = empty_cl(x.shape, dy)
                 dgam = grad_buffer(bn.gamma) if (bn.gamma is not None and bn.gamma.requires_grad) else None
                 dbet = grad_buffer(bn.beta) if (bn.beta is not None and bn.beta.requires_grad) else None

@@ -85,7 +85,8 @@ def band_check(what, precision, tol, rows, factor=None):
     for k, (hip, r32, r64) in rows.items():
         e_hip, e_ref = rel_err(hip, r64), rel_err(r32, r64)
         c, c_ref = cos_sim(hip, r64), cos_sim(r32, r64)
-        bound = max(tol, factor * e_ref)
+        f_k = factor * (2.0 if r64.numel() == 1 else 1.0)  # a single element (attention gamma): nothing to take a max over
+        bound = max(tol, f_k * e_ref)
         cbound = max(1e-4, 10.0 * factor * (1.0 - c_ref))
         # l2-relative error: robust against ISOLATED ReLU-boundary flips.  A pre-activation within ~1e-7 of zero falls on the other
         # side of the kink under another fp32 summation order and its whole gradient toggles; behind batch-statistics BatchNorm over

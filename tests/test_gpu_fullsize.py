@@ -6,6 +6,7 @@ the T-batched launches, the LDS-window kernel, split-K and the multi-module spec
 """
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import band_check as _band_check
 
@@ -200,8 +201,15 @@ def test_discriminator_fwd_bwd_paper_config(setup, precision, tol):
 
     torch.set_num_threads(min(16, torch.get_num_threads()))
     model, sd_cpu, _, _ = setup
+    # Eight DISTINCT sequences (per-sample amplitude and smooth structure), as a batch of real and generated radar is.  Eight iid
+    # uniform-noise sequences are a degenerate batch for the BatchNorm1d in front of the last linear layer: their pooled features
+    # agree to 1e-3 of their size (|mean| / batch std = 870 median, 2600 at the 90th percentile, measured on the CPU oracle), the
+    # normalisation divides by that tiny spread and every gradient of the spatial discriminator inherits the forward rounding error
+    # x ~1e3: 1.7e-1 in bf16x3, 2.4e-4 even for the reference's own fp32 (profiles/r02_pytest_gpu_r2p.log).  Here the ratio is 2.8.
     torch.manual_seed(31)
-    seq = torch.rand(8, 22, 1, 256, 256)
+    amp = torch.linspace(0.15, 2.5, 8).view(8, 1, 1, 1, 1)
+    low = F.interpolate(torch.rand(8 * 22, 1, 8, 8), size=(256, 256), mode="bilinear", align_corners=False).view(8, 22, 1, 256, 256)
+    seq = amp * (0.5 * torch.rand(8, 22, 1, 256, 256) + low * torch.rand(8, 1, 1, 1, 1) * 2)
     cot = torch.randn(8, 2, 1)
     torch.manual_seed(3)
     idxs = torch.randint(0, 22, (8,)).tolist()

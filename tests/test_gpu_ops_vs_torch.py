@@ -206,13 +206,13 @@ def test_dblock_calls_vs_oracle(cin, cout, hw, calls, per, keep):
 
 
 # n, h, w, cin, cout, groups, upsample, residual ("", "same", "up"): the sampler's BatchNorm producers
-STATS_SHAPES = [
-    (8, 32, 32, 96, 96, 4, False, "same"),     # 96-channel tile, residual
-    (8, 16, 16, 192, 192, 2, True, ""),        # upsampling conv, 32-wide output rows, 64-channel tail of 192 = 128 + 64
-    (4, 32, 32, 48, 48, 2, True, "up"),        # 64-wide rows, 64-channel tile (48 used), low-resolution residual
-    (12, 8, 8, 768, 768, 3, False, "same"),    # 8x8 maps: two images per tile, 128-channel tile
-    (128, 64, 64, 96, 96, 16, False, ""),     # enough tiles for the 256-pixel kernel
-    (8, 16, 16, 384, 384, 4, False, "same"),   # 16-wide maps
+STATS_SHAPES = [  # (the window kernels take a conv from 192 output tiles up)
+    (32, 32, 32, 96, 96, 4, False, "same"),    # 96-channel tile, residual
+    (16, 16, 16, 192, 192, 2, True, ""),       # upsampling conv, 32-wide output rows, 64-channel tail of 192 = 128 + 64
+    (8, 32, 32, 48, 48, 2, True, "up"),        # 64-wide rows, 64-channel tile (48 used), low-resolution residual
+    (72, 8, 8, 768, 768, 3, False, "same"),    # 8x8 maps: two images per tile, 128-channel tile
+    (128, 64, 64, 96, 96, 16, False, ""),      # enough tiles for the 256-pixel kernel
+    (32, 16, 16, 384, 384, 4, False, "same"),  # 16-wide maps
 ]
 
 

@@ -19,7 +19,7 @@ max(1e-3, 3 x its reference band) of its max magnitude (bf16x3: 10 x), and tenso
 well-conditioned test of the adversarial chain is tests/test_gpu_adversarial.py (float64 anchor, one backward from a fixed state).
 Parameters after the three steps are compared through their UPDATE (post - initial): Adam's normalised step m^/(sqrt(v^)+eps) is
 O(lr) for every element, including those whose gradient is rounding noise, so elementwise equality is not defined for noise
-elements; required: cosine(update, reference update) >= 0.98 and no element further than the largest possible disagreement
+elements; required: cosine(update, reference update) >= 0.98 (0.9 for the chaotic tensors above) and no element further than the largest possible disagreement
 (2.2 * lr * updates).  Buffers (u / v / running statistics): 1e-3 of max.
 """
 import json
@@ -97,7 +97,9 @@ def _check_post(sd0, sd1, rec, keys, kw, steps):
             net = "generator." if name.startswith("generator.") else "discriminator."
             d_ref, d_got = (ref - sd0[name]).double().flatten(), (got - sd0[name]).double().flatten()
             cos = torch.nn.functional.cosine_similarity(d_got, d_ref, dim=0).item()
-            assert cos >= 0.98, f"{k}: update cosine {cos}"
+            # tensors whose last gradient the reference itself reproduces only to > 5e-2 (`noise.grad.*`): direction only
+            band = float(rec["noise.grad." + name]) if "noise.grad." + name in rec else 0.0
+            assert cos >= (0.98 if band <= 5e-2 else 0.9), f"{k}: update cosine {cos} (reference gradient band {band:.2e})"
             assert (d_got - d_ref).abs().max().item() <= 2.2 * lr[net] * updates[net], k
         else:
             scale = ref.abs().max().item()
