@@ -83,7 +83,7 @@ typedef struct dgmr_conv_args {
                                 feature maps through the LDS-window kernel */
     int32_t residual_up;     /* 1: residual is [N][H/2][W/2][Cout], added with nearest-2x upsampling (the 1x1 shortcut of an upsampling
                                 G-block evaluated before the upsample: conv1x1(up(x)) == up(conv1x1(x)), common.py:142-143,154) */
-    int32_t reserved0;
+    int32_t reserved0;       /* must be 0 (library-internal) */
     /* -- ABI 6 -- */
     float* stats_out;        /* NULL, or [dgmr_conv_stats_rows(args)][2][Cout]: per-workgroup-tile partial sums (sum y, sum y^2) of the
                                 OUTPUT, one row per pixel tile - the BatchNorm batch statistics of the next layer taken in this conv's
@@ -91,7 +91,17 @@ typedef struct dgmr_conv_args {
                                 Rows are ordered like the samples; dgmr_bn_partial_reduce folds them per statistics group.
                                 With mask_src (data gradient through relu(BatchNorm(x))) the second sum is sum y * mask_src instead:
                                 with dgmr_bn_bwd_center the two sums BatchNorm's backward needs (common.py:76,145 backwards). */
+    /* -- ABI 7 -- */
+    const uint16_t* w_phase; /* NULL, or (with `upsample`, 3x3, bf16 modes) the tap sums of the four output-pixel parities as bf16 planes
+                                [2][4*Cout][2*2][Cin]: dgmr_upsample_phase_weights then dgmr_split_weights.  The upsampling conv of
+                                UpsampleGBlock (common.py:142,148) then runs as four 2x2 convs on the low-resolution input - 16 instead of
+                                36 multiply steps per input pixel, same sums up to the fp32 rounding of the tap sums. */
 } dgmr_conv_args;
+
+/* out[(py*2+px)*Cout + co][a][b][ci] = sum of w[co][ky][kx][ci] over the taps (ky, kx) that read input pixel (h + py - 1 + a,
+ * w + px - 1 + b) when the conv runs on the nearest-2x upsampled map at output pixel (2h + py, 2w + px): ky in {0} | {1,2} for py = 0,
+ * a = 0 | 1; {0,1} | {2} for py = 1; kx likewise.  w: [Cout][3][3][Cin] fp32 (channels-last OIHW); out: [4*Cout][2][2][Cin] fp32. */
+int dgmr_upsample_phase_weights(const float* w, float* out, int Cout, int Cin, void* stream);
 
 /* Number of partial-sum rows dgmr_conv_fwd writes to stats_out for these arguments (host arithmetic, no launch): 0 when the kernel
  * the library would dispatch has no fused statistics (only the LDS-window 3x3 kernels of the bf16 modes do), then stats_out must

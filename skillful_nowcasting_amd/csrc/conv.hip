@@ -552,7 +552,7 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     const bool is3d = p.KD == 3 && p.D > 1 && glds_ok && !p.upsample && !p.residual_up;
     if (!(g_precision != 0 && p.w_split && ((p.KD == 1 && p.D == 1) || is3d) && p.KH == 3 && p.KW == 3 && p.Cin % 8 == 0 &&
           (p.W == 16 || p.W % 32 == 0 || small8) &&
-          (g_tune_window < 0 ? (M64 / 128) * ((C + 127) / 128) >= 192 : g_tune_window >= 1)))
+          (g_tune_window < 0 ? (M64 / 128) * ((C + 127) / 128) * (p.reserved0 ? 4 : 1) >= 192 : g_tune_window >= 1)))
         return false;
     w->tw_shift = small8 ? 3 : (p.W == 16 ? 4 : 5);
     w->g_shift = small8 ? 1 : 0;
@@ -561,7 +561,7 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     // (not at 128 output channels: 8 accumulator blocks per wave spill at two workgroups per CU).  Measured +2 ... +8 % on the
     // 96- / 64-channel layers of the sampler at T x B maps (gpurun r2o), -10 ... -20 % on launches of a few hundred workgroups:
     // automatic only when the 256-pixel tiles still fill the chip four times over
-    const int64_t big_wgs = (M64 / 256) * ((C + w->bnw - 1) / w->bnw);
+    const int64_t big_wgs = (M64 / 256) * ((C + w->bnw - 1) / w->bnw) * (p.reserved0 ? 4 : 1);
     w->big = !small8 && w->bnw != 128 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 &&
              (g_tune_window == 2 || (g_tune_window < 0 && big_wgs >= 2048));
     w->glds = glds_ok || w->big;
@@ -573,7 +573,26 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     return true;
 }
 
+// nearest-2x upsample + 3x3 conv == four 2x2 convs ("phases", one per output-pixel parity) on the low-resolution input with tap sums
+// as weights (w_phase): 16 instead of 36 multiply steps per input pixel.  The library's private copy of the arguments then describes
+// the LOW-resolution map, reserved0 = 1 tells the LDS-DMA window kernel to walk the phases (conv_win_glds.h).
+static bool phase_plan(dgmr_conv_args& p, WinPlan* w) {
+    if (!(p.upsample && p.w_phase && g_precision != 0 && p.KD == 1 && p.D == 1 && p.KH == 3 && p.KW == 3 && p.epi_mode == DGMR_EPI_PLAIN &&
+          !p.addend && !p.mask_src && p.H % 2 == 0 && p.W % 2 == 0))
+        return false;
+    dgmr_conv_args q = p;
+    q.H = p.H / 2;
+    q.W = p.W / 2;
+    q.upsample = 0;
+    q.reserved0 = 1;
+    q.w_split = p.w_phase;
+    if (!(window_plan(q, w) && w->glds)) return false;
+    p = q;
+    return true;
+}
+
 static void conv_args_defaults(dgmr_conv_args& p) {
+    p.reserved0 = 0;
     if (p.scale_group < 1) p.scale_group = 1;
     if (p.pre_group < 1) p.pre_group = 1;
     if (p.mask_group < 1) p.mask_group = 1;
@@ -588,6 +607,7 @@ extern "C" int dgmr_conv_stats_rows(const dgmr_conv_args* a) {
     dgmr_conv_args p = *a;
     conv_args_defaults(p);
     WinPlan w;
+    if (phase_plan(p, &w)) return 4 * w.grid_x;
     return (window_plan(p, &w) && w.glds) ? w.grid_x : 0;
 }
 
@@ -631,13 +651,14 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     if (g_tune_variant >= V_F128x128 && g_tune_variant <= V_F128x32) variant = g_tune_variant;
     // 3x3 convs of the big feature maps in the bf16 modes: LDS-window kernel (needs pre-split weights)
     WinPlan wp;
+    const bool phases = phase_plan(p, &wp);  // (rewrites p to the low-resolution map when it applies)
     DGMR_CHECK_ARG(!p.stats_out || (window_plan(p, &wp) && wp.glds && p.epi_mode == DGMR_EPI_PLAIN),
                    "dgmr_conv_fwd: stats_out given but the dispatched kernel has no fused statistics (ask dgmr_conv_stats_rows first)");
     if (window_plan(p, &wp)) {
         {
             const int tw_shift = wp.tw_shift, g_shift = wp.g_shift, tiles_w = wp.tiles_w, tiles_hw = wp.tiles_hw, bnw = wp.bnw;
             const bool big = wp.big, glds_ok = wp.glds && !wp.big;
-            const dim3 grid((unsigned)wp.grid_x, (unsigned)((C + bnw - 1) / bnw));
+            const dim3 grid((unsigned)wp.grid_x, (unsigned)((C + bnw - 1) / bnw) * (phases ? 4u : 1u));
             const int v = bnw == 128 ? V_WIN128 : (bnw == 96 ? V_WIN96 : V_WIN64);
             ProfScope ps(v, flops, s);
 #define DGMR_WIN(BN_, WM_, WN_)                                                                                              \
@@ -923,6 +944,34 @@ extern "C" int dgmr_sn_wgrad_finalize(const float* g, float* gw, float* dot, con
     hipLaunchKernelGGL(sn_wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, s, g, gw, dot, inv_sigma, u, v, Cout, Cin, taps, groups,
                        accumulate);
     if (dot) hipLaunchKernelGGL(zero_n_kernel, dim3(1), dim3(WG_MAX_GROUPS), 0, s, dot, groups);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[(ph*Cout + co)][a][b][ci]: see dgmr_hip.h; one thread per output element
+__global__ void phase_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
+    const int64_t total = (int64_t)16 * Cout * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        int64_t r = i / Cin;
+        const int b = (int)(r & 1), a = (int)((r >> 1) & 1);
+        r >>= 2;
+        const int co = (int)(r % Cout), ph = (int)(r / Cout), py = ph >> 1, px = ph & 1;
+        // taps of filter row ky that land on input row offset a for output parity py: py = 0: {0} | {1, 2};  py = 1: {0, 1} | {2}
+        const int ky0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), ky1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+        const int kx0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kx1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+        float acc = 0.f;
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((size_t)co * 3 + ky) * 3 + kx) * Cin + ci];
+        out[i] = acc;
+    }
+}
+
+extern "C" int dgmr_upsample_phase_weights(const float* w, float* out, int Cout, int Cin, void* stream) {
+    DGMR_CHECK_ARG(w && out && Cout > 0 && Cin > 0, "dgmr_upsample_phase_weights: bad args");
+    const int64_t total = (int64_t)16 * Cout * Cin;
+    hipLaunchKernelGGL(phase_weights_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, w,
+                       out, Cout, Cin);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

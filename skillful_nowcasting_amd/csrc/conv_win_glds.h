@@ -71,7 +71,14 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     const int trem = g_shift ? 0 : tile - n * tiles_hw;
     const int th = trem / tiles_w;
     const int h0 = th * TH, w0 = (trem - th * tiles_w) * TW;
-    const int n0 = blockIdx.y * BN;
+    // Phase mode (p.reserved0 = 1, set by the library for `upsample` convs that come with w_phase): the map (p.H x p.W) is the
+    // LOW-resolution input; output pixel (2h + py, 2w + px) of the nearest-2x-upsampled conv reads the 2 x 2 input pixels
+    // (h + py - 1 + a, w + px - 1 + b) with the tap sums of w_phase - four of nine MFMA steps per output, a halo staged once per
+    // 128 INPUT pixels.  blockIdx.y = phase * (column tiles) + column tile.
+    const bool phase = p.reserved0 != 0;
+    const int ntile_y = phase ? (int)gridDim.y >> 2 : (int)gridDim.y;
+    const int ph = (int)blockIdx.y / ntile_y, py = ph >> 1, px = ph & 1;
+    const int n0 = ((int)blockIdx.y - ph * ntile_y) * BN;
     const int us = p.upsample ? 1 : 0;
     const int Hs = p.H >> us, Ws = p.W >> us;
     const int oh = (h0 - 1) >> us, ow = (w0 - 1) >> us;
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     const int HP = ((TH >> us) + 2) * HTw;
     const int npix = HP << g_shift;
     const int nchunks = (p.Cin + CK - 1) / CK;
-    const int taps = 9 * KD;
+    const int taps = phase ? 4 : 9 * KD;
 
     // ---- activation halo (registers -> prologue -> split -> swizzled ds_write), as conv3x3_win_kernel ----
     const int cq = tid & 7;
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     };
 
     // ---- weights: stage s = chunk * 9 + tap, written by LDS-DMA; unit u of a stage = 16 bytes at LDS offset 16 u ----
-    const size_t plane_stride = (size_t)p.Cout * 9 * p.KD * p.Cin;  // bf16 elements per plane
+    const size_t plane_stride = phase ? (size_t)p.Cout * 16 * p.Cin : (size_t)p.Cout * 9 * p.KD * p.Cin;  // bf16 elements per plane
     // per-lane element offsets of the row / k-slot this lane fills (32 bits: a weight plane is < 2^31 elements); the tap / chunk part of
     // the address is wave-uniform and goes into the scalar base of global_load_lds.  b_tail: the same with k-slots beyond Cin
     // redirected to channel group 0 (only the last chunk of a Cin % 32 != 0 layer uses it)
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
         const int plane = u / (BN * 4);
         const int r = (u >> 2) % BN;
         const int ch = ((u ^ (r >> 2)) & 3) * 8;  // first channel (inside a chunk) of the logical k-slot held by physical slot u & 3
-        const uint32_t row = (uint32_t)(plane * plane_stride) + (uint32_t)min(n0 + r, p.Cout - 1) * (uint32_t)taps * p.Cin;
+        const uint32_t row = (uint32_t)(plane * plane_stride) + (uint32_t)(ph * p.Cout + min(n0 + r, p.Cout - 1)) * (uint32_t)taps * p.Cin;
         b_off[i] = row + ch;
         b_tail[i] = row + (c_last + ch < p.Cin ? c_last + ch : 0);  // absolute channel: the tail's scalar base has no chunk offset
     }
@@ -179,8 +186,8 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
         const int prow = (q >> tw_shift) & (TH - 1), pcol = q & (TW - 1), pbase = (q >> sub_shift) * HP;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            rowpix[i][d] = pbase + (((h0 + prow + d - 1) >> us) - oh) * HTw;
-            colpix[i][d] = ((w0 + pcol + d - 1) >> us) - ow;
+            rowpix[i][d] = pbase + (((h0 + prow + d + py - 1) >> us) - oh) * HTw;  // (py = px = 0 outside the phase mode;
+            colpix[i][d] = ((w0 + pcol + d + px - 1) >> us) - ow;                  //  there d = 0, 1 are its two taps per axis)
         }
     }
     const int kg = lane >> 5;
@@ -235,7 +242,26 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     stage_a(0, 0);
     dma_drain();
     __syncthreads();
-    const int ngroups = nchunks * KD;  // groups of nine taps: (chunk, kd)
+    const int ngroups = phase ? 0 : nchunks * KD;  // groups of nine taps: (chunk, kd)
+    if (phase) {
+#pragma unroll 1
+        for (int chunk = 0; chunk < nchunks; ++chunk) {  // four taps per chunk: the stage parity restarts with every chunk
+            const bool more = chunk + 1 < nchunks;
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                const int st = tap & 1;
+                if (tap < 3) dma_b(chunk, tap + 1, st ^ 1);
+                else if (more) dma_b(chunk + 1, 0, st ^ 1);
+                mma(tap >> 1, tap & 1, st);
+                if (tap == 3 && more) {
+                    __syncthreads();
+                    stage_a(chunk + 1, 0);
+                }
+                dma_drain();
+                __syncthreads();
+            }
+        }
+    }
 #pragma unroll 1
     for (int g = 0; g < ngroups; ++g) {
         const int chunk = KD == 3 ? g / 3 : g;
@@ -280,6 +306,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     // dependent loads made a ConvGRU step conv spend as long in its epilogue as in its 18 taps.)
     const int emode = p.epi_mode;
     const int cmax = p.Cout - 1;
+    const int pshift = phase ? 1 : 0, oH = p.H << pshift, oW = p.W << pshift;  // the output map (phase mode: twice the input's)
     // BatchNorm statistics of the OUTPUT for the next layer, taken here (stats_out): per column sum y and sum y^2 (data gradient
     // through relu(BatchNorm(x)), i.e. with mask_src: sum y and sum y * x, the two sums of BatchNorm's backward) over this lane's
     // 16 TM rows, folded over the two lane halves, the WM waves (LDS) and written as ONE row of partials per workgroup tile
@@ -292,9 +319,10 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int hh = h0 + ((q >> tw_shift) & (TH - 1)), ww = w0 + (q & (TW - 1)), ni = n + (q >> sub_shift);
-            const size_t mrow = (size_t)((ni * p.H + hh) * p.W + ww) * p.Cout;
-            const size_t rrow = p.residual_up ? (((size_t)ni * (p.H >> 1) + (hh >> 1)) * (p.W >> 1) + (ww >> 1)) * p.Cout : mrow;
+            const int ni = n + (q >> sub_shift);
+            const int hh = ((h0 + ((q >> tw_shift) & (TH - 1))) << pshift) + py, ww = ((w0 + (q & (TW - 1))) << pshift) + px;
+            const size_t mrow = (size_t)((ni * oH + hh) * oW + ww) * p.Cout;
+            const size_t rrow = p.residual_up ? (((size_t)ni * (oH >> 1) + (hh >> 1)) * (oW >> 1) + (ww >> 1)) * p.Cout : mrow;
             float v[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
@@ -369,7 +397,8 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
             float v = 0.f;
 #pragma unroll
             for (int q = 0; q < WM; ++q) v += red[(q * BN + cl) * 2 + which];
-            if (n0 + cl < p.Cout) p.stats_out[((size_t)blockIdx.x * 2 + which) * p.Cout + n0 + cl] = v;
+            const size_t srow = phase ? (size_t)blockIdx.x * 4 + ph : (size_t)blockIdx.x;  // (a tile's four phases: consecutive rows)
+            if (n0 + cl < p.Cout) p.stats_out[(srow * 2 + which) * p.Cout + n0 + cl] = v;
         }
     }
 }

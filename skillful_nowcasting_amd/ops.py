@@ -377,6 +377,29 @@ def _split_planes(w: torch.Tensor, flipped: bool, coff: int = 0, cin: Optional[i
     return out
 
 
+_phase_cache = {}
+_NO_PHASES = bool(int(__import__("os").environ.get("DGMR_NO_PHASES", "0")))  # measurement switch (tools/conv_bench.py)
+
+
+def _phase_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """bf16 (hi, lo) planes of the four parity ("phase") tap sums of a 3x3 conv that follows a nearest-2x upsample
+    (dgmr_conv_args.w_phase); cached until the parameter changes.  None in exact-f32 mode (the upsampled conv then runs as written)."""
+    if _PRECISION_CODE == 0 or _NO_PHASES or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[1] % 8:
+        return None
+    cout, cin = w.shape[0], w.shape[1]
+    key = id(w)
+    tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    hit = _phase_cache.get(key)
+    if hit is not None and hit[0] == tag and hit[2]() is w:
+        return hit[1]
+    sums = torch.empty(16 * cout * cin, device=w.device, dtype=torch.float32)
+    call("dgmr_upsample_phase_weights", _p(w), _p(sums), cout, cin, _stream())
+    out = torch.empty(2 * 16 * cout * cin, device=w.device, dtype=torch.int16)
+    call("dgmr_split_weights", _p(sums), _p(out), 16 * cout, cin, 0, 0, _stream())
+    _phase_cache[key] = (tag, out, weakref.ref(w, lambda _r, k=key: _phase_cache.pop(k, None)))
+    return out
+
+
 def _kdims(w: torch.Tensor):
     ks = list(w.shape[2:])
     return tuple([1] + ks) if len(ks) == 2 else tuple(ks)
@@ -388,11 +411,12 @@ EPI_PLAIN, EPI_GRU_GATE, EPI_GRU_BLEND = 0, 1, 2
 def _launch_conv(x, w_ptr, bias, scale, y, n, d, h, w_, cin, cout, kd, kh, kw, *, upsample=False, pre_relu=False, pre_a=None,
                  pre_b=None, pre_group=1, residual=None, addend=None, mask_src=None, mask_a=None, mask_b=None, mask_group=1,
                  scale_group=None, act_relu=False, w_cin=0, w_coff=0, epi_mode=EPI_PLAIN, gru_h=None, gru_pu=None, pre_out=None,
-                 device=None, w_split=None, residual_up=False, want_stats=False):
+                 device=None, w_split=None, residual_up=False, want_stats=False, w_phase=None):
     """`want_stats`: ask for the BatchNorm partial sums of the OUTPUT (dgmr_conv_args.stats_out); returns the [rows, 2, Cout] partials
     tensor, or None when the kernel the library dispatches for these arguments has no fused statistics."""
     a = ConvArgs()
     a.w_split = _p(w_split)
+    a.w_phase = _p(w_phase)
     a.residual_up = int(bool(residual_up))
     a.w_cin, a.w_coff, a.epi_mode = w_cin, w_coff, epi_mode
     a.gru_h, a.gru_pu, a.pre_out = _p(gru_h), _p(gru_pu), _p(pre_out)
@@ -449,7 +473,7 @@ class ConvFn(Function):
                                 pre_relu=spec.pre_relu, pre_a=bn.a if bn else None, pre_b=bn.b if bn else None,
                                 pre_group=bn.group_size if bn else 1, residual=residual, act_relu=spec.act_relu,
                                 scale_group=n // groups, w_split=_split_planes(w, False), residual_up=spec.residual_up,
-                                want_stats=spec.want_stats)
+                                want_stats=spec.want_stats, w_phase=_phase_planes(w) if spec.upsample else None)
         ctx.spec = spec  # flags only are read from it in backward; its tensors are re-read from saved_tensors
         ctx.has_residual = residual is not None
         # parameters are kept as-is (checkpointing hands back DETACHED copies of saved tensors: .grad must land on the real ones)

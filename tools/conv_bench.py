@@ -93,6 +93,21 @@ def main():
 
         ms = bench(fwd)
         line = f"{name:22s} M={n*d*h*w:8d} K={cin*kd*kh*kw:6d} N={cout:4d}  fwd {ms*1e3:9.1f} us {flops/ms/1e9:7.1f} TF"
+        if up and wsp is not None and ks == (1, 3, 3):  # the same conv as four 2x2 phase convs on the low-resolution input
+            sums = torch.empty(16 * cout * cin, device=dev)
+            call("dgmr_upsample_phase_weights", wt.data_ptr(), sums.data_ptr(), cout, cin, ops._stream())
+            wph = torch.empty(2 * sums.numel(), device=dev, dtype=torch.int16)
+            call("dgmr_split_weights", sums.data_ptr(), wph.data_ptr(), 16 * cout, cin, 0, 0, ops._stream())
+            y_direct = y.clone()
+            y.zero_()
+
+            def fwd_ph():
+                ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, d, h, w, cin, cout, kd, kh, kw, upsample=up,
+                                 pre_a=a if bn else None, pre_b=b if bn else None, pre_group=n, w_split=wsp, w_phase=wph)
+
+            msp = bench(fwd_ph)
+            diff = (y - y_direct).abs().max().item() / y_direct.abs().max().item()
+            line += f" | phases {msp*1e3:9.1f} us {flops/msp/1e9:7.1f} TF (algorithmic) diff {diff:.1e}"
         if "--bwd" in sys.argv:
             m = n * d * h * w
             k = cin * kd * kh * kw
