@@ -70,6 +70,76 @@ def test_window_conv_variants_agree(tuned, n, h, w, cin, cout, up, bn, res):
     assert float((ys[3] - ys[0]).abs().max()) <= tol
 
 
+# n, h, w (output), cin, cout, batchnorm-on-load, residual
+PHASE_CASES = [
+    (8, 64, 64, 96, 96, True, False),      # 32-wide input rows, 96-channel tile
+    (16, 32, 32, 192, 192, True, False),   # 16-wide input maps, 128 + 64 columns
+    (64, 16, 16, 384, 384, True, False),   # 8x8 input maps: two images per tile
+    (4, 128, 128, 96, 48, True, False),    # 48 of 64 columns
+    (40, 128, 128, 96, 96, True, False),   # enough tiles for the 256-pixel kernel
+    (6, 64, 64, 40, 200, False, True),     # ragged chunk, ragged columns, residual
+]
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("n,h,w,cin,cout,bn,res", PHASE_CASES)
+def test_upsample_phases_match_upsampled_conv(n, h, w, cin, cout, bn, res, prec):
+    """dgmr_conv_args.w_phase: the nearest-2x upsample + 3x3 conv as four 2x2 convs on the low-resolution input gives the sums of the
+    conv on the upsampled map (same kernel family, same arithmetic; the tap sums are rounded to fp32 before the bf16 split, and the
+    products are added in another order: 3e-5 of the output's magnitude in bf16x3, where products carry 16 bits; 2e-2 in plain bf16,
+    where SUMMED weights are rounded to 8 bits once instead of each tap separately)."""
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import ops
+    from skillful_nowcasting_amd._lib import call
+
+    torch.manual_seed(2)
+    x = torch.randn(n * (h // 2) * (w // 2) * cin, device=DEV)
+    wt = torch.randn(cout * 9 * cin, device=DEV) * 0.05
+    bias = torch.randn(cout, device=DEV)
+    scale = torch.rand(n, device=DEV) + 0.5
+    a = torch.rand(n * cin, device=DEV) + 0.5
+    b = torch.randn(n * cin, device=DEV) * 0.1
+    r = torch.randn(n * h * w * cout, device=DEV) if res else None
+    S.set_precision(prec)
+    try:
+        wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
+        call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, ops._stream())
+        sums = torch.empty(16 * cout * cin, device=DEV)
+        call("dgmr_upsample_phase_weights", wt.data_ptr(), sums.data_ptr(), cout, cin, ops._stream())
+        # the tap sums themselves, against torch
+        w4 = wt.view(cout, 3, 3, cin)
+        rows = {0: ((0, 1), (1, 3)), 1: ((0, 2), (2, 3))}  # parity -> (tap range of offset 0, of offset 1)
+        want = torch.stack([torch.stack([torch.stack([w4[:, rows[py][ai][0]:rows[py][ai][1], rows[px][bi][0]:rows[px][bi][1]].sum((1, 2))
+                                                      for bi in (0, 1)], 1) for ai in (0, 1)], 1)
+                            for py in (0, 1) for px in (0, 1)], 0)  # [4][Cout][2][2][Cin]
+        assert torch.allclose(sums.view(4, cout, 2, 2, cin), want, rtol=0, atol=1e-6)
+        wph = torch.empty(2 * sums.numel(), device=DEV, dtype=torch.int16)
+        call("dgmr_split_weights", sums.data_ptr(), wph.data_ptr(), 16 * cout, cin, 0, 0, ops._stream())
+        ys = []
+        for ph in (None, wph):
+            y = torch.full((n * h * w * cout,), float("nan"), device=DEV)
+            part = ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, 1, h, w, cin, cout, 1, 3, 3, upsample=True,
+                                    pre_a=a if bn else None, pre_b=b if bn else None, pre_group=1, scale_group=1, residual=r,
+                                    w_split=wsp, w_phase=ph, want_stats=True)
+            torch.cuda.synchronize()
+            assert part is not None
+            ys.append((y, part))
+    finally:
+        S.set_precision("f32")
+    (y0, p0), (y1, p1) = ys
+    assert not torch.isnan(y1).any()
+    tol = 3e-5 if prec == "bf16x3" else 2e-2
+    assert float((y1 - y0).abs().max()) <= tol * float(y0.abs().max())
+    # fused output statistics: per sample (8x8 input maps: per pair of samples, a tile is two images), against the tensor the kernel wrote
+    rows = p1.shape[0]
+    g = n if rows >= 4 * n else n // 2
+    assert rows % (4 * g) == 0
+    yd = y1.double().view(g, -1, cout)
+    want_s = torch.stack([yd.sum(1), (yd * yd).sum(1)], 1)
+    got_s = p1.double().view(g, rows // g, 2, cout).sum(1)
+    assert float((got_s - want_s).abs().max()) <= 2e-6 * float(want_s.abs().max())
+
+
 @pytest.mark.parametrize("n,d,h,w,cin,cout,relu,res", [
     (2, 6, 32, 32, 48, 48, True, True),      # the temporal discriminator's first 3-D block shape (channel tails on both sides)
     (3, 4, 16, 16, 16, 96, False, False),
