@@ -96,7 +96,18 @@ typedef struct dgmr_conv_args {
                                 [2][4*Cout][2*2][Cin]: dgmr_upsample_phase_weights then dgmr_split_weights.  The upsampling conv of
                                 UpsampleGBlock (common.py:142,148) then runs as four 2x2 convs on the low-resolution input - 16 instead of
                                 36 multiply steps per input pixel, same sums up to the fp32 rounding of the tap sums. */
+    int32_t pool2;           /* 1: y = 2x2 sum pool of the conv, [N][H/2][W/2][Cout] (H, W stay the conv's map; mask_src / stats_out refer to
+                                the pooled output) - the data gradient of an upsampling conv (common.py:142,148 backwards) without
+                                writing the full-resolution gradient.  Needs w_phase = dgmr_pool2_phase_weights + dgmr_split_weights
+                                ([2][Cout][16][Cin]) and a conv the window kernel takes: ask dgmr_conv_pool2_supported. */
+    int32_t reserved1;
 } dgmr_conv_args;
+
+/* 1 when dgmr_conv_fwd accepts these arguments with pool2 = 1 (host arithmetic, no launch). */
+int dgmr_conv_pool2_supported(const dgmr_conv_args* a);
+/* out[co][(p*2+q)*4 + a*2+b][ci]: the 4x4 stride-2 kernel of "3x3 conv then 2x2 sum pool" (row u = 2a + 1 - p sums the taps ky with
+ * ky + i = u, i in {0,1}), grouped by the parity (p, q) of the input pixel.  w: [Cout][3][3][Cin] fp32; out: [Cout][16][Cin] fp32. */
+int dgmr_pool2_phase_weights(const float* w, float* out, int Cout, int Cin, void* stream);
 
 /* out[(py*2+px)*Cout + co][a][b][ci] = sum of w[co][ky][kx][ci] over the taps (ky, kx) that read input pixel (h + py - 1 + a,
  * w + px - 1 + b) when the conv runs on the nearest-2x upsampled map at output pixel (2h + py, 2w + px): ky in {0} | {1,2} for py = 0,

@@ -27,7 +27,7 @@ class ConvArgs(Structure):
         ("scale_group", c_int32), ("pre_group", c_int32), ("mask_group", c_int32), ("act_relu", c_int32),
         ("w_cin", c_int32), ("w_coff", c_int32), ("epi_mode", c_int32), ("ksplit", c_int32),
         ("gru_h", P), ("gru_pu", P), ("pre_out", P), ("splitk_ws", P), ("splitk_ws_bytes", c_int64), ("w_split", P),
-        ("residual_up", c_int32), ("reserved0", c_int32), ("stats_out", P), ("w_phase", P),
+        ("residual_up", c_int32), ("reserved0", c_int32), ("stats_out", P), ("w_phase", P), ("pool2", c_int32), ("reserved1", c_int32),
     ]
 
 
@@ -105,6 +105,8 @@ SIGNATURES = {
     "dgmr_grid_cell_loss": [P, i, L, P, P, f, P, P, f, P, L, P],
     "dgmr_adam": [P, P, P, P, L, c_double, c_double, c_double, c_double, i, P],
     "dgmr_upsample_phase_weights": [P, P, i, i, P],
+    "dgmr_pool2_phase_weights": [P, P, i, i, P],
+    "dgmr_conv_pool2_supported": [POINTER(ConvArgs)],
     "dgmr_split_weights": [P, P, L, i, i, i, P],
     "dgmr_set_precision": [i],
     "dgmr_get_precision": [],

@@ -591,6 +591,33 @@ static bool phase_plan(dgmr_conv_args& p, WinPlan* w) {
     return true;
 }
 
+// 3x3 conv followed by a 2x2 sum pool (pool2: the data gradient of an upsampling conv) as ONE pass of the window kernel over the four
+// pixel-parity planes of the input with the 2x2 tap sums of w_phase; p then describes the pooled (output) map, reserved0 = 2.
+static bool pooled_plan(dgmr_conv_args& p, WinPlan* w) {
+    if (!(p.pool2 && !p.upsample && p.w_phase && g_precision != 0 && p.KD == 1 && p.D == 1 && p.KH == 3 && p.KW == 3 &&
+          p.epi_mode == DGMR_EPI_PLAIN && !p.addend && !p.residual && p.H % 2 == 0 && p.W % 2 == 0))
+        return false;
+    dgmr_conv_args q = p;
+    q.H = p.H / 2;
+    q.W = p.W / 2;
+    q.reserved0 = 2;
+    q.w_split = p.w_phase;
+    if (!(window_plan(q, w) && w->glds)) return false;
+    p = q;
+    return true;
+}
+
+extern "C" int dgmr_conv_pool2_supported(const dgmr_conv_args* a) {
+    if (!a || a->N <= 0 || a->H <= 0 || a->W <= 0 || a->Cout <= 0 || a->Cin <= 0) return 0;
+    dgmr_conv_args p = *a;
+    p.reserved0 = 0;
+    if (p.scale_group < 1) p.scale_group = 1;
+    if (p.pre_group < 1) p.pre_group = 1;
+    if (p.mask_group < 1) p.mask_group = 1;
+    WinPlan w;
+    return pooled_plan(p, &w) ? 1 : 0;
+}
+
 static void conv_args_defaults(dgmr_conv_args& p) {
     p.reserved0 = 0;
     if (p.scale_group < 1) p.scale_group = 1;
@@ -608,6 +635,7 @@ extern "C" int dgmr_conv_stats_rows(const dgmr_conv_args* a) {
     conv_args_defaults(p);
     WinPlan w;
     if (phase_plan(p, &w)) return 4 * w.grid_x;
+    if (p.pool2) return pooled_plan(p, &w) ? w.grid_x : 0;
     return (window_plan(p, &w) && w.glds) ? w.grid_x : 0;
 }
 
@@ -652,6 +680,7 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     // 3x3 convs of the big feature maps in the bf16 modes: LDS-window kernel (needs pre-split weights)
     WinPlan wp;
     const bool phases = phase_plan(p, &wp);  // (rewrites p to the low-resolution map when it applies)
+    DGMR_CHECK_ARG(!p.pool2 || pooled_plan(p, &wp), "dgmr_conv_fwd: pool2 needs a conv the window kernel takes (dgmr_conv_pool2_supported)");
     DGMR_CHECK_ARG(!p.stats_out || (window_plan(p, &wp) && wp.glds && p.epi_mode == DGMR_EPI_PLAIN),
                    "dgmr_conv_fwd: stats_out given but the dispatched kernel has no fused statistics (ask dgmr_conv_stats_rows first)");
     if (window_plan(p, &wp)) {
@@ -965,6 +994,32 @@ __global__ void phase_weights_kernel(const float* __restrict__ w, float* __restr
             for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((size_t)co * 3 + ky) * 3 + kx) * Cin + ci];
         out[i] = acc;
     }
+}
+
+// out[co][(p*2+q)*4 + a*2+b][ci] = sum of w[co][ky][kx][ci] over ky + i = 2a + 1 - p (i in {0, 1}: the pooled rows), kx likewise: the
+// 4 x 4 stride-2 kernel of "3x3 conv, then 2x2 sum pool", split by the parity (p, q) of the input pixel it multiplies
+__global__ void pool2_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
+    const int64_t total = (int64_t)16 * Cout * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        int64_t r = i / Cin;
+        const int b = (int)(r & 1), a = (int)((r >> 1) & 1), q = (int)((r >> 2) & 1), pp = (int)((r >> 3) & 1);
+        const int co = (int)(r >> 4);
+        const int u = 2 * a + 1 - pp, v = 2 * b + 1 - q;  // 0..3: row / column of the 4x4 kernel
+        float acc = 0.f;
+        for (int ky = max(0, u - 1); ky <= min(2, u); ++ky)
+            for (int kx = max(0, v - 1); kx <= min(2, v); ++kx) acc += w[(((size_t)co * 3 + ky) * 3 + kx) * Cin + ci];
+        out[i] = acc;
+    }
+}
+
+extern "C" int dgmr_pool2_phase_weights(const float* w, float* out, int Cout, int Cin, void* stream) {
+    DGMR_CHECK_ARG(w && out && Cout > 0 && Cin > 0, "dgmr_pool2_phase_weights: bad args");
+    const int64_t total = (int64_t)16 * Cout * Cin;
+    hipLaunchKernelGGL(pool2_weights_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, w,
+                       out, Cout, Cin);
+    DGMR_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int dgmr_upsample_phase_weights(const float* w, float* out, int Cout, int Cin, void* stream) {

@@ -75,7 +75,11 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     // LOW-resolution input; output pixel (2h + py, 2w + px) of the nearest-2x-upsampled conv reads the 2 x 2 input pixels
     // (h + py - 1 + a, w + px - 1 + b) with the tap sums of w_phase - four of nine MFMA steps per output, a halo staged once per
     // 128 INPUT pixels.  blockIdx.y = phase * (column tiles) + column tile.
-    const bool phase = p.reserved0 != 0;
+    // Pooled mode (p.reserved0 = 2, the data gradient of such a conv: 3x3 conv of the (2 p.H x 2 p.W) input followed by a 2 x 2 sum
+    // pool = 4 x 4 stride-2 conv): the input is walked as its four pixel-parity planes (strided views, staged like depth planes), each
+    // with the 2 x 2 taps of w_phase ([16 taps] = plane * 4 + tap) - 16 instead of 36 multiply steps per output pixel, and the
+    // full-resolution gradient is never written.
+    const bool phase = p.reserved0 == 1, pooled = p.reserved0 == 2;
     const int ntile_y = phase ? (int)gridDim.y >> 2 : (int)gridDim.y;
     const int ph = (int)blockIdx.y / ntile_y, py = ph >> 1, px = ph & 1;
     const int n0 = ((int)blockIdx.y - ph * ntile_y) * BN;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     const int HP = ((TH >> us) + 2) * HTw;
     const int npix = HP << g_shift;
     const int nchunks = (p.Cin + CK - 1) / CK;
-    const int taps = phase ? 4 : 9 * KD;
+    const int taps = phase ? 4 : (pooled ? 16 : 9 * KD);
 
     // ---- activation halo (registers -> prologue -> split -> swizzled ds_write), as conv3x3_win_kernel ----
     const int cq = tid & 7;
@@ -99,7 +103,9 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
         const int lr = prem / HTw, lc = prem - lr * HTw;
         const int ih = oh + lr, iw = ow + lc;
         const bool ok = pix < npix && (unsigned)ih < (unsigned)Hs && (unsigned)iw < (unsigned)Ws;
-        a_goff[i] = ok ? (((uint32_t)(n + sub) * Hs + ih) * Ws + iw) * p.Cin + cq * 4 : 0u;
+        a_goff[i] = !ok ? 0u
+                    : pooled ? (((uint32_t)(n + sub) * 2 * Hs + 2 * ih) * 2 * Ws + 2 * iw) * p.Cin + cq * 4  // pixel (2 ih, 2 iw): plane (0, 0)
+                             : (((uint32_t)(n + sub) * Hs + ih) * Ws + iw) * p.Cin + cq * 4;
         a_valid |= (ok ? 1u : 0u) << i;
     }
     const float* pa_base = p.pre_a ? p.pre_a : p.x;
@@ -108,13 +114,13 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     const uint32_t plane_elems = (uint32_t)Hs * Ws * p.Cin;
 
     // fetch, transform and store one 32-channel halo (latency covered by the other workgroups); kd: depth tap of a 3-D conv
-    auto stage_a = [&](int chunk, int kd) {
+    auto stage_a = [&](int chunk, int kd, uint32_t view_off = 0u) {  // view_off: element offset of a parity plane (pooled mode)
         f32x4 ra[APASS];
         const int cb = chunk * CK + cq * 4;
         const int dz = KD == 3 ? kd - 1 : 0;
         const bool kok = cb < p.Cin && (unsigned)(dpl + dz) < (unsigned)p.D;
         const unsigned valid = kok ? a_valid : 0u;
-        const uint32_t shift = chunk * CK + dz * (int)plane_elems;  // wraps consistently for dz = -1
+        const uint32_t shift = chunk * CK + dz * (int)plane_elems + view_off;  // wraps consistently for dz = -1
 #pragma unroll
         for (int i = 0; i < APASS; ++i)
             ra[i] = *reinterpret_cast<const f32x4*>(p.x + (((valid >> i) & 1u) ? a_goff[i] + shift : 0u));
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     };
 
     // ---- weights: stage s = chunk * 9 + tap, written by LDS-DMA; unit u of a stage = 16 bytes at LDS offset 16 u ----
-    const size_t plane_stride = phase ? (size_t)p.Cout * 16 * p.Cin : (size_t)p.Cout * 9 * p.KD * p.Cin;  // bf16 elements per plane
+    const size_t plane_stride = (phase || pooled) ? (size_t)p.Cout * 16 * p.Cin : (size_t)p.Cout * 9 * p.KD * p.Cin;  // bf16 elements per plane
     // per-lane element offsets of the row / k-slot this lane fills (32 bits: a weight plane is < 2^31 elements); the tap / chunk part of
     // the address is wave-uniform and goes into the scalar base of global_load_lds.  b_tail: the same with k-slots beyond Cin
     // redirected to channel group 0 (only the last chunk of a Cin % 32 != 0 layer uses it)
@@ -242,7 +248,34 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     stage_a(0, 0);
     dma_drain();
     __syncthreads();
-    const int ngroups = phase ? 0 : nchunks * KD;  // groups of nine taps: (chunk, kd)
+    const int ngroups = (phase || pooled) ? 0 : nchunks * KD;  // groups of nine taps: (chunk, kd)
+    if (pooled) {
+        // groups of four taps: (parity plane, chunk).  Input row 2r - 1 + u, u = 0..3, of output row r: even rows (plane bit 0) are
+        // u = 1, 3 = plane rows r, r + 1; odd rows u = 0, 2 = plane rows r - 1, r - hence the window row  a + 1 - parity  of tap a
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+            const int pp = pl >> 1, qq = pl & 1;
+#pragma unroll 1
+            for (int chunk = 0; chunk < nchunks; ++chunk) {
+                const bool last_chunk = chunk + 1 == nchunks;
+                const bool more = !(pl == 3 && last_chunk);
+                const int nchunk = last_chunk ? 0 : chunk + 1, npl = last_chunk ? pl + 1 : pl;
+#pragma unroll
+                for (int tap = 0; tap < 4; ++tap) {
+                    const int st = tap & 1;
+                    if (tap < 3) dma_b(chunk, pl * 4 + tap + 1, st ^ 1);
+                    else if (more) dma_b(nchunk, npl * 4, st ^ 1);
+                    mma((tap >> 1) + 1 - pp, (tap & 1) + 1 - qq, st);
+                    if (tap == 3 && more) {
+                        __syncthreads();
+                        stage_a(nchunk, 0, (uint32_t)(((npl >> 1) * 2 * Ws + (npl & 1)) * p.Cin));
+                    }
+                    dma_drain();
+                    __syncthreads();
+                }
+            }
+        }
+    }
     if (phase) {
 #pragma unroll 1
         for (int chunk = 0; chunk < nchunks; ++chunk) {  // four taps per chunk: the stage parity restarts with every chunk

@@ -400,6 +400,25 @@ def _phase_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
     return out
 
 
+def _pool2_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """The same for the data gradient of that conv: bf16 planes of the 4x4 stride-2 kernel "flipped 3x3 conv, then 2x2 sum pool",
+    grouped by input-pixel parity (dgmr_conv_args.pool2 / w_phase)."""
+    if _PRECISION_CODE == 0 or _NO_PHASES or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] % 8:
+        return None
+    cout, cin = w.shape[0], w.shape[1]
+    key = (id(w), "pool2")
+    tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    hit = _phase_cache.get(key)
+    if hit is not None and hit[0] == tag and hit[2]() is w:
+        return hit[1]
+    sums = torch.empty(16 * cout * cin, device=w.device, dtype=torch.float32)
+    call("dgmr_pool2_phase_weights", _p(_flipped_weight(w)), _p(sums), cin, cout, _stream())
+    out = torch.empty(2 * 16 * cout * cin, device=w.device, dtype=torch.int16)
+    call("dgmr_split_weights", _p(sums), _p(out), 16 * cin, cout, 0, 0, _stream())
+    _phase_cache[key] = (tag, out, weakref.ref(w, lambda _r, k=key: _phase_cache.pop(k, None)))
+    return out
+
+
 def _kdims(w: torch.Tensor):
     ks = list(w.shape[2:])
     return tuple([1] + ks) if len(ks) == 2 else tuple(ks)
@@ -411,9 +430,11 @@ EPI_PLAIN, EPI_GRU_GATE, EPI_GRU_BLEND = 0, 1, 2
 def _launch_conv(x, w_ptr, bias, scale, y, n, d, h, w_, cin, cout, kd, kh, kw, *, upsample=False, pre_relu=False, pre_a=None,
                  pre_b=None, pre_group=1, residual=None, addend=None, mask_src=None, mask_a=None, mask_b=None, mask_group=1,
                  scale_group=None, act_relu=False, w_cin=0, w_coff=0, epi_mode=EPI_PLAIN, gru_h=None, gru_pu=None, pre_out=None,
-                 device=None, w_split=None, residual_up=False, want_stats=False, w_phase=None):
+                 device=None, w_split=None, residual_up=False, want_stats=False, w_phase=None, pool2=False):
     """`want_stats`: ask for the BatchNorm partial sums of the OUTPUT (dgmr_conv_args.stats_out); returns the [rows, 2, Cout] partials
-    tensor, or None when the kernel the library dispatches for these arguments has no fused statistics."""
+    tensor, or None when the kernel the library dispatches for these arguments has no fused statistics.
+    `pool2`: y is the 2x2 sum pool of the conv (dgmr_conv_args.pool2); returns NotImplemented - nothing launched - when the library has
+    no single-pass kernel for these arguments."""
     a = ConvArgs()
     a.w_split = _p(w_split)
     a.w_phase = _p(w_phase)
@@ -431,6 +452,12 @@ def _launch_conv(x, w_ptr, bias, scale, y, n, d, h, w_, cin, cout, kd, kh, kw, *
     a.scale_group = scale_group if scale_group else n
     a.pre_group, a.mask_group = pre_group, mask_group
     a.act_relu = int(act_relu)
+    a.pool2 = int(bool(pool2))
+    if pool2:
+        from ._lib import load
+
+        if not load().dgmr_conv_pool2_supported(ctypes.byref(a)):
+            return NotImplemented
     partials = None
     if want_stats:
         from ._lib import load
@@ -550,8 +577,20 @@ class ConvFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wt = _flipped_weight(w)
-            g_sums = None
+            g_sums = NotImplemented
             if spec.upsample:
+                # flipped conv at full resolution, then the 2x2 window sum (nearest-2x backwards): one pass over the parity planes of dy
+                w_pool = _pool2_planes(w)
+                if w_pool is not None:
+                    g = empty_cl(x.shape, dy)
+                    g_sums = _launch_conv(dy, _p(wt), None, scale, g, n, d, h, wd, cout, cin, kd, kh, kw,
+                                          mask_src=x if (bn or spec.pre_relu) else None, mask_a=bn_a if bn else None,
+                                          mask_b=bn_b if bn else None, mask_group=bn.group_size if bn else 1, scale_group=n // groups,
+                                          w_split=_split_planes(w, True), w_phase=w_pool, pool2=True, want_stats=bn is not None)
+            if g_sums is not NotImplemented:
+                pass
+            elif spec.upsample:
+                g_sums = None
                 hi = empty_cl((n, cin, h, wd) if x.dim() == 4 else (n, cin, d, h, wd), dy)
                 _launch_conv(dy, _p(wt), None, scale, hi, n, d, h, wd, cout, cin, kd, kh, kw, scale_group=n // groups,
                              w_split=_split_planes(w, True))

@@ -42,6 +42,9 @@ def _conv_ref(x, w, b, up=False, relu_in=False):
     (2, 20, 52, 17, 3, False, True),     # ragged M / N / K
     (24, 96, 96, 32, 3, False, True),    # big map: LDS-window kernel in the bf16 modes (TW = 32, BN = 96)
     (8, 48, 128, 32, 3, True, False),    # window kernel with nearest-2x upsample-on-load (64x64 out), Cin = 1.5 chunks
+    (24, 96, 96, 32, 3, True, True),     # upsampling conv on the phase path: forward 4 x (2x2), data gradient 4 parity planes x (2x2)
+    (48, 192, 96, 16, 3, True, False),   # ... 16-wide input maps, 128 + 64 output columns / 96 gradient columns
+    (104, 384, 192, 8, 3, True, True),   # ... 8x8 input maps (two images per tile)
     (96, 64, 48, 16, 3, False, False),   # window kernel, 16-wide maps (TW = 16), Cout = 48 on the 64-wide tile
     (6, 40, 256, 64, 3, False, True),    # window kernel, Cin = 40 (ragged chunk), two N tiles of 128
     (64, 64, 768, 8, 3, False, True),    # window kernel on 8x8 maps: a tile is two whole images with their own halos

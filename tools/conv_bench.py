@@ -125,6 +125,35 @@ def main():
 
             ms2 = bench(wg)
             line += f" | wgrad ns={ns:4d} {ms2*1e3:9.1f} us {flops/ms2/1e9:7.1f} TF"
+            if up and wsp is not None:  # data gradient of the upsampling conv: conv at full resolution + 2x2 sum, vs one pooled pass
+                dx = torch.empty_like(x)
+                hi = torch.empty(n * h * w * cin, device=dev)
+                wflip = torch.randn(cin * 9 * cout, device=dev) * 0.05
+                wfs = torch.empty(2 * wflip.numel(), device=dev, dtype=torch.int16)
+                call("dgmr_split_weights", wflip.data_ptr(), wfs.data_ptr(), cin * 9, cout, 0, 0, ops._stream())
+                sums = torch.empty(16 * cout * cin, device=dev)
+                call("dgmr_pool2_phase_weights", wflip.data_ptr(), sums.data_ptr(), cin, cout, ops._stream())
+                wpl = torch.empty(2 * sums.numel(), device=dev, dtype=torch.int16)
+                call("dgmr_split_weights", sums.data_ptr(), wpl.data_ptr(), 16 * cin, cout, 0, 0, ops._stream())
+
+                def dg_old():
+                    ops._launch_conv(y, wflip.data_ptr(), None, scale, hi, n, d, h, w, cout, cin, kd, kh, kw, w_split=wfs)
+                    call("dgmr_pool_fwd", hi.data_ptr(), None, dx.data_ptr(), n, d, h, w, cin, 1, 1.0, x.data_ptr(),
+                         a.data_ptr() if bn else None, b.data_ptr() if bn else None, n, ops._stream())
+
+                ms3 = bench(dg_old)
+                dx_old = dx.clone()
+                dx.zero_()
+
+                def dg_new():
+                    r = ops._launch_conv(y, wflip.data_ptr(), None, scale, dx, n, d, h, w, cout, cin, kd, kh, kw, mask_src=x,
+                                         mask_a=a if bn else None, mask_b=b if bn else None, mask_group=n, w_split=wfs, w_phase=wpl,
+                                         pool2=True)
+                    assert r is not NotImplemented
+
+                ms4 = bench(dg_new)
+                diff = (dx - dx_old).abs().max().item() / dx_old.abs().max().item()
+                line += f" | dgrad conv+pool {ms3*1e3:9.1f} us, pooled pass {ms4*1e3:9.1f} us {flops/ms4/1e9:7.1f} TF diff {diff:.1e}"
             if not up:
                 dx = torch.empty_like(x)
                 wflip = torch.empty_like(wt)
