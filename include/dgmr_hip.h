@@ -103,6 +103,11 @@ typedef struct dgmr_conv_args {
     int32_t reserved1;
 } dgmr_conv_args;
 
+/* Weight gradient of an upsampling conv (common.py:142,148 backwards) as a 1x1 problem: z[n][r][c][co*9 + ky*3 + kx] = the sum of the
+ * 2x2 pixels of dy ([N][2H][2W][C]) that meet input pixel (r, c) under tap (ky, kx), so that dW[co][ky][kx][ci] = sum over the INPUT
+ * pixels of z * pre(x) - dgmr_conv_wgrad with KH = KW = 1, Cout = 9 C, dy = z: a quarter of the multiply steps of the gradient taken
+ * on the upsampled map, and its partial[..][co*9 + tap][ci] is the layout dgmr_wgrad_reduce expects.  z: [N][H][W][9 C] floats. */
+int dgmr_upsample_wgrad_sums(const float* dy, float* z, int N, int H, int W, int C, void* stream);
 /* 1 when dgmr_conv_fwd accepts these arguments with pool2 = 1 (host arithmetic, no launch). */
 int dgmr_conv_pool2_supported(const dgmr_conv_args* a);
 /* out[co][(p*2+q)*4 + a*2+b][ci]: the 4x4 stride-2 kernel of "3x3 conv then 2x2 sum pool" (row u = 2a + 1 - p sums the taps ky with

@@ -106,6 +106,7 @@ SIGNATURES = {
     "dgmr_adam": [P, P, P, P, L, c_double, c_double, c_double, c_double, i, P],
     "dgmr_upsample_phase_weights": [P, P, i, i, P],
     "dgmr_pool2_phase_weights": [P, P, i, i, P],
+    "dgmr_upsample_wgrad_sums": [P, P, i, i, i, i, P],
     "dgmr_conv_pool2_supported": [POINTER(ConvArgs)],
     "dgmr_split_weights": [P, P, L, i, i, i, P],
     "dgmr_set_precision": [i],

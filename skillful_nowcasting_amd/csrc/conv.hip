@@ -548,7 +548,7 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     const bool small8 = p.H == 8 && p.W == 8 && p.D == 1 && !p.upsample && p.N % 2 == 0 && (!p.scale || p.scale_group % 2 == 0) &&
                         (!p.pre_a || p.pre_group % 2 == 0) && (!p.mask_a || p.mask_group % 2 == 0);
     // the LDS-DMA kernel (both bf16 modes) also takes 3x3x3 convs, plane by plane
-    const bool glds_ok = g_precision != 0 && (g_tune_window < 0 || g_tune_window == 3);
+    const bool glds_ok = g_precision != 0 && (g_tune_window < 0 || g_tune_window >= 3);
     const bool is3d = p.KD == 3 && p.D > 1 && glds_ok && !p.upsample && !p.residual_up;
     if (!(g_precision != 0 && p.w_split && ((p.KD == 1 && p.D == 1) || is3d) && p.KH == 3 && p.KW == 3 && p.Cin % 8 == 0 &&
           (p.W == 16 || p.W % 32 == 0 || small8) &&
@@ -719,9 +719,19 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         else                                                                                                                          \
             hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
     } while (0)
-                if (bnw == 128) DGMR_GLDS(128, 2, 2);
+#define DGMR_GLDS_PRIV(BN_, WM_, WN_)                                                                                                       \
+    do {                                                                                                                                    \
+        if (g_precision == 1)                                                                                                               \
+            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 3, 128, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 1, 128, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
+    } while (0)
+                if (bnw == 128 && g_tune_window == 4) DGMR_GLDS_PRIV(128, 1, 4);
+                else if (bnw == 64 && g_tune_window == 4) DGMR_GLDS_PRIV(64, 2, 2);
+                else if (bnw == 128) DGMR_GLDS(128, 2, 2);
                 else if (bnw == 96) DGMR_GLDS(96, 4, 1);
                 else DGMR_GLDS(64, 4, 1);
+#undef DGMR_GLDS_PRIV
 #undef DGMR_GLDS
             }
             else if (bnw == 128) {
@@ -1053,7 +1063,7 @@ extern "C" int dgmr_set_precision(int mode) {
 extern "C" int dgmr_get_precision(void) { return g_precision; }
 
 extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window) {
-    DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 3 && wgrad_window >= -1 &&
+    DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 4 && wgrad_window >= -1 &&
                        wgrad_window <= 1,
                    "dgmr_conv_tune: variant %d ksplit %d window %d wgrad_window %d", variant, ksplit, window, wgrad_window);
     g_tune_variant = variant;

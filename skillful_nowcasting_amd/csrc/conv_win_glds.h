@@ -38,7 +38,11 @@ __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" 
 // BM: output pixels per workgroup.  256 (8 x 32 or 16 x 16 pixels of one image) gives every wave twice the pixels per weight
 // fragment: (TM + TN) * planes LDS reads feed TM * TN * terms MFMAs, half the barriers per MFMA, a 1.33x instead of 1.59x halo - at
 // two workgroups per CU instead of three (68 KB of LDS, ~170 registers).
-template <int BN, int WM, int WN, int NS, int BM = 128>
+// PRIV: every wave streams ITS OWN 32 x TN output-channel slice of the weights into a private double buffer and nothing but the
+// activation halo is shared: no barrier between taps (one pair per 32-channel chunk, when the halo is replaced), the waves of a
+// workgroup drift apart and the SIMDs interleave them freely - the per-tap barrier made every workgroup wait for its slowest SIMD
+// nine times per chunk (PMC: 37 % of the wave cycles parked, matrix pipe 50 % busy).
+template <int BN, int WM, int WN, int NS, int BM = 128, bool PRIV = false>
 __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift,
                                                                                           const int tiles_w, const int tiles_hw,
                                                                                           const int g_shift) {
@@ -52,10 +56,13 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     constexpr int AMAX = BM == 256 ? 10 * 34 : 6 * 34;  // halo pixels: 6 x 34 / 10 x 18 (BM 128), 10 x 34 / 18 x 18 (BM 256)
     constexpr int APASS = (AMAX * 8 + 255) / 256;
     constexpr int BUNITS = BN * 4 * NP;  // 16-byte units of one weight stage
-    constexpr int BPASS = (BUNITS + 255) / 256;  // plain bf16 at 96 channels: 384 units = one full pass + waves 0, 1 of a second
+    // PRIV: a wave's slice is TN x 32 rows per plane = TN * 2 DMA instructions (16 rows each) per plane
+    constexpr int BPASS = PRIV ? TN * 2 * NP : (BUNITS + 255) / 256;  // plain bf16 at 96 channels: 384 units = one full pass + waves 0, 1 of a second
+    constexpr int WSLICE = NP * TN * 32 * ROW;                        // dwords of one wave's private slice of a stage
+    constexpr int BSTAGE = PRIV ? 4 * WSLICE : NP * BN * ROW;         // dwords of one stage
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BUNITS % 64 == 0, "bad tile");
 
-    __shared__ __attribute__((aligned(16))) uint32_t smem[NP * AMAX * ROW + 2 * NP * BN * ROW];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[NP * AMAX * ROW + 2 * BSTAGE];
     uint32_t* As = smem;                     // [plane][pixel][ROW]
     uint32_t* Bs = smem + NP * AMAX * ROW;   // [stage][plane][co][ROW]
 
@@ -159,9 +166,9 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
         const int u = min(tid + i * 256, BUNITS - 1);  // (lanes of a wave beyond the stage never issue: see dma_b)
-        const int plane = u / (BN * 4);
-        const int r = (u >> 2) % BN;
-        const int ch = ((u ^ (r >> 2)) & 3) * 8;  // first channel (inside a chunk) of the logical k-slot held by physical slot u & 3
+        const int plane = PRIV ? i / (TN * 2) : u / (BN * 4);
+        const int r = PRIV ? wn * TN * 32 + (i % (TN * 2)) * 16 + (lane >> 2) : (u >> 2) % BN;
+        const int ch = (((PRIV ? lane : u) ^ (r >> 2)) & 3) * 8;  // first channel (inside a chunk) of the logical k-slot held by physical slot u & 3
         const uint32_t row = (uint32_t)(plane * plane_stride) + (uint32_t)(ph * p.Cout + min(n0 + r, p.Cout - 1)) * (uint32_t)taps * p.Cin;
         b_off[i] = row + ch;
         b_tail[i] = row + (c_last + ch < p.Cin ? c_last + ch : 0);  // absolute channel: the tail's scalar base has no chunk offset
@@ -171,9 +178,12 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
         const bool tail = has_tail && chunk == nchunks - 1;
         const uint16_t* base = p.w_split + ((size_t)tap * p.Cin + (tail ? 0 : chunk * CK));
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i)
-            if (i * 256 + wid * 64 < BUNITS)  // wave-uniform: a wave fills 64 consecutive units
-                lds_dma16(base + (tail ? b_tail[i] : b_off[i]), Bs + stage * NP * BN * ROW + (i * 256 + wid * 64) * 4);
+        for (int i = 0; i < BPASS; ++i) {
+            if (PRIV)  // 16 rows x 64 bytes of this wave's own slice: [plane][TN * 32 rows][ROW]
+                lds_dma16(base + (tail ? b_tail[i] : b_off[i]), Bs + stage * BSTAGE + wid * WSLICE + i * 16 * ROW);
+            else if (i * 256 + wid * 64 < BUNITS)  // wave-uniform: a wave fills 64 consecutive units
+                lds_dma16(base + (tail ? b_tail[i] : b_off[i]), Bs + stage * BSTAGE + (i * 256 + wid * 64) * 4);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -198,8 +208,11 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     }
     const int kg = lane >> 5;
     const int bsw = (lane >> 2) & 3;  // swizzle of this lane's weight rows (row = 32 j + (lane & 31))
-    const uint32_t* Bb0 = Bs + (wn * TN * 32 + (lane & 31)) * ROW;
-    auto mma = [&](int dyi, int dxi, int stage) {
+    const uint32_t* Bb0 = PRIV ? Bs + wid * WSLICE + (lane & 31) * ROW : Bs + (wn * TN * 32 + (lane & 31)) * ROW;
+    constexpr int BPLANE = PRIV ? TN * 32 : BN;  // rows between the hi and the lo plane of a stage
+    // half: the chunk holds <= 16 real channels (Cin = 48, 144: the last chunk) - its second 16-channel step is all zeros, skipped
+    const bool tail16 = (p.Cin & (CK - 1)) != 0 && (p.Cin & (CK - 1)) <= 16;
+    auto mma = [&](int dyi, int dxi, int stage, bool half) {
         const uint32_t* Ab[TM];
         int asw[TM];
 #pragma unroll
@@ -208,9 +221,10 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
             Ab[i] = As + pix * ROW;
             asw[i] = (pix >> 2) & 3;
         }
-        const uint32_t* Bb = Bb0 + stage * NP * BN * ROW;
+        const uint32_t* Bb = Bb0 + stage * BSTAGE;
 #pragma unroll
         for (int kk = 0; kk < CK / 16; ++kk) {
+            if (kk == 1 && half) break;  // (wave-uniform)
             const int ks = kk * 2 + kg;  // logical 16-byte k-slot of this lane's fragment
             bf16x8_t ah[TM], bh[TN], al[TM], bl[TN];
 #pragma unroll
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + j * 32 * ROW + ob));
-                if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BN + j * 32) * ROW + ob));
+                if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BPLANE + j * 32) * ROW + ob));
             }
             __builtin_amdgcn_s_setprio(1);
             if (SPLIT) {
@@ -265,13 +279,13 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
                     const int st = tap & 1;
                     if (tap < 3) dma_b(chunk, pl * 4 + tap + 1, st ^ 1);
                     else if (more) dma_b(nchunk, npl * 4, st ^ 1);
-                    mma((tap >> 1) + 1 - pp, (tap & 1) + 1 - qq, st);
+                    mma((tap >> 1) + 1 - pp, (tap & 1) + 1 - qq, st, tail16 && last_chunk);
                     if (tap == 3 && more) {
                         __syncthreads();
                         stage_a(nchunk, 0, (uint32_t)(((npl >> 1) * 2 * Ws + (npl & 1)) * p.Cin));
                     }
                     dma_drain();
-                    __syncthreads();
+                    if (!PRIV || (tap == 3 && more)) __syncthreads();
                 }
             }
         }
@@ -285,13 +299,13 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
                 const int st = tap & 1;
                 if (tap < 3) dma_b(chunk, tap + 1, st ^ 1);
                 else if (more) dma_b(chunk + 1, 0, st ^ 1);
-                mma(tap >> 1, tap & 1, st);
+                mma(tap >> 1, tap & 1, st, tail16 && !more);
                 if (tap == 3 && more) {
                     __syncthreads();
                     stage_a(chunk + 1, 0);
                 }
                 dma_drain();
-                __syncthreads();
+                if (!PRIV || (tap == 3 && more)) __syncthreads();
             }
         }
     }
@@ -307,13 +321,13 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
             // the next stage's DMA is in flight under this tap's MFMAs
             if (tap < 8) dma_b(chunk, kd * 9 + tap + 1, st ^ 1);
             else if (more) dma_b(nchunk, nkd * 9, st ^ 1);
-            mma(tap / 3, tap % 3, st);
+            mma(tap / 3, tap % 3, st, tail16 && chunk == nchunks - 1);
             if (tap == 8 && more) {
                 __syncthreads();  // every wave is done with this group's halo
                 stage_a(nchunk, nkd);
             }
             dma_drain();  // the stage written under this tap's MFMAs is read by every wave after the barrier
-            __syncthreads();
+            if (!PRIV || (tap == 8 && more)) __syncthreads();
         }
     }
 
@@ -412,7 +426,8 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
             }
         }
     }
-    if (want_stats) {  // (wave-uniform; the main loop ended on a barrier, the LDS is free)
+    if (want_stats) {  // (wave-uniform)
+        if (PRIV) __syncthreads();  // no barrier since the last halo: other waves may still be reading the LDS
         float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {

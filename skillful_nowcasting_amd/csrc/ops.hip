@@ -1256,6 +1256,50 @@ extern "C" int dgmr_pool_fwd(const float* x, const float* addend, float* y, int 
     return 0;
 }
 
+// z[n][r][c][co*9 + ky*3 + kx] = sum_{i,j in {0,1}} dy[n][2r + 1 - ky + i][2c + 1 - kx + j][co]  (zero outside the map): the window
+// sums of the output gradient that meet input pixel (r, c) under tap (ky, kx) of a 3x3 conv on the nearest-2x upsampled map.  One
+// block = P consecutive pixels of an input row: the 4 x (2P + 2) x C window goes through LDS once, every output is 4 LDS reads and
+// one coalesced store.
+__global__ void upsample_wgrad_sums_kernel(const float* __restrict__ dy, float* __restrict__ z, int H, int W, int C, int P) {
+    extern __shared__ float win[];  // [4][2P + 2][C]
+    const int wblocks = W / P;
+    const int64_t b = blockIdx.x;
+    const int c0 = (int)(b % wblocks) * P;
+    const int r = (int)((b / wblocks) % H);
+    const int n = (int)(b / ((int64_t)wblocks * H));
+    const int H2 = 2 * H, W2 = 2 * W, cols = 2 * P + 2, C4 = C >> 2;
+    for (int i = threadIdx.x; i < 4 * cols * C4; i += blockDim.x) {
+        const int c4 = i % C4, col = (i / C4) % cols, row = i / (C4 * cols);
+        const int R = 2 * r - 1 + row, Cc = 2 * c0 - 1 + col;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)R < (unsigned)H2 && (unsigned)Cc < (unsigned)W2)
+            v = *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H2 + R) * W2 + Cc) * C + c4 * 4);
+        *reinterpret_cast<f32x4*>(win + ((size_t)row * cols + col) * C + c4 * 4) = v;
+    }
+    __syncthreads();
+    const int C9 = 9 * C;
+    float* zrow = z + (((size_t)n * H + r) * W + c0) * C9;
+    for (int e = threadIdx.x; e < P * C9; e += blockDim.x) {
+        const int j = e / C9, rem = e - j * C9;
+        const int co = rem / 9, tap = rem - co * 9, ky = tap / 3, kx = tap - ky * 3;
+        const float* w0 = win + ((size_t)(2 - ky) * cols + 2 * j + 2 - kx) * C + co;
+        zrow[e] = (w0[0] + w0[C]) + (w0[(size_t)cols * C] + w0[(size_t)cols * C + C]);
+    }
+}
+
+extern "C" int dgmr_upsample_wgrad_sums(const float* dy, float* z, int N, int H, int W, int C, void* stream) {
+    DGMR_CHECK_ARG(dy && z && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dgmr_upsample_wgrad_sums: bad args (C=%d)", C);
+    int P = 8;
+    while (P > 1 && (W % P != 0 || (size_t)4 * (2 * P + 2) * C * sizeof(float) > 48 * 1024)) P >>= 1;
+    const size_t lds = (size_t)4 * (2 * P + 2) * C * sizeof(float);
+    DGMR_CHECK_ARG(lds <= 64 * 1024, "dgmr_upsample_wgrad_sums: C=%d too wide", C);
+    const int64_t blocks = (int64_t)N * H * (W / P);
+    DGMR_CHECK_ARG(blocks < (1ll << 31), "dgmr_upsample_wgrad_sums: grid too large");
+    hipLaunchKernelGGL(upsample_wgrad_sums_kernel, dim3((unsigned)blocks), dim3(256), lds, ST, dy, z, H, W, C, P);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int dgmr_pool_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, int pd, float scale, void* stream) {
     DGMR_CHECK_ARG(dy && dx, "dgmr_pool_bwd: null pointer");
     DGMR_CHECK_ARG(C % 4 == 0 && (pd == 1 || pd == 2), "dgmr_pool_bwd: C=%d pd=%d unsupported", C, pd);

@@ -545,13 +545,26 @@ class ConvFn(Function):
         taps = kd * kh * kw
         if w.requires_grad:
             wa = WgradArgs()
-            wa.x, wa.dy = _p(x), _p(dy)
             wa.pre_a, wa.pre_b = (_p(bn_a), _p(bn_b)) if bn else (None, None)
-            wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, d, h, wd, cin, cout
-            wa.KD, wa.KH, wa.KW = kd, kh, kw
-            wa.upsample, wa.pre_relu, wa.pre_group = int(spec.upsample), int(spec.pre_relu), (bn.group_size if bn else 1)
+            wa.pre_relu, wa.pre_group = int(spec.pre_relu), (bn.group_size if bn else 1)
             wa.groups = groups
-            wa.bias_grad = _p(grad_buffer(bias)) if want_bias else None
+            if spec.upsample and _PRECISION_CODE != 0 and not _NO_PHASES and (kd, kh, kw) == (1, 3, 3) and d == 1:
+                # upsampling conv, bf16 modes: sum the 2x2 pixels of dy that meet each INPUT pixel under each tap (9 planes), then the
+                # gradient is a 1x1 problem on the low-resolution map - a quarter of the multiply steps (dgmr_upsample_wgrad_sums)
+                z9 = torch.empty(n * (h // 2) * (wd // 2) * 9 * cout, device=dev, dtype=torch.float32)
+                call("dgmr_upsample_wgrad_sums", _p(dy), _p(z9), n, h // 2, wd // 2, cout, st)
+                wa.x, wa.dy = _p(x), _p(z9)
+                wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, 1, h // 2, wd // 2, cin, 9 * cout
+                wa.KD, wa.KH, wa.KW, wa.upsample = 1, 1, 1, 0
+                wa.bias_grad = None
+                if want_bias:
+                    tmp = torch.empty(2 * cout, device=dev, dtype=torch.float64)
+                    call("dgmr_colsum", _p(dy), _p(grad_buffer(bias)), _p(tmp), m, cout, 1, st)
+            else:
+                wa.x, wa.dy = _p(x), _p(dy)
+                wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, d, h, wd, cin, cout
+                wa.KD, wa.KH, wa.KW, wa.upsample = kd, kh, kw, int(spec.upsample)
+                wa.bias_grad = _p(grad_buffer(bias)) if want_bias else None
             call("dgmr_conv_wgrad_plan", ctypes.byref(wa))  # slab count: depends on which kernel the library will pick
             ns = wa.nsplit
             partial = torch.empty(ns * cout * k, device=dev, dtype=torch.float32)

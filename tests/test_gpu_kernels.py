@@ -56,7 +56,9 @@ def test_window_conv_variants_agree(tuned, n, h, w, cin, cout, up, bn, res):
     wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
     call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, ops._stream())
     ys = {}
-    for mode in (1, 3, 2, 0):  # register-staged window, LDS-DMA window, LDS-DMA window with 256-pixel tiles (where eligible), implicit GEMM
+    # register-staged window, LDS-DMA window, the same with private per-wave weight slices (no barrier between taps; 128- and
+    # 64-column tiles), with 256-pixel tiles (where eligible), implicit GEMM
+    for mode in (1, 3, 4, 2, 0):
         tuned(-1, -1, mode, -1)
         y = torch.full((n * h * w * cout,), float("nan"), device=DEV)
         ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, 1, h, w, cin, cout, 1, 3, 3, upsample=up, pre_a=a if bn else None,
@@ -66,6 +68,7 @@ def test_window_conv_variants_agree(tuned, n, h, w, cin, cout, up, bn, res):
     assert not torch.isnan(ys[3]).any()
     assert torch.equal(ys[1], ys[3]), f"window kernels differ: max {float((ys[1] - ys[3]).abs().max()):.3e}"
     assert torch.equal(ys[2], ys[3]), f"256-pixel-tile window kernel differs: max {float((ys[2] - ys[3]).abs().max()):.3e}"
+    assert torch.equal(ys[4], ys[3]), f"private-slice window kernel differs: max {float((ys[4] - ys[3]).abs().max()):.3e}"
     tol = 2e-6 * float(ys[0].abs().max())
     assert float((ys[3] - ys[0]).abs().max()) <= tol
 

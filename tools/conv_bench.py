@@ -43,6 +43,17 @@ SHAPES = [
     ("gru4.h-step B4", 4, 1, 64, 64, 48, 48, (1, 3, 3), False, False),
     ("gru3.h-step B16", 16, 1, 32, 32, 96, 96, (1, 3, 3), False, False),
     ("gru2.x-part T18B4", 72, 1, 16, 16, 384, 192, (1, 3, 3), False, False),
+    # weight gradient of the upsampling convs as a 1x1 problem on the 9 pair-summed planes of dy (Cout' = 9 Cout)
+    ("z9 up_g1", 288, 1, 8, 8, 768, 3456, (1, 1, 1), False, True),
+    ("z9 up_g2", 288, 1, 16, 16, 384, 1728, (1, 1, 1), False, True),
+    ("z9 up_g3", 288, 1, 32, 32, 192, 864, (1, 1, 1), False, True),
+    ("z9 up_g4", 288, 1, 64, 64, 96, 432, (1, 1, 1), False, True),
+    # the same layers as they run now (real channel counts)
+    ("real up_g1.first", 288, 1, 16, 16, 768, 384, (1, 3, 3), True, True),
+    ("real up_g2.first", 288, 1, 32, 32, 384, 192, (1, 3, 3), True, True),
+    ("real up_g3.first", 288, 1, 64, 64, 192, 96, (1, 3, 3), True, True),
+    ("real up_g4.first", 288, 1, 128, 128, 96, 48, (1, 3, 3), True, True),
+    ("real up_g4.last", 288, 1, 128, 128, 48, 48, (1, 3, 3), False, True),
 ]
 
 
@@ -125,6 +136,28 @@ def main():
 
             ms2 = bench(wg)
             line += f" | wgrad ns={ns:4d} {ms2*1e3:9.1f} us {flops/ms2/1e9:7.1f} TF"
+            if up and wsp is not None and ks == (1, 3, 3):  # weight gradient through the 9 pair-summed planes (1x1 problem)
+                z9 = torch.empty(n * (h // 2) * (w // 2) * 9 * cout, device=dev)
+                wz = WgradArgs()
+                wz.x, wz.dy = x.data_ptr(), z9.data_ptr()
+                wz.pre_a, wz.pre_b = (a.data_ptr(), b.data_ptr()) if bn else (None, None)
+                wz.N, wz.D, wz.H, wz.W, wz.Cin, wz.Cout = n, 1, h // 2, w // 2, cin, 9 * cout
+                wz.KD, wz.KH, wz.KW, wz.upsample, wz.pre_relu, wz.pre_group, wz.groups = 1, 1, 1, 0, 0, n, 1
+                call("dgmr_conv_wgrad_plan", ctypes.byref(wz))
+                pz = torch.empty(wz.nsplit * 9 * cout * cin, device=dev)
+                wz.partial = pz.data_ptr()
+
+                def zb():
+                    call("dgmr_upsample_wgrad_sums", y.data_ptr(), z9.data_ptr(), n, h // 2, w // 2, cout, ops._stream())
+
+                def zg():
+                    call("dgmr_conv_wgrad", ctypes.byref(wz), ops._stream())
+
+                t1, t2 = bench(zb), bench(zg)
+                gold = partial.view(ns, -1).sum(0)
+                gnew = pz.view(wz.nsplit, -1).sum(0)
+                diff = (gnew - gold).abs().max().item() / gold.abs().max().item()
+                line += f" | z9: sums {t1*1e3:7.1f} us + 1x1 wgrad ns={wz.nsplit} {t2*1e3:7.1f} us diff {diff:.1e}"
             if up and wsp is not None:  # data gradient of the upsampling conv: conv at full resolution + 2x2 sum, vs one pooled pass
                 dx = torch.empty_like(x)
                 hi = torch.empty(n * h * w * cin, device=dev)
