@@ -1279,11 +1279,11 @@ __global__ void upsample_wgrad_sums_kernel(const float* __restrict__ dy, float* 
     __syncthreads();
     const int C9 = 9 * C;
     float* zrow = z + (((size_t)n * H + r) * W + c0) * C9;
-    for (int e = threadIdx.x; e < P * C9; e += blockDim.x) {
-        const int j = e / C9, rem = e - j * C9;
+    for (int rem = threadIdx.x; rem < C9; rem += blockDim.x) {  // (divisions by constants only: the loop over pixels is inside)
         const int co = rem / 9, tap = rem - co * 9, ky = tap / 3, kx = tap - ky * 3;
-        const float* w0 = win + ((size_t)(2 - ky) * cols + 2 * j + 2 - kx) * C + co;
-        zrow[e] = (w0[0] + w0[C]) + (w0[(size_t)cols * C] + w0[(size_t)cols * C + C]);
+        const float* w0 = win + ((size_t)(2 - ky) * cols + 2 - kx) * C + co;
+        const int rs = cols * C;
+        for (int j = 0; j < P; ++j, w0 += 2 * C) zrow[(size_t)j * C9 + rem] = (w0[0] + w0[C]) + (w0[rs] + w0[rs + C]);
     }
 }
 

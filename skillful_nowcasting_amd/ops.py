@@ -556,11 +556,11 @@ class ConvFn(Function):
                 wa.x, wa.dy = _p(x), _p(z9)
                 wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, 1, h // 2, wd // 2, cin, 9 * cout
                 wa.KD, wa.KH, wa.KW, wa.upsample = 1, 1, 1, 0
-                wa.bias_grad = None
-                if want_bias:
-                    tmp = torch.empty(2 * cout, device=dev, dtype=torch.float64)
-                    call("dgmr_colsum", _p(dy), _p(grad_buffer(bias)), _p(tmp), m, cout, 1, st)
+                # bias: the centre-tap plane (ky = kx = 1) holds every pixel of dy exactly once - its column sums ride in the kernel
+                z9_bias = torch.zeros(9 * cout, device=dev, dtype=torch.float32) if want_bias else None
+                wa.bias_grad = _p(z9_bias)
             else:
+                z9_bias = None
                 wa.x, wa.dy = _p(x), _p(dy)
                 wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, d, h, wd, cin, cout
                 wa.KD, wa.KH, wa.KW, wa.upsample = kd, kh, kw, int(spec.upsample)
@@ -570,6 +570,8 @@ class ConvFn(Function):
             partial = torch.empty(ns * cout * k, device=dev, dtype=torch.float32)
             wa.partial = _p(partial)
             call("dgmr_conv_wgrad", ctypes.byref(wa), st)
+            if z9_bias is not None:
+                grad_buffer(bias).add_(z9_bias.view(cout, 9)[:, 4])
             gw = grad_buffer(w)
             g = torch.empty(cout * k, device=dev, dtype=torch.float32)
             if scale is None:
