@@ -687,7 +687,7 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         {
             const int tw_shift = wp.tw_shift, g_shift = wp.g_shift, tiles_w = wp.tiles_w, tiles_hw = wp.tiles_hw, bnw = wp.bnw;
             const bool big = wp.big, glds_ok = wp.glds && !wp.big;
-            const dim3 grid((unsigned)wp.grid_x, (unsigned)((C + bnw - 1) / bnw) * (phases ? 4u : 1u));
+            const dim3 grid((unsigned)wp.grid_x * (phases ? 4u : 1u), (unsigned)((C + bnw - 1) / bnw));
             const int v = bnw == 128 ? V_WIN128 : (bnw == 96 ? V_WIN96 : V_WIN64);
             ProfScope ps(v, flops, s);
 #define DGMR_WIN(BN_, WM_, WN_)                                                                                              \

@@ -70,7 +70,14 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     const int wm = wid / WN, wn = wid % WN;
     const int TW = 1 << tw_shift, TH = (BM >> tw_shift) >> g_shift;
     const int sub_shift = LOG_BM - g_shift;
-    const int tile = blockIdx.x;
+    // phase mode: blockIdx.x = 4 x tiles.  The four phases of a tile read the same input halo: they get workgroup ids 8 apart, i.e.
+    // the SAME XCD (ids are dealt round-robin over the 8 XCDs) back to back, so three of the four halo fetches hit that XCD's L2
+    // (PMC before: 5.2x the input read from the fabric; phases as blockIdx.y put them a whole grid row apart)
+    const bool phase_pre = p.reserved0 == 1;
+    const int bid = blockIdx.x;
+    const bool xcd_map = phase_pre && (gridDim.x & 31) == 0;
+    const int ph_pre = !phase_pre ? 0 : (xcd_map ? (bid >> 3) & 3 : bid & 3);
+    const int tile = !phase_pre ? bid : (xcd_map ? ((bid >> 5) << 3) | (bid & 7) : bid >> 2);
     const int n = g_shift ? (tile << g_shift) : tile / tiles_hw;  // first image of the tile; 3-D: depth plane (sample * D + d)
     const int KD = p.KD;                                           // 1, or 3 (then g_shift == 0)
     const int smp = KD == 3 ? n / p.D : n;                         // sample of the tile's first image: statistics / sigma groups
@@ -81,15 +88,14 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
     // Phase mode (p.reserved0 = 1, set by the library for `upsample` convs that come with w_phase): the map (p.H x p.W) is the
     // LOW-resolution input; output pixel (2h + py, 2w + px) of the nearest-2x-upsampled conv reads the 2 x 2 input pixels
     // (h + py - 1 + a, w + px - 1 + b) with the tap sums of w_phase - four of nine MFMA steps per output, a halo staged once per
-    // 128 INPUT pixels.  blockIdx.y = phase * (column tiles) + column tile.
+    // 128 INPUT pixels.
     // Pooled mode (p.reserved0 = 2, the data gradient of such a conv: 3x3 conv of the (2 p.H x 2 p.W) input followed by a 2 x 2 sum
     // pool = 4 x 4 stride-2 conv): the input is walked as its four pixel-parity planes (strided views, staged like depth planes), each
     // with the 2 x 2 taps of w_phase ([16 taps] = plane * 4 + tap) - 16 instead of 36 multiply steps per output pixel, and the
     // full-resolution gradient is never written.
     const bool phase = p.reserved0 == 1, pooled = p.reserved0 == 2;
-    const int ntile_y = phase ? (int)gridDim.y >> 2 : (int)gridDim.y;
-    const int ph = (int)blockIdx.y / ntile_y, py = ph >> 1, px = ph & 1;
-    const int n0 = ((int)blockIdx.y - ph * ntile_y) * BN;
+    const int ph = ph_pre, py = ph >> 1, px = ph & 1;
+    const int n0 = (int)blockIdx.y * BN;
     const int us = p.upsample ? 1 : 0;
     const int Hs = p.H >> us, Ws = p.W >> us;
     const int oh = (h0 - 1) >> us, ow = (w0 - 1) >> us;
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3
             float v = 0.f;
 #pragma unroll
             for (int q = 0; q < WM; ++q) v += red[(q * BN + cl) * 2 + which];
-            const size_t srow = phase ? (size_t)blockIdx.x * 4 + ph : (size_t)blockIdx.x;  // (a tile's four phases: consecutive rows)
+            const size_t srow = phase ? (size_t)tile * 4 + ph : (size_t)tile;  // (a tile's four phases: consecutive rows)
             if (n0 + cl < p.Cout) p.stats_out[(srow * 2 + which) * p.Cout + n0 + cl] = v;
         }
     }

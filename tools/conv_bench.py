@@ -79,6 +79,7 @@ def main():
             call("dgmr_conv_tune", *[int(v) for v in a.split("=")[1].split(",")])
     print("precision:", ops.get_precision(), flush=True)
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    
     for name, n, d, h, w, cin, cout, ks, up, bn in SHAPES:
         if only and not any(o in name for o in only):
             continue
@@ -98,13 +99,20 @@ def main():
             wsp = torch.empty(2 * wt.numel(), device=dev, dtype=torch.int16)
             call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * kd * 9, cin, 0, 0, ops._stream())
 
+        wph0 = None
+        if "--phases-only" in sys.argv and up and wsp is not None and ks == (1, 3, 3):  # PMC runs: only the path the product takes
+            sums0 = torch.empty(16 * cout * cin, device=dev)
+            call("dgmr_upsample_phase_weights", wt.data_ptr(), sums0.data_ptr(), cout, cin, ops._stream())
+            wph0 = torch.empty(2 * sums0.numel(), device=dev, dtype=torch.int16)
+            call("dgmr_split_weights", sums0.data_ptr(), wph0.data_ptr(), 16 * cout, cin, 0, 0, ops._stream())
+
         def fwd():
             ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, d, h, w, cin, cout, kd, kh, kw, upsample=up,
-                             pre_a=a if bn else None, pre_b=b if bn else None, pre_group=n, w_split=wsp)
+                             pre_a=a if bn else None, pre_b=b if bn else None, pre_group=n, w_split=wsp, w_phase=wph0)
 
         ms = bench(fwd)
         line = f"{name:22s} M={n*d*h*w:8d} K={cin*kd*kh*kw:6d} N={cout:4d}  fwd {ms*1e3:9.1f} us {flops/ms/1e9:7.1f} TF"
-        if up and wsp is not None and ks == (1, 3, 3):  # the same conv as four 2x2 phase convs on the low-resolution input
+        if up and wsp is not None and ks == (1, 3, 3) and wph0 is None:  # the same conv as four 2x2 phase convs on the low-resolution input
             sums = torch.empty(16 * cout * cin, device=dev)
             call("dgmr_upsample_phase_weights", wt.data_ptr(), sums.data_ptr(), cout, cin, ops._stream())
             wph = torch.empty(2 * sums.numel(), device=dev, dtype=torch.int16)
