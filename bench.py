@@ -222,15 +222,17 @@ def main():
         ms = (ctypes.c_double * nv)()
         fl = (ctypes.c_double * nv)()
         cnt = (ctypes.c_int64 * nv)()
-        lib.dgmr_profile_collect(ms, fl, cnt, nv)
+        ex = (ctypes.c_double * nv)()
+        lib.dgmr_profile_collect2(ms, fl, ex, cnt, nv)
         rows = [dict(kernel=lib.dgmr_profile_variant_name(i).decode(), launches=int(cnt[i]), total_ms=ms[i],
                      avg_us=(1e3 * ms[i] / cnt[i]) if cnt[i] else 0.0, tflops=(fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] > 0 else 0.0,
                      flops_per_launch=(fl[i] / cnt[i]) if cnt[i] else 0.0) for i in range(nv)]
         # every conv kernel (forward, data gradient, weight gradient) runs in the selected arithmetic mode
         mult = {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
-        for r in rows:
+        for i_row, r in enumerate(rows):
             r["peak_tflops"] = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
-            r["mfma_executed_tflops"] = r["tflops"] * mult
+            # matrix-pipe work really issued: phase / pooled launches of the upsampling convs execute 16/36 of their algorithmic MACs
+            r["mfma_executed_tflops"] = (ex[i_row] / (r["total_ms"] * 1e-3) / 1e12 * mult) if r["total_ms"] > 0 else 0.0
             r["frac"] = r["tflops"] / r["peak_tflops"]
         dom = max(rows, key=lambda r: r["total_ms"])
         tot_ms = sum(r["total_ms"] for r in rows)

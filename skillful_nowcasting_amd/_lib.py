@@ -115,6 +115,7 @@ SIGNATURES = {
     "dgmr_conv_tune": [i, i, i, i],
     "dgmr_profile_variants": [],
     "dgmr_profile_collect": [P, P, P, i],
+    "dgmr_profile_collect2": [P, P, P, P, i],
 }
 del i, f, L
 

@@ -236,7 +236,8 @@ __global__ void splitk_reduce4_kernel(const dgmr_conv_args p, const int M, const
 // ------------------------------------------------------------------------------------------------
 struct ProfRec {
     int variant;
-    double flops;
+    double flops;     // algorithmic: 2 * MACs of the dense convolution as the reference states it
+    double executed;  // multiply-accumulates x 2 the launch really performs (phase / pooled decompositions: 16/36 of the above)
     hipEvent_t e0, e1;
 };
 bool g_prof_on = false;
@@ -259,11 +260,12 @@ struct ProfScope {
     bool on;
     ProfRec r;
     hipStream_t s;
-    ProfScope(int variant, double flops, hipStream_t st) : on(g_prof_on), s(st) {
+    ProfScope(int variant, double flops, hipStream_t st, double exec_frac = 1.0) : on(g_prof_on), s(st) {
         if (!on) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         r.variant = variant;
         r.flops = flops;
+        r.executed = flops * exec_frac;
         r.e0 = prof_event();
         r.e1 = prof_event();
         (void)hipEventRecord(r.e0, s);
@@ -689,7 +691,7 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
             const bool big = wp.big, glds_ok = wp.glds && !wp.big;
             const dim3 grid((unsigned)wp.grid_x * (phases ? 4u : 1u), (unsigned)((C + bnw - 1) / bnw));
             const int v = bnw == 128 ? V_WIN128 : (bnw == 96 ? V_WIN96 : V_WIN64);
-            ProfScope ps(v, flops, s);
+            ProfScope ps(v, flops, s, (phases || p.reserved0 == 2) ? 16.0 / 36.0 : 1.0);
 #define DGMR_WIN(BN_, WM_, WN_)                                                                                              \
     do {                                                                                                                     \
         if (g_precision == 1)                                                                                                \
@@ -1084,10 +1086,15 @@ extern "C" const char* dgmr_profile_variant_name(int v) { return (v >= 0 && v < 
 
 // Synchronises the events recorded so far and returns per-variant totals; clears the records.
 extern "C" int dgmr_profile_collect(double* total_ms, double* total_flops, int64_t* launches, int n) {
+    return dgmr_profile_collect2(total_ms, total_flops, nullptr, launches, n);
+}
+
+extern "C" int dgmr_profile_collect2(double* total_ms, double* total_flops, double* executed_flops, int64_t* launches, int n) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (int i = 0; i < n; ++i) {
         total_ms[i] = 0.0;
         total_flops[i] = 0.0;
+        if (executed_flops) executed_flops[i] = 0.0;
         launches[i] = 0;
     }
     for (auto& r : g_prof) {
@@ -1096,6 +1103,7 @@ extern "C" int dgmr_profile_collect(double* total_ms, double* total_flops, int64
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && r.variant < n) {
             total_ms[r.variant] += ms;
             total_flops[r.variant] += r.flops;
+            if (executed_flops) executed_flops[r.variant] += r.executed;
             launches[r.variant] += 1;
         }
         g_event_pool.push_back(r.e0);

@@ -39,13 +39,17 @@ def main():
         "shape": kv.get("shape", ""),
         "launch_us": launch_us,
         "algorithmic_tflops": alg_flops / launch_us / 1e6,
-        "mfma_executed_tflops": mult * alg_flops / launch_us / 1e6,
+        # matrix-pipe work from the instruction counter when it was collected (32x32x16 bf16 MFMA = 32768 flop per wave-instruction):
+        # exact also for launches that execute fewer MACs than the algorithmic count (phase / pooled upsampling convs)
+        "mfma_executed_tflops": (c["SQ_INSTS_MFMA"] * 32768.0 if c.get("SQ_INSTS_MFMA", 0) > 0 and kv.get("precision", "bf16x3") != "f32"
+                                 else mult * alg_flops) / launch_us / 1e6,
         "gpu_cycles_per_xcd": cyc,
         "effective_clock_ghz": cyc / launch_us / 1e3,
         "mfma_util": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc),
         "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8 XCDs): share of the SIMD cycles of this launch in "
                           "which the matrix pipe was busy (counter passes run the kernel ~5-10 % slower than the un-instrumented launch_us)",
-        "mfma_executed_frac_of_spec_peak": mult * alg_flops / launch_us / 1e6 / 2500.0,
+        "mfma_executed_frac_of_spec_peak": (c["SQ_INSTS_MFMA"] * 32768.0 if c.get("SQ_INSTS_MFMA", 0) > 0 and kv.get("precision", "bf16x3") != "f32"
+                                            else mult * alg_flops) / launch_us / 1e6 / 2500.0,
         "fetch_size_kb": c["FETCH_SIZE"],
         "write_size_kb": c["WRITE_SIZE"],
         "hbm_read_bytes_corrected": rd,
