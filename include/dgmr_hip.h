@@ -103,6 +103,25 @@ typedef struct dgmr_conv_args {
     int32_t reserved1;
 } dgmr_conv_args;
 
+/* ---- the sampler's output layer: relu(BatchNorm(x)) -> 1x1 conv to 4 channels (generators.py:159-166), streaming fp32 kernels ----
+ * x: [M][C] (C <= 64, % 4); a, b: BatchNorm affine per call group [G][C]; w: [4][C]; scale: 1/sigma per call group [G] or NULL;
+ * a call group = pixels_per_group consecutive pixels (M = G * pixels_per_group).  Exact fp32 in every precision mode.
+ * dgmr_head_blocks: number of per-block partial rows the backward writes (0: shape unsupported, use the conv entry points). */
+int dgmr_head_blocks(int64_t M, int64_t pixels_per_group, int C);
+int dgmr_head_fwd(const float* x, const float* a, const float* b, const float* w, const float* bias, const float* scale, float* y,
+                  int64_t M, int64_t pixels_per_group, int C, void* stream);
+/* Backward pass 1 - the data gradient g = [a x + b > 0] (1/sigma) W^T dy is formed in registers and NOT written: per block
+ * bn_partials[blk][2][C] = (sum g, sum g x)  (-> dgmr_bn_partial_reduce, dgmr_bn_bwd_center), w_partials[blk][4][C] = sum dy (x) relu(a x + b)
+ * (the raw weight gradient; blocks of a call group are consecutive: dgmr_wgrad_reduce with nsplit = blocks), bias_partials[blk][4]. */
+int dgmr_head_bwd_sums(const float* x, const float* a, const float* b, const float* w, const float* scale, const float* dy,
+                       float* bn_partials, float* w_partials, float* bias_partials, int64_t M, int64_t pixels_per_group, int C,
+                       void* stream);
+/* Backward pass 2 - g recomputed, BatchNorm's backward applied (dgmr_bn_bwd_apply's arithmetic), dx written; dgamma / dbeta
+ * accumulated from `sums` when given. */
+int dgmr_head_bwd_apply(const float* x, const float* a, const float* b, const float* w, const float* scale, const float* dy,
+                        const float* mean, const float* rstd, const float* gamma, const double* sums, float* dx, float* dgamma,
+                        float* dbeta, int64_t M, int64_t pixels_per_group, int C, int train, void* stream);
+
 /* Weight gradient of an upsampling conv (common.py:142,148 backwards) as a 1x1 problem: z[n][r][c][co*9 + ky*3 + kx] = the sum of the
  * 2x2 pixels of dy ([N][2H][2W][C]) that meet input pixel (r, c) under tap (ky, kx), so that dW[co][ky][kx][ci] = sum over the INPUT
  * pixels of z * pre(x) - dgmr_conv_wgrad with KH = KW = 1, Cout = 9 C, dy = z: a quarter of the multiply steps of the gradient taken

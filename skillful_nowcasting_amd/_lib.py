@@ -107,6 +107,10 @@ SIGNATURES = {
     "dgmr_upsample_phase_weights": [P, P, i, i, P],
     "dgmr_pool2_phase_weights": [P, P, i, i, P],
     "dgmr_upsample_wgrad_sums": [P, P, i, i, i, i, P],
+    "dgmr_head_blocks": [L, L, i],
+    "dgmr_head_fwd": [P, P, P, P, P, P, P, L, L, i, P],
+    "dgmr_head_bwd_sums": [P, P, P, P, P, P, P, P, P, L, L, i, P],
+    "dgmr_head_bwd_apply": [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, i, i, P],
     "dgmr_conv_pool2_supported": [POINTER(ConvArgs)],
     "dgmr_split_weights": [P, P, L, i, i, i, P],
     "dgmr_set_precision": [i],

@@ -43,7 +43,7 @@ __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" 
 // workgroup drift apart and the SIMDs interleave them freely - the per-tap barrier made every workgroup wait for its slowest SIMD
 // nine times per chunk (PMC: 37 % of the wave cycles parked, matrix pipe 50 % busy).
 template <int BN, int WM, int WN, int NS, int BM = 128, bool PRIV = false>
-__global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift,
+__global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift,
                                                                                           const int tiles_w, const int tiles_hw,
                                                                                           const int g_shift) {
     constexpr int CK = 32;

@@ -1300,6 +1300,257 @@ extern "C" int dgmr_upsample_wgrad_sums(const float* dy, float* z, int N, int H,
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The sampler's output layer (generators.py:159-166): relu(BatchNorm(x)) -> spectrally-normalised 1x1 conv to 4 channels, on
+// T x draws x B maps of 128 x 128 x 48: 28 M pixels, 5.4 GB per pass over x and 48 multiply-adds per output - pure HBM streaming,
+// which the MFMA conv kernels did at 0.4 ... 1.4 TB/s.  Three fp32 VALU kernels, 16 lanes per pixel (one float4 of channels each,
+// C <= 64): forward; backward pass 1 (data gradient formed in registers, NOT written: BatchNorm's backward sums, the raw weight
+// gradient per call group and the bias gradient as per-block partials, deterministic); backward pass 2 (gradient recomputed,
+// BatchNorm backward applied, dx written).  x is read three times and written once in total; exact fp32 in every precision mode.
+// A block walks `ppb` consecutive pixels of ONE call group (same BatchNorm statistics, same 1/sigma).
+struct HeadGeom {
+    int64_t ppg;  // pixels per call group
+    int ppb;      // pixels per block (multiple of 16, divides ppg)
+    int bpg;      // blocks per group
+    int C, C4;
+};
+
+__device__ __forceinline__ float sum16(float v) {
+    v += __shfl_xor(v, 1, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 8, 16);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       const float* __restrict__ scale, float* __restrict__ y, HeadGeom gm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & 15, j = lane >> 4;
+    const bool act = q < gm.C4;
+    const int g = blockIdx.x / gm.bpg;
+    const int64_t p0 = (int64_t)g * gm.ppg + (int64_t)(blockIdx.x - g * gm.bpg) * gm.ppb;
+    const int cq = act ? q * 4 : 0;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 av = act ? *reinterpret_cast<const f32x4*>(a + (size_t)g * gm.C + cq) : zero;
+    const f32x4 bv = act ? *reinterpret_cast<const f32x4*>(b + (size_t)g * gm.C + cq) : zero;
+    f32x4 wv[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) wv[o] = act ? *reinterpret_cast<const f32x4*>(w + (size_t)o * gm.C + cq) : zero;
+    const float sc = scale ? scale[g] : 1.f;
+    const f32x4 bs = bias ? *reinterpret_cast<const f32x4*>(bias) : zero;
+    for (int it = wave * 4 + j; it < gm.ppb; it += 16) {
+        const int64_t p = p0 + it;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + p * gm.C + cq);
+        f32x4 s;
+        float xh[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xh[c] = fmaxf(fmaf(av[c], xv[c], bv[c]), 0.f);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d = fmaf(wv[o][c], xh[c], d);
+            s[o] = sum16(act ? d : 0.f);
+        }
+        if (q == 0) {
+            f32x4 o4;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) o4[o] = fmaf(s[o], sc, bs[o]);
+            *reinterpret_cast<f32x4*>(y + p * 4) = o4;
+        }
+    }
+}
+
+// the data gradient of pixel p, channels 4q .. 4q+3, behind the relu(BatchNorm) mask: g = [a x + b > 0] * (1/sigma) * W^T dy
+__device__ __forceinline__ void head_grad(const f32x4& xv, const f32x4& dyv, const f32x4& av, const f32x4& bv, const f32x4 (&wv)[4],
+                                          float sc, float (&gr)[4], float (&xh)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float pre = fmaf(av[c], xv[c], bv[c]);
+        xh[c] = fmaxf(pre, 0.f);
+        float t = wv[0][c] * dyv[0];
+        t = fmaf(wv[1][c], dyv[1], t);
+        t = fmaf(wv[2][c], dyv[2], t);
+        t = fmaf(wv[3][c], dyv[3], t);
+        gr[c] = pre > 0.f ? t * sc : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                            const float* __restrict__ b, const float* __restrict__ w,
+                                                            const float* __restrict__ scale, const float* __restrict__ dy,
+                                                            float* __restrict__ bn_part, float* __restrict__ w_part,
+                                                            float* __restrict__ bias_part, HeadGeom gm) {
+    __shared__ float red[4][16][28];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & 15, j = lane >> 4;
+    const bool act = q < gm.C4;
+    const int g = blockIdx.x / gm.bpg;
+    const int64_t p0 = (int64_t)g * gm.ppg + (int64_t)(blockIdx.x - g * gm.bpg) * gm.ppb;
+    const int cq = act ? q * 4 : 0;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 av = act ? *reinterpret_cast<const f32x4*>(a + (size_t)g * gm.C + cq) : zero;
+    const f32x4 bv = act ? *reinterpret_cast<const f32x4*>(b + (size_t)g * gm.C + cq) : zero;
+    f32x4 wv[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) wv[o] = act ? *reinterpret_cast<const f32x4*>(w + (size_t)o * gm.C + cq) : zero;
+    const float sc = scale ? scale[g] : 1.f;
+    float acc[28];  // S0[4] | S1[4] | dW[4 o][4 c] | db[4]
+#pragma unroll
+    for (int i = 0; i < 28; ++i) acc[i] = 0.f;
+    for (int it = wave * 4 + j; it < gm.ppb; it += 16) {
+        const int64_t p = p0 + it;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + p * gm.C + cq);
+        const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + p * 4);
+        float gr[4], xh[4];
+        head_grad(xv, dyv, av, bv, wv, sc, gr, xh);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc[c] += gr[c];
+            acc[4 + c] = fmaf(gr[c], xv[c], acc[4 + c]);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[8 + o * 4 + c] = fmaf(dyv[o], xh[c], acc[8 + o * 4 + c]);
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[24 + o] += dyv[o];
+    }
+    // fold the four pixel slots of the wave, then the four waves; one partial row per block
+#pragma unroll
+    for (int i = 0; i < 28; ++i) {
+        float v = acc[i];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (j == 0) red[wave][q][i] = v;
+    }
+    __syncthreads();
+    if (wave == 0 && j == 0 && act) {
+        float tot[28];
+#pragma unroll
+        for (int i = 0; i < 28; ++i) tot[i] = (red[0][q][i] + red[1][q][i]) + (red[2][q][i] + red[3][q][i]);
+        float* bp = bn_part + (size_t)blockIdx.x * 2 * gm.C;
+        float* wp = w_part + (size_t)blockIdx.x * 4 * gm.C;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bp[cq + c] = tot[c];
+            bp[gm.C + cq + c] = tot[4 + c];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) wp[(size_t)o * gm.C + cq + c] = tot[8 + o * 4 + c];
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) bias_part[(size_t)blockIdx.x * 4 + o] = tot[24 + o];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                             const float* __restrict__ b, const float* __restrict__ w,
+                                                             const float* __restrict__ scale, const float* __restrict__ dy,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                             float* __restrict__ dx, HeadGeom gm, int train) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & 15, j = lane >> 4;
+    const bool act = q < gm.C4;
+    const int g = blockIdx.x / gm.bpg;
+    const int64_t p0 = (int64_t)g * gm.ppg + (int64_t)(blockIdx.x - g * gm.bpg) * gm.ppb;
+    const int cq = act ? q * 4 : 0;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 av = act ? *reinterpret_cast<const f32x4*>(a + (size_t)g * gm.C + cq) : zero;
+    const f32x4 bv = act ? *reinterpret_cast<const f32x4*>(b + (size_t)g * gm.C + cq) : zero;
+    f32x4 wv[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) wv[o] = act ? *reinterpret_cast<const f32x4*>(w + (size_t)o * gm.C + cq) : zero;
+    const float sc = scale ? scale[g] : 1.f;
+    // the same arithmetic as bn_bwd_apply_kernel: v = (g - S0/R - xhat * S1/R) * gamma * rstd
+    const float invR = 1.f / (float)gm.ppg;
+    float mu[4], rs[4], k0[4], k1[4], gs[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const size_t gc = (size_t)g * gm.C + cq + c;
+        mu[c] = mean[gc];
+        rs[c] = rstd[gc];
+        k0[c] = (float)sums[((size_t)g * 2 + 0) * gm.C + cq + c] * invR;
+        k1[c] = (float)sums[((size_t)g * 2 + 1) * gm.C + cq + c] * invR;
+        gs[c] = (gamma ? gamma[cq + c] : 1.f) * rs[c];
+    }
+    for (int it = wave * 4 + j; it < gm.ppb; it += 16) {
+        const int64_t p = p0 + it;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + p * gm.C + cq);
+        const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + p * 4);
+        float gr[4], xh[4];
+        head_grad(xv, dyv, av, bv, wv, sc, gr, xh);
+        f32x4 o4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = gr[c];
+            if (train) {
+                const float xn = (xv[c] - mu[c]) * rs[c];
+                v = v - k0[c] - xn * k1[c];
+            }
+            o4[c] = v * gs[c];
+        }
+        if (act) *reinterpret_cast<f32x4*>(dx + p * gm.C + cq) = o4;
+    }
+}
+
+static bool head_geom(int64_t M, int64_t ppg, int C, HeadGeom* gm) {
+    if (!(M > 0 && ppg > 0 && M % ppg == 0 && C % 4 == 0 && C >= 4 && C <= 64 && ppg % 16 == 0)) return false;
+    int ppb = 4096;
+    while (ppb > 16 && ppg % ppb != 0) ppb >>= 1;
+    if (ppg % ppb != 0) return false;
+    gm->ppg = ppg;
+    gm->ppb = ppb;
+    gm->bpg = (int)(ppg / ppb);
+    gm->C = C;
+    gm->C4 = C / 4;
+    return (M / ppg) * gm->bpg < (1ll << 31);
+}
+
+extern "C" int dgmr_head_blocks(int64_t M, int64_t pixels_per_group, int C) {
+    HeadGeom gm;
+    return head_geom(M, pixels_per_group, C, &gm) ? (int)((M / pixels_per_group) * gm.bpg) : 0;
+}
+
+extern "C" int dgmr_head_fwd(const float* x, const float* a, const float* b, const float* w, const float* bias, const float* scale,
+                             float* y, int64_t M, int64_t pixels_per_group, int C, void* stream) {
+    HeadGeom gm;
+    DGMR_CHECK_ARG(x && a && b && w && y, "dgmr_head_fwd: null pointer");
+    DGMR_CHECK_ARG(head_geom(M, pixels_per_group, C, &gm), "dgmr_head_fwd: M=%lld pixels_per_group=%lld C=%d unsupported", (long long)M,
+                   (long long)pixels_per_group, C);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((M / pixels_per_group) * gm.bpg)), dim3(256), 0, ST, x, a, b, w, bias, scale, y, gm);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_head_bwd_sums(const float* x, const float* a, const float* b, const float* w, const float* scale, const float* dy,
+                                  float* bn_partials, float* w_partials, float* bias_partials, int64_t M, int64_t pixels_per_group,
+                                  int C, void* stream) {
+    HeadGeom gm;
+    DGMR_CHECK_ARG(x && a && b && w && dy && bn_partials && w_partials && bias_partials, "dgmr_head_bwd_sums: null pointer");
+    DGMR_CHECK_ARG(head_geom(M, pixels_per_group, C, &gm), "dgmr_head_bwd_sums: M=%lld pixels_per_group=%lld C=%d unsupported",
+                   (long long)M, (long long)pixels_per_group, C);
+    hipLaunchKernelGGL(head_bwd_sums_kernel, dim3((unsigned)((M / pixels_per_group) * gm.bpg)), dim3(256), 0, ST, x, a, b, w, scale, dy,
+                       bn_partials, w_partials, bias_partials, gm);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_head_bwd_apply(const float* x, const float* a, const float* b, const float* w, const float* scale, const float* dy,
+                                   const float* mean, const float* rstd, const float* gamma, const double* sums, float* dx,
+                                   float* dgamma, float* dbeta, int64_t M, int64_t pixels_per_group, int C, int train, void* stream) {
+    HeadGeom gm;
+    DGMR_CHECK_ARG(x && a && b && w && dy && mean && rstd && sums && dx, "dgmr_head_bwd_apply: null pointer");
+    DGMR_CHECK_ARG(head_geom(M, pixels_per_group, C, &gm), "dgmr_head_bwd_apply: M=%lld pixels_per_group=%lld C=%d unsupported",
+                   (long long)M, (long long)pixels_per_group, C);
+    const int G = (int)(M / pixels_per_group);
+    hipLaunchKernelGGL(head_bwd_apply_kernel, dim3((unsigned)(G * gm.bpg)), dim3(256), 0, ST, x, a, b, w, scale, dy, mean, rstd, gamma, sums,
+                       dx, gm, train);
+    if (dgamma || dbeta)
+        hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, sums, dgamma, dbeta, G, C);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int dgmr_pool_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, int pd, float scale, void* stream) {
     DGMR_CHECK_ARG(dy && dx, "dgmr_pool_bwd: null pointer");
     DGMR_CHECK_ARG(C % 4 == 0 && (pd == 1 || pd == 2), "dgmr_pool_bwd: C=%d pd=%d unsupported", C, pd);

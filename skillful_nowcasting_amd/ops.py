@@ -651,9 +651,88 @@ def call_nsplit(m: int, cout: int, k: int, groups: int = 1) -> int:
     return int(load().dgmr_conv_wgrad_nsplit(m, cout, k, groups))
 
 
+class HeadFn(Function):
+    """The sampler's output layer, relu(BatchNorm(x)) -> SN 1x1 conv to 4 channels (generators.py:159-166), as three streaming fp32
+    kernels (dgmr_head_*): 28 M pixels x 48 channels at the paper size, HBM-bound.  The data gradient of the conv is never written:
+    pass 1 takes BatchNorm's backward sums, the raw weight gradient and the bias gradient from it in registers, pass 2 recomputes it
+    and applies BatchNorm's backward.  Same contract as ConvFn (parameter gradients accumulate straight into .grad)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, scale, bn_gamma, bn_beta, spec: ConvSpec):
+        require_hip(x)
+        x = to_cl(x)
+        require_weight_layout(w)
+        n, c, _, h, wd = _dims(x)
+        bn = spec.bn
+        m, ppg = n * h * wd, bn.group_size * h * wd
+        y = empty_cl((n, 4, h, wd), x)
+        call("dgmr_head_fwd", _p(x), _p(bn.a), _p(bn.b), _p(w), _p(bias), _p(scale), _p(y), m, ppg, c, _stream())
+        sn = spec.sn
+        ctx.spec = spec
+        ctx.params = (w, bias)
+        ctx.save_for_backward(x, scale, sn.u if sn else None, sn.v if sn else None, bn.a, bn.b, bn.mean, bn.rstd)
+        ctx.geom = (n, c, h, wd, m, ppg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ._lib import load
+
+        spec: ConvSpec = ctx.spec
+        x, scale, sn_u, sn_v, bn_a, bn_b, bn_mean, bn_rstd = ctx.saved_tensors
+        w, bias = ctx.params
+        n, c, h, wd, m, ppg = ctx.geom
+        bn = spec.bn
+        dy = to_cl(dy)
+        dev, st = dy.device, _stream()
+        groups = m // ppg
+        nblk = int(load().dgmr_head_blocks(m, ppg, c))
+        bn_part = torch.empty(nblk, 2, c, device=dev, dtype=torch.float32)
+        w_part = torch.empty(nblk, 4, c, device=dev, dtype=torch.float32)
+        b_part = torch.empty(nblk, 4, device=dev, dtype=torch.float32)
+        call("dgmr_head_bwd_sums", _p(x), _p(bn_a), _p(bn_b), _p(w), _p(scale), _p(dy), _p(bn_part), _p(w_part), _p(b_part), m, ppg, c, st)
+        if bias is not None and bias.requires_grad:
+            grad_buffer(bias).add_(b_part.sum(0))
+        if w.requires_grad:
+            gw = grad_buffer(w)
+            g = torch.empty(4 * c, device=dev, dtype=torch.float32)
+            if scale is None:
+                call("dgmr_wgrad_reduce", _p(w_part), nblk, 1, 4 * c, None, None, _p(g), None, st)
+                call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), None, None, None, None, 4, c, 1, 1, 1, st)
+            else:
+                dot = torch.zeros(groups, device=dev, dtype=torch.float32)
+                call("dgmr_wgrad_reduce", _p(w_part), nblk, groups, 4 * c, _p(w), _p(scale), _p(g), _p(dot), st)
+                call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), _p(sn_u), _p(sn_v), 4, c, 1, groups, 1, st)
+        sums = torch.zeros(groups * 2 * c, device=dev, dtype=torch.float64)
+        call("dgmr_bn_partial_reduce", _p(bn_part), _p(sums), groups, nblk // groups, c, st)
+        call("dgmr_bn_bwd_center", _p(sums), _p(bn_mean), _p(bn_rstd), groups, c, st)
+        dx = empty_cl(x.shape, dy)
+        dgam = grad_buffer(bn.gamma) if (bn.gamma is not None and bn.gamma.requires_grad) else None
+        dbet = grad_buffer(bn.beta) if (bn.beta is not None and bn.beta.requires_grad) else None
+        call("dgmr_head_bwd_apply", _p(x), _p(bn_a), _p(bn_b), _p(w), _p(scale), _p(dy), _p(bn_mean), _p(bn_rstd), _p(bn.gamma), _p(sums),
+             _p(dx), _p(dgam), _p(dbet), m, ppg, c, int(bn.train), st)
+        return dx, None, None, None, None, None, None
+
+
+def _head_applies(x, w, scale, residual, spec: ConvSpec) -> bool:
+    bn = spec.bn
+    if bn is None or x.dim() != 4 or w.dim() != 4 or tuple(w.shape[2:]) != (1, 1) or w.shape[0] != 4 or residual is not None:
+        return False
+    if spec.upsample or spec.act_relu or spec.want_stats or spec.gamma_scale or w.shape[1] != x.shape[1]:
+        return False
+    if (spec.sn is not None and spec.sn.groups != bn.groups) or (spec.sn is None and scale is not None):
+        return False
+    from ._lib import load
+
+    n, c, h, wd = x.shape
+    return int(load().dgmr_head_blocks(n * h * wd, bn.group_size * h * wd, c)) > 0
+
+
 def conv(x, w, bias=None, scale=None, residual=None, spec: Optional[ConvSpec] = None):
     spec = spec or ConvSpec()
     bn = spec.bn
+    if _head_applies(x, w, scale, residual, spec):
+        return HeadFn.apply(x, w, bias, scale, bn.gamma, bn.beta, spec)
     return ConvFn.apply(x, w, bias, scale, residual, bn.gamma if bn else None, bn.beta if bn else None, spec)
 
 

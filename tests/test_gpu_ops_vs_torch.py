@@ -263,3 +263,56 @@ def test_conv_output_statistics(mode, n, h, w, cin, cout, groups, up, res):
     finally:
         S.set_precision("f32")
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n,hw,c,groups", [(12, 32, 48, 3), (8, 64, 48, 8), (6, 16, 64, 2), (4, 32, 24, 1)])
+def test_sampler_head_vs_torch(n, hw, c, groups):
+    """ops.HeadFn (dgmr_head_*): relu(BatchNorm(x)) -> spectrally-normalised 1x1 conv to 4 channels, per call group its own batch
+    statistics and sigma - forward, input gradient (through the batch statistics), weight / bias / gamma / beta gradients and the
+    running statistics against torch in float64."""
+    from skillful_nowcasting_amd import ops
+
+    torch.manual_seed(c + hw)
+    x = torch.randn(n, c, hw, hw, dtype=torch.float64) * 1.5 + 0.4
+    w = torch.randn(4, c, 1, 1, dtype=torch.float64) * c ** -0.5
+    b = torch.randn(4, dtype=torch.float64)
+    gam = torch.rand(c, dtype=torch.float64) + 0.5
+    bet = torch.randn(c, dtype=torch.float64) * 0.3
+    u = F.normalize(torch.randn(groups, 4, dtype=torch.float64), dim=1)
+    v = F.normalize(torch.randn(groups, c, dtype=torch.float64), dim=1)
+    cot = torch.randn(n, 4, hw, hw, dtype=torch.float64)
+    per = n // groups
+    # ---- float64 reference ----
+    xr, wr, br, gr, ber = (t.clone().requires_grad_(True) for t in (x, w, b, gam, bet))
+    ys, sig = [], []
+    for q in range(groups):
+        xq = xr[q * per:(q + 1) * per]
+        hq = F.relu(F.batch_norm(xq, None, None, gr, ber, True, 0.1, 1e-5))
+        sigma = torch.dot(u[q], wr.flatten(1) @ v[q])
+        sig.append(sigma.detach())
+        ys.append(F.conv2d(hq, wr / sigma, br))
+    yref = torch.cat(ys, 0)
+    (yref * cot).sum().backward()
+    # ---- HIP ----
+    mf = torch.channels_last
+    xd = x.float().to(DEV).contiguous(memory_format=mf).requires_grad_(True)
+    wd = torch.nn.Parameter(w.float().to(DEV).contiguous(memory_format=mf))
+    bd = torch.nn.Parameter(b.float().to(DEV))
+    gd = torch.nn.Parameter(gam.float().to(DEV))
+    bed = torch.nn.Parameter(bet.float().to(DEV))
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    nb = torch.zeros((), dtype=torch.long, device=DEV)
+    st = ops.bn_prepare(xd.detach(), gd, bed, rm, rv, nb, 1e-5, 0.1, True, groups)
+    inv_sigma = (1.0 / torch.stack(sig)).float().to(DEV)
+    sn = ops.SNCall(inv_sigma, u.float().to(DEV), v.float().to(DEV), groups)
+    spec = ops.ConvSpec(bn=st, sn=sn)
+    assert ops._head_applies(xd, wd, inv_sigma, None, spec)
+    y = ops.conv(xd, wd, bd, inv_sigma, None, spec)
+    (y * cot.float().to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    _close(y, yref, "forward", 1e-5)
+    _close(xd.grad, xr.grad, "input gradient", 5e-5)
+    _close(wd.grad, wr.grad, "weight gradient", 2e-5)
+    _close(bd.grad, br.grad, "bias gradient", 2e-5)
+    _close(gd.grad, gr.grad, "gamma gradient", 2e-5)
+    _close(bed.grad, ber.grad, "beta gradient", 2e-5)
