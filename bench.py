@@ -137,11 +137,17 @@ def time_steps(model, batch, first_idx, n, barrier):
     barrier()
     t0 = time.perf_counter()
     evs[0].record()
+    host = []
     for i in range(n):
+        h0 = time.perf_counter()
         model.training_step(batch, first_idx + i)
         evs[i + 1].record()
+        ms_ = torch.cuda.memory_stats()
+        host.append((round(1e3 * (time.perf_counter() - h0), 1), round(torch.cuda.memory_reserved() / 2**30, 2),
+                     ms_.get("num_device_alloc", 0), ms_.get("num_alloc_retries", 0)))
     barrier()
     dt = time.perf_counter() - t0
+    time_steps.host = host  # per step: host ms inside training_step, reserved GB, device allocations so far, allocator retries
     return dt, [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
 
 
@@ -199,6 +205,7 @@ def main():
     for i in range(args.warmup):
         model.training_step(batch, i)
     dt, step_ms = time_steps(model, batch, args.warmup, args.steps, barrier)
+    step_host = list(time_steps.host)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -284,7 +291,11 @@ def main():
         out = {
             "metric": "radar frames/sec (G+D step) 4->18 @256^2" if args.workload == "paper" else f"radar frames/sec (G+D step) [{args.workload}]",
             "value": value, "unit": "radar frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "ms_per_step_median": ms_median, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "ms_per_step_median": ms_median, "step_ms": [round(v, 1) for v in step_ms], "step_host_ms__reserved_gb__device_allocs__retries": step_host,
+            "hbm": {"max_allocated_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                    "reserved_gb": round(torch.cuda.memory_reserved() / 2**30, 1),
+                    "alloc_retries": torch.cuda.memory_stats().get("num_alloc_retries", 0)},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 tensors, split-bf16 MFMA operands, fp32 accumulate)", "bf16": "bf16"}[args.precision],
             "data": "synthetic torch.rand frames, random-init weights",
             "config": {"workload": f"DGMR.training_step {args.workload}: {kw}, H=W={hw}", "per_gpu_batch": B, "global_batch": world * B,

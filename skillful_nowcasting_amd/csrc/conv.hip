@@ -465,7 +465,7 @@ __global__ void flip_weights_kernel(const float* __restrict__ w, float* __restri
 constexpr int WG_MAX_GROUPS = 128;
 // Partial element i = (co, tap, ci) of a [Cout][taps][cs] slab lands at j = (co*taps + tap)*ct + coff + ci of g / w
 // (cs == ct, coff == 0: j == i).
-template <int MAXG>
+template <int MAXG, bool VEC4 = true>
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int groups, size_t numel,
                                     const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ g,
                                     float* __restrict__ dot, int taps, int cs, int ct, int coff) {
@@ -475,7 +475,41 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
     float d[MAXG];  // one running <P_q, W> per group, in registers (MAXG = 128: ~3 waves per SIMD, still an HBM-bound stream)
 #pragma unroll
     for (int q = 0; q < MAXG; ++q) d[q] = 0.f;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
+    // four consecutive elements per thread (16-byte loads: the slab walk of one element is a chain of nsplit dependent-address
+    // loads, 4-byte lanes left the stream at 0.5 TB/s); a quad never leaves its (co, tap) row: cs, ct, coff are multiples of 4
+    const bool vec4 = VEC4 && (numel & 3) == 0 && (cs & 3) == 0 && (ct & 3) == 0 && (coff & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(partial) & 15) == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0 &&
+                      (!w || (reinterpret_cast<uintptr_t>(w) & 15) == 0);
+    if (vec4) {
+        const size_t n4 = numel >> 2;
+        for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * blockDim.x) {
+            const size_t i = i4 << 2;
+            size_t j = i;
+            if (cs != ct) {
+                const size_t co = i / rowlen, r = i - co * rowlen;
+                const size_t tap = r / cs, ci = r - tap * cs;
+                j = (co * taps + tap) * ct + coff + ci;
+            }
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 wi = w ? *reinterpret_cast<const f32x4*>(w + j) : zero;
+            f32x4 tot = zero;
+#pragma unroll
+            for (int q = 0; q < MAXG; ++q) {
+                if (q < groups) {
+                    f32x4 s = zero;
+                    for (int k = 0; k < spg; ++k) s += *reinterpret_cast<const f32x4*>(partial + (size_t)(q * spg + k) * numel + i);
+                    const float sq = scale ? scale[q] : 1.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {  // the element order of the scalar path: bit-identical sums per element
+                        tot[e] = fmaf(s[e], sq, tot[e]);
+                        d[q] = fmaf(s[e], wi[e], d[q]);
+                    }
+                }
+            }
+            *reinterpret_cast<f32x4*>(g + j) = tot;
+        }
+    }
+    for (size_t i = vec4 ? numel : blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
         size_t j = i;
         if (cs != ct) {
             const size_t co = i / rowlen, r = i - co * rowlen;

@@ -80,6 +80,23 @@ def _splitk_ws(device) -> torch.Tensor:
     return ws
 
 
+_SCRATCH = {}
+
+
+def _scratch(numel: int, device, key: str) -> torch.Tensor:
+    """A persistent fp32 scratch buffer per (device, key), grown to the largest request: for multi-GB temporaries that live inside one
+    backward function (launches are stream-ordered: the next user overwrites it only after the previous kernels).  Kept out of
+    torch's caching allocator on purpose - a 22.8 GB temporary that comes and goes made the allocator split its cached block for
+    other requests and hipMalloc a second one a few steps later (0.4 s stall in the third step, tools/mem_segments.py)."""
+    k = (device, key)
+    buf = _SCRATCH.get(k)
+    if buf is None or buf.numel() < numel:
+        _SCRATCH.pop(k, None)
+        buf = torch.empty(numel, device=device, dtype=torch.float32)
+        _SCRATCH[k] = buf
+    return buf[:numel]
+
+
 def require_hip(t: torch.Tensor, what: str = "input"):
     if not t.is_cuda:
         raise RuntimeError(
@@ -551,7 +568,7 @@ class ConvFn(Function):
             if spec.upsample and _PRECISION_CODE != 0 and not _NO_PHASES and (kd, kh, kw) == (1, 3, 3) and d == 1:
                 # upsampling conv, bf16 modes: sum the 2x2 pixels of dy that meet each INPUT pixel under each tap (9 planes), then the
                 # gradient is a 1x1 problem on the low-resolution map - a quarter of the multiply steps (dgmr_upsample_wgrad_sums)
-                z9 = torch.empty(n * (h // 2) * (wd // 2) * 9 * cout, device=dev, dtype=torch.float32)
+                z9 = _scratch(n * (h // 2) * (wd // 2) * 9 * cout, dev, "z9")
                 call("dgmr_upsample_wgrad_sums", _p(dy), _p(z9), n, h // 2, wd // 2, cout, st)
                 wa.x, wa.dy = _p(x), _p(z9)
                 wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, 1, h // 2, wd // 2, cin, 9 * cout
