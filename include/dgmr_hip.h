@@ -75,7 +75,8 @@ typedef struct dgmr_conv_args {
     int32_t ksplit;        /* out: ignored on input; the library splits K itself when splitk_ws is given and the grid is small */
     const float* gru_h;    /* [M][Cout] previous hidden state (GRU modes) */
     const float* gru_pu;   /* [M][Cout] update-gate pre-activation (DGMR_EPI_GRU_BLEND) */
-    float* pre_out;        /* [M][Cout] receives the pre-activation (scale+bias applied) in the GRU modes (needed by the backward) */
+    float* pre_out;        /* [M][Cout] receives the pre-activation (scale+bias applied) in the GRU modes (needed by the backward);
+                              NULL: not stored (forwards without a graph: a fifth of the recurrent step's HBM traffic) */
     float* splitk_ws;      /* NULL, or scratch for split-K partial sums */
     int64_t splitk_ws_bytes;
     const uint16_t* w_split; /* NULL, or the SAME weights (of the slice, if w_cin/w_coff select one) pre-split into dense bf16

@@ -225,7 +225,7 @@ __global__ void splitk_reduce4_kernel(const dgmr_conv_args p, const int M, const
                 o[j] = t;
             }
         }
-        if (p.epi_mode != DGMR_EPI_PLAIN) *reinterpret_cast<f32x4*>(p.pre_out + idx) = v;
+        if (p.epi_mode != DGMR_EPI_PLAIN && p.pre_out) *reinterpret_cast<f32x4*>(p.pre_out + idx) = v;
         *reinterpret_cast<f32x4*>(p.y + idx) = o;
     }
 }
@@ -588,11 +588,15 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     const bool is3d = p.KD == 3 && p.D > 1 && glds_ok && !p.upsample && !p.residual_up;
     if (!(g_precision != 0 && p.w_split && ((p.KD == 1 && p.D == 1) || is3d) && p.KH == 3 && p.KW == 3 && p.Cin % 8 == 0 &&
           (p.W == 16 || p.W % 32 == 0 || small8) &&
-          (g_tune_window < 0 ? (M64 / 128) * ((C + 127) / 128) * (p.reserved0 ? 4 : 1) >= 192 : g_tune_window >= 1)))
+          (g_tune_window < 0 ? (M64 / 128) * ((C + 63) / 64) * (p.reserved0 ? 4 : 1) >= 192 : g_tune_window >= 1)))
         return false;
     w->tw_shift = small8 ? 3 : (p.W == 16 ? 4 : 5);
     w->g_shift = small8 ? 1 : 0;
     w->bnw = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
+    // few pixels, many channels (the ConvGRU steps on 8x8 / 16x16 maps: 6144 pixels x 384 channels): 128-column tiles would leave
+    // half the CUs without a workgroup - 64-column tiles double the grid (measured 146 -> see profiles/README.md, us per step conv)
+    if (g_tune_window < 0 && C % 64 == 0 && (M64 / 128) * ((C + w->bnw - 1) / w->bnw) * (p.reserved0 ? 4 : 1) < 256) w->bnw = 64;
+    if (g_tune_window < 0 && (M64 / 128) * ((C + w->bnw - 1) / w->bnw) * (p.reserved0 ? 4 : 1) < 192) return false;
     // 256-pixel tiles (8 x 32 or 16 x 16 pixels of one image), LDS-DMA kernel
     // (not at 128 output channels: 8 accumulator blocks per wave spill at two workgroups per CU).  Measured +2 ... +8 % on the
     // 96- / 64-channel layers of the sampler at T x B maps (gpurun r2o), -10 ... -20 % on launches of a few hundred workgroups:
@@ -689,8 +693,8 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     // the kernels address the input with 32-bit element offsets
     DGMR_CHECK_ARG((M64 >> (a->upsample ? 2 : 0)) * a->Cin < (1ll << 32), "dgmr_conv_fwd: input of %lld x %d elements exceeds 2^32",
                    (long long)M64, a->Cin);
-    DGMR_CHECK_ARG(a->epi_mode == DGMR_EPI_PLAIN || (a->pre_out && a->gru_h && (a->epi_mode != DGMR_EPI_GRU_BLEND || a->gru_pu)),
-                   "dgmr_conv_fwd: epi_mode %d needs pre_out / gru_h / gru_pu", a->epi_mode);
+    DGMR_CHECK_ARG(a->epi_mode == DGMR_EPI_PLAIN || (a->gru_h && (a->epi_mode != DGMR_EPI_GRU_BLEND || a->gru_pu)),
+                   "dgmr_conv_fwd: epi_mode %d needs gru_h / gru_pu", a->epi_mode);
     DGMR_CHECK_ARG(a->w_cin == 0 || (a->w_cin >= a->w_coff + a->Cin && a->w_coff >= 0 && a->w_coff % 4 == 0 && a->w_cin % 4 == 0),
                    "dgmr_conv_fwd: weight slice [%d, %d) of %d channels is invalid", a->w_coff, a->w_coff + a->Cin, a->w_cin);
     dgmr_conv_args p = *a;

@@ -110,10 +110,10 @@ __device__ __forceinline__ void epilogue_store_row(const dgmr_conv_args& p, floa
     if (p.addend) v += p.addend[idx];
     v = fmaf(v, e.sc, bias_v);
     if (p.epi_mode == DGMR_EPI_GRU_GATE) {
-        p.pre_out[idx] = v;
+        if (p.pre_out) p.pre_out[idx] = v;
         v = sigmoid_(v) * p.gru_h[idx];
     } else if (p.epi_mode == DGMR_EPI_GRU_BLEND) {
-        p.pre_out[idx] = v;
+        if (p.pre_out) p.pre_out[idx] = v;
         const float s = sigmoid_(p.gru_pu[idx]);
         v = s * p.gru_h[idx] + (1.f - s) * fmaxf(v, 0.f);
     } else {
@@ -136,10 +136,10 @@ __device__ __forceinline__ void epilogue_store(const dgmr_conv_args& p, float v,
     if (p.scale) v *= p.scale[n / p.scale_group];
     if (p.bias) v += p.bias[col];
     if (p.epi_mode == DGMR_EPI_GRU_GATE) {  // r * h with r = sigmoid(pre)   (ConvGRU.py:69-71,78)
-        p.pre_out[idx] = v;
+        if (p.pre_out) p.pre_out[idx] = v;
         v = sigmoid_(v) * p.gru_h[idx];
     } else if (p.epi_mode == DGMR_EPI_GRU_BLEND) {  // u*h + (1-u)*relu(pre_c)   (ConvGRU.py:80-84)
-        p.pre_out[idx] = v;
+        if (p.pre_out) p.pre_out[idx] = v;
         const float s = sigmoid_(p.gru_pu[idx]);
         v = s * p.gru_h[idx] + (1.f - s) * fmaxf(v, 0.f);
     } else {

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
                         o = sigmoid_(v[j]) * hv[j];
                     }
                     if (colj[j] < p.Cout) {
-                        p.pre_out[mrow + colj[j]] = v[j];
+                        if (p.pre_out) p.pre_out[mrow + colj[j]] = v[j];
                         p.y[mrow + colj[j]] = o;
                     }
                 }

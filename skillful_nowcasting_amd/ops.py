@@ -80,6 +80,7 @@ def _splitk_ws(device) -> torch.Tensor:
     return ws
 
 
+_GRU_KEEP_ALWAYS = bool(int(__import__("os").environ.get("DGMR_GRU_KEEP_ALWAYS", "0")))  # measurement switch
 _SCRATCH = {}
 
 
@@ -1049,24 +1050,36 @@ class ConvGRUFn(Function):
             x_ptr = step_ptr
         buf = empty_cl(((T + 1) * b, ch, hh, ww), x_all)  # h_{-1} = h0, h_0, ..., h_{T-1}
         _copy(_p(h0), _p(buf), n_step)
-        pr, pu, pc, rh = (empty_cl((tb, ch, hh, ww), x_all) for _ in range(4))
+        # forwards without a graph (the discriminator passes' generator forward, the first pass of the checkpointed draws, eval): the
+        # gate pre-activations and r*h of earlier steps are only read by the backward - not stored, one step of scratch instead
+        keep = any(ctx.needs_input_grad) or _GRU_KEEP_ALWAYS
+        if keep:
+            pr, pu, pc, rh = (empty_cl((tb, ch, hh, ww), x_all) for _ in range(4))
+        else:
+            pu, rh = (empty_cl((b, ch, hh, ww), x_all) for _ in range(2))
+            pr = pc = None
+
+        def kept(t_: Optional[torch.Tensor], t: int):
+            return None if t_ is None else (step_ptr(t_, t) if keep else t_.data_ptr())
+
         sr, su, sc = seqs
         spr, spu, spc = (_split_planes(w, False, cx, ch) for w in (wr, wu, wc))  # h halves as bf16 planes (bf16 modes, big maps)
         for t in range(T):
             hp, out = step_ptr(buf, t), step_ptr(buf, t + 1)
-            _launch_conv(hp, _p(wr), br, scale_ptr(sr, t), step_ptr(rh, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
-                         addend=x_ptr(xr, t), epi_mode=EPI_GRU_GATE, gru_h=hp, pre_out=step_ptr(pr, t), device=dev, w_split=spr,
+            _launch_conv(hp, _p(wr), br, scale_ptr(sr, t), kept(rh, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
+                         addend=x_ptr(xr, t), epi_mode=EPI_GRU_GATE, gru_h=hp, pre_out=kept(pr, t), device=dev, w_split=spr,
                          scale_group=sgroup(sr))
-            _launch_conv(hp, _p(wu), bu, scale_ptr(su, t), step_ptr(pu, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
+            _launch_conv(hp, _p(wu), bu, scale_ptr(su, t), kept(pu, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
                          addend=x_ptr(xu, t), device=dev, w_split=spu, scale_group=sgroup(su))
-            _launch_conv(step_ptr(rh, t), _p(wc), bc, scale_ptr(sc, t), out, b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
-                         addend=x_ptr(xc, t), epi_mode=EPI_GRU_BLEND, gru_h=hp, gru_pu=step_ptr(pu, t), pre_out=step_ptr(pc, t),
+            _launch_conv(kept(rh, t), _p(wc), bc, scale_ptr(sc, t), out, b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
+                         addend=x_ptr(xc, t), epi_mode=EPI_GRU_BLEND, gru_h=hp, gru_pu=kept(pu, t), pre_out=kept(pc, t),
                          device=dev, w_split=spc, scale_group=sgroup(sc))
         ctx.params = params
         ctx.geom = (T, b, cx, ch, hh, ww, kh, kw, draws)
         ctx.x_shared = x_shared
         ctx.groups = tuple(q.groups for q in seqs)
-        ctx.save_for_backward(x_all, buf, pr, pu, pc, rh, sr.inv_sigma, sr.u, sr.v, su.inv_sigma, su.u, su.v, sc.inv_sigma, sc.u, sc.v)
+        if keep:
+            ctx.save_for_backward(x_all, buf, pr, pu, pc, rh, sr.inv_sigma, sr.u, sr.v, su.inv_sigma, su.u, su.v, sc.inv_sigma, sc.u, sc.v)
         return buf[b:]
 
     @staticmethod

@@ -43,6 +43,11 @@ SHAPES = [
     ("gru4.h-step B4", 4, 1, 64, 64, 48, 48, (1, 3, 3), False, False),
     ("gru3.h-step B16", 16, 1, 32, 32, 96, 96, (1, 3, 3), False, False),
     ("gru2.x-part T18B4", 72, 1, 16, 16, 384, 192, (1, 3, 3), False, False),
+    # recurrent step convs with the six draws batched (96 samples per step)
+    ("gru4.h-step B96", 96, 1, 64, 64, 48, 48, (1, 3, 3), False, False),
+    ("gru3.h-step B96", 96, 1, 32, 32, 96, 96, (1, 3, 3), False, False),
+    ("gru2.h-step B96", 96, 1, 16, 16, 192, 192, (1, 3, 3), False, False),
+    ("gru1.h-step B96", 96, 1, 8, 8, 384, 384, (1, 3, 3), False, False),
     # weight gradient of the upsampling convs as a 1x1 problem on the 9 pair-summed planes of dy (Cout' = 9 Cout)
     ("z9 up_g1", 288, 1, 8, 8, 768, 3456, (1, 1, 1), False, True),
     ("z9 up_g2", 288, 1, 16, 16, 384, 1728, (1, 1, 1), False, True),
@@ -54,6 +59,11 @@ SHAPES = [
     ("real up_g3.first", 288, 1, 64, 64, 192, 96, (1, 3, 3), True, True),
     ("real up_g4.first", 288, 1, 128, 128, 96, 48, (1, 3, 3), True, True),
     ("real up_g4.last", 288, 1, 128, 128, 48, 48, (1, 3, 3), False, True),
+    # the upsampling convs as the step runs them: all six draws in one batch, 108 spectral-norm call groups (--groups=108)
+    ("full up_g1.first", 1728, 1, 16, 16, 768, 768, (1, 3, 3), True, True),
+    ("full up_g2.first", 1728, 1, 32, 32, 384, 384, (1, 3, 3), True, True),
+    ("full up_g3.first", 1728, 1, 64, 64, 192, 192, (1, 3, 3), True, True),
+    ("full up_g4.first", 1728, 1, 128, 128, 96, 96, (1, 3, 3), True, True),
 ]
 
 
@@ -69,7 +79,14 @@ def bench(fn, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
+GROUPS = 1
+
+
 def main():
+    global GROUPS
+    for a_ in sys.argv[1:]:
+        if a_.startswith("--groups="):
+            GROUPS = int(a_.split("=")[1])
     load()
     dev = "cuda"
     for a in sys.argv[1:]:
@@ -138,6 +155,12 @@ def main():
             wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, d, h, w, cin, cout
             wa.KD, wa.KH, wa.KW = kd, kh, kw
             wa.upsample, wa.pre_relu, wa.pre_group, wa.nsplit = int(up), 0, n, ns
+            if GROUPS > 1:
+                wa.groups = GROUPS
+                call("dgmr_conv_wgrad_plan", ctypes.byref(wa))
+                ns = wa.nsplit
+                partial = torch.empty(ns * cout * k, device=dev)
+                wa.partial = partial.data_ptr()
 
             def wg():
                 call("dgmr_conv_wgrad", ctypes.byref(wa), ops._stream())
@@ -150,7 +173,7 @@ def main():
                 wz.x, wz.dy = x.data_ptr(), z9.data_ptr()
                 wz.pre_a, wz.pre_b = (a.data_ptr(), b.data_ptr()) if bn else (None, None)
                 wz.N, wz.D, wz.H, wz.W, wz.Cin, wz.Cout = n, 1, h // 2, w // 2, cin, 9 * cout
-                wz.KD, wz.KH, wz.KW, wz.upsample, wz.pre_relu, wz.pre_group, wz.groups = 1, 1, 1, 0, 0, n, 1
+                wz.KD, wz.KH, wz.KW, wz.upsample, wz.pre_relu, wz.pre_group, wz.groups = 1, 1, 1, 0, 0, n, GROUPS
                 call("dgmr_conv_wgrad_plan", ctypes.byref(wz))
                 pz = torch.empty(wz.nsplit * 9 * cout * cin, device=dev)
                 wz.partial = pz.data_ptr()
