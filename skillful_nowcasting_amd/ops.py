@@ -80,6 +80,48 @@ def _splitk_ws(device) -> torch.Tensor:
     return ws
 
 
+# Weight gradients off the critical path: the backward chain only needs each conv's DATA gradient; its weight gradient (window /
+# im2col kernel, slab reduce, spectral-norm finalize - latency-bound kernels at 20-30 % matrix-pipe occupancy) runs on a second
+# stream beside the data-gradient convs of the layers below.  The main stream joins it when the backward pass ends
+# (autograd engine callback), i.e. before anything can read a .grad.
+_WGRAD_STREAM = __import__("os").environ.get("DGMR_WGRAD_STREAM", "1") != "0"
+_SIDE_STREAMS = {}
+_SIDE_PENDING = {}
+_SIDE_KEEP = []  # (event after the side work, tensors it reads)
+
+
+def _join_side_streams():
+    for idx, main in list(_SIDE_PENDING.items()):
+        main.wait_stream(_SIDE_STREAMS[idx])
+    _SIDE_PENDING.clear()
+    _SIDE_KEEP.clear()  # everything the main stream does from here on is ordered behind the side work
+
+
+def _on_side_stream(dev, fn, tensors):
+    """Run fn() (kernel launches through _stream()) on the device's side stream, ordered after everything issued so far on the current
+    stream; `tensors`: what fn reads that the caller may free right after (kept alive for the side stream's work)."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(idx)
+    if side is None:
+        side = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
+    while _SIDE_KEEP and _SIDE_KEEP[0][0].query():
+        _SIDE_KEEP.pop(0)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        fn()
+    tensors = tuple(t for t in tensors if isinstance(t, torch.Tensor))
+    for t in tensors:
+        t.record_stream(side)
+    # A reference is held until the side work is done: autograd accumulates a second gradient INTO a buffered one in place when
+    # nobody else holds it (InputBuffer) - e.g. the gradient this conv hands to its residual - and would overwrite dy on the main
+    # stream under the weight-gradient kernel still reading it here.
+    _SIDE_KEEP.append((side.record_event(), tensors))
+    if idx not in _SIDE_PENDING:
+        _SIDE_PENDING[idx] = main
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+
+
 _GRU_KEEP_ALWAYS = bool(int(__import__("os").environ.get("DGMR_GRU_KEEP_ALWAYS", "0")))  # measurement switch
 _SCRATCH = {}
 
@@ -562,50 +604,57 @@ class ConvFn(Function):
         groups = spec.groups
         taps = kd * kh * kw
         if w.requires_grad:
-            wa = WgradArgs()
-            wa.pre_a, wa.pre_b = (_p(bn_a), _p(bn_b)) if bn else (None, None)
-            wa.pre_relu, wa.pre_group = int(spec.pre_relu), (bn.group_size if bn else 1)
-            wa.groups = groups
-            if spec.upsample and _PRECISION_CODE != 0 and not _NO_PHASES and (kd, kh, kw) == (1, 3, 3) and d == 1:
-                # upsampling conv, bf16 modes: sum the 2x2 pixels of dy that meet each INPUT pixel under each tap (9 planes), then the
-                # gradient is a 1x1 problem on the low-resolution map - a quarter of the multiply steps (dgmr_upsample_wgrad_sums)
-                z9 = _scratch(n * (h // 2) * (wd // 2) * 9 * cout, dev, "z9")
-                call("dgmr_upsample_wgrad_sums", _p(dy), _p(z9), n, h // 2, wd // 2, cout, st)
-                wa.x, wa.dy = _p(x), _p(z9)
-                wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, 1, h // 2, wd // 2, cin, 9 * cout
-                wa.KD, wa.KH, wa.KW, wa.upsample = 1, 1, 1, 0
-                # bias: the centre-tap plane (ky = kx = 1) holds every pixel of dy exactly once - its column sums ride in the kernel
-                z9_bias = torch.zeros(9 * cout, device=dev, dtype=torch.float32) if want_bias else None
-                wa.bias_grad = _p(z9_bias)
-            else:
-                z9_bias = None
-                wa.x, wa.dy = _p(x), _p(dy)
-                wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, d, h, wd, cin, cout
-                wa.KD, wa.KH, wa.KW, wa.upsample = kd, kh, kw, int(spec.upsample)
-                wa.bias_grad = _p(grad_buffer(bias)) if want_bias else None
-            call("dgmr_conv_wgrad_plan", ctypes.byref(wa))  # slab count: depends on which kernel the library will pick
-            ns = wa.nsplit
-            partial = torch.empty(ns * cout * k, device=dev, dtype=torch.float32)
-            wa.partial = _p(partial)
-            call("dgmr_conv_wgrad", ctypes.byref(wa), st)
-            if z9_bias is not None:
-                grad_buffer(bias).add_(z9_bias.view(cout, 9)[:, 4])
-            gw = grad_buffer(w)
-            g = torch.empty(cout * k, device=dev, dtype=torch.float32)
-            if scale is None:
-                call("dgmr_wgrad_reduce", _p(partial), ns, 1, cout * k, None, None, _p(g), None, st)
-                call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), None, None, None, None, cout, cin, taps, 1, 1, st)
-            else:
-                # g = sum_q P_q / sigma_q ; dot[q] = <P_q, W>   (P_q: raw weight gradient over the rows of call q)
-                dot = torch.zeros(groups, device=dev, dtype=torch.float32)
-                call("dgmr_wgrad_reduce", _p(partial), ns, groups, cout * k, _p(w), _p(scale), _p(g), _p(dot), st)
-                if spec.sn is not None:
-                    call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), _p(sn_u), _p(sn_v), cout, cin, taps, groups, 1, st)
-                else:  # learnable scalar gain: d scale = <P, W>, dW = scale * P
-                    if scale_param is not None and scale_param.requires_grad:
-                        gs = grad_buffer(scale_param)
-                        call("dgmr_axpby", _p(gs), _p(dot), _p(gs), 1.0, 1.0, 1, st)
+            def weight_grad():
+                st = _stream()  # (the side stream when run there)
+                wa = WgradArgs()
+                wa.pre_a, wa.pre_b = (_p(bn_a), _p(bn_b)) if bn else (None, None)
+                wa.pre_relu, wa.pre_group = int(spec.pre_relu), (bn.group_size if bn else 1)
+                wa.groups = groups
+                if spec.upsample and _PRECISION_CODE != 0 and not _NO_PHASES and (kd, kh, kw) == (1, 3, 3) and d == 1:
+                    # upsampling conv, bf16 modes: sum the 2x2 pixels of dy that meet each INPUT pixel under each tap (9 planes), then the
+                    # gradient is a 1x1 problem on the low-resolution map - a quarter of the multiply steps (dgmr_upsample_wgrad_sums)
+                    z9 = _scratch(n * (h // 2) * (wd // 2) * 9 * cout, dev, "z9")
+                    call("dgmr_upsample_wgrad_sums", _p(dy), _p(z9), n, h // 2, wd // 2, cout, st)
+                    wa.x, wa.dy = _p(x), _p(z9)
+                    wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, 1, h // 2, wd // 2, cin, 9 * cout
+                    wa.KD, wa.KH, wa.KW, wa.upsample = 1, 1, 1, 0
+                    # bias: the centre-tap plane (ky = kx = 1) holds every pixel of dy exactly once - its column sums ride in the kernel
+                    z9_bias = torch.zeros(9 * cout, device=dev, dtype=torch.float32) if want_bias else None
+                    wa.bias_grad = _p(z9_bias)
+                else:
+                    z9_bias = None
+                    wa.x, wa.dy = _p(x), _p(dy)
+                    wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, d, h, wd, cin, cout
+                    wa.KD, wa.KH, wa.KW, wa.upsample = kd, kh, kw, int(spec.upsample)
+                    wa.bias_grad = _p(grad_buffer(bias)) if want_bias else None
+                call("dgmr_conv_wgrad_plan", ctypes.byref(wa))  # slab count: depends on which kernel the library will pick
+                ns = wa.nsplit
+                partial = torch.empty(ns * cout * k, device=dev, dtype=torch.float32)
+                wa.partial = _p(partial)
+                call("dgmr_conv_wgrad", ctypes.byref(wa), st)
+                if z9_bias is not None:
+                    grad_buffer(bias).add_(z9_bias.view(cout, 9)[:, 4])
+                gw = grad_buffer(w)
+                g = torch.empty(cout * k, device=dev, dtype=torch.float32)
+                if scale is None:
+                    call("dgmr_wgrad_reduce", _p(partial), ns, 1, cout * k, None, None, _p(g), None, st)
                     call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), None, None, None, None, cout, cin, taps, 1, 1, st)
+                else:
+                    # g = sum_q P_q / sigma_q ; dot[q] = <P_q, W>   (P_q: raw weight gradient over the rows of call q)
+                    dot = torch.zeros(groups, device=dev, dtype=torch.float32)
+                    call("dgmr_wgrad_reduce", _p(partial), ns, groups, cout * k, _p(w), _p(scale), _p(g), _p(dot), st)
+                    if spec.sn is not None:
+                        call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), _p(sn_u), _p(sn_v), cout, cin, taps, groups, 1, st)
+                    else:  # learnable scalar gain: d scale = <P, W>, dW = scale * P
+                        if scale_param is not None and scale_param.requires_grad:
+                            gs = grad_buffer(scale_param)
+                            call("dgmr_axpby", _p(gs), _p(dot), _p(gs), 1.0, 1.0, 1, st)
+                        call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), None, None, None, None, cout, cin, taps, 1, 1, st)
+
+            if _WGRAD_STREAM and ctx.needs_input_grad[0]:
+                _on_side_stream(dev, weight_grad, (x, dy, scale, bn_a, bn_b, sn_u, sn_v))
+            else:
+                weight_grad()
         # ---- input ----
         dx = None
         if ctx.needs_input_grad[0]:
