@@ -1197,6 +1197,47 @@ class ConvGRUFn(Function):
                 dsum.append(ds)
             x_rep = empty_cl((TD, cx, hh, ww), dout_all)  # the shared maps once per step, as the weight gradient's "input"
             call("dgmr_repeat_rows", _p(x_all), _p(x_rep), draws * cx * hh * ww, T, st)
+        # ---- weight / bias gradients, batched over T: off the critical path, beside the x-part data gradients and the layers below ----
+        def weight_grads():
+            st = _stream()  # (the side stream when run there)
+            hprev_all = buf  # rows [0, T*B) are h_{-1} .. h_{T-2}
+            for ki, (w, bias, dp, inv_s, u_, v_, g_, hsrc) in enumerate(((wr, br, dpr, isr, ur, vr, gr, hprev_all),
+                                                                         (wu, bu, dpu, isu, uu, vu, gu, hprev_all),
+                                                                         (wc, bc, dpc, isc, uc, vc, gc, rh))):
+                m = tb * hh * ww
+                want_bias = bias is not None and bias.requires_grad
+                if not w.requires_grad:
+                    if want_bias:
+                        tmpd = torch.empty(2 * ch, device=dev, dtype=torch.float64)
+                        call("dgmr_colsum", _p(dp), _p(grad_buffer(bias)), _p(tmpd), m, ch, 1, st)
+                    continue
+                g = torch.empty(ch * taps * ct, device=dev, dtype=torch.float32)
+                dot = torch.zeros(g_, device=dev, dtype=torch.float32)
+                # x half: T*B maps, or (shared x) the T per-step sums against T copies of the one map; h half: always T*B maps
+                x_half = (x_rep, dsum[ki], TD, cx, 0) if x_shared else (x_all, dp, tb, cx, 0)
+                for src, dy, nimg, cin, coff in (x_half, (hsrc, dp, tb, ch, cx)):
+                    k = taps * cin
+                    wa = WgradArgs()
+                    wa.x, wa.dy = _p(src), _p(dy)
+                    wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = nimg, 1, hh, ww, cin, ch
+                    wa.KD, wa.KH, wa.KW = 1, kh, kw
+                    wa.upsample, wa.pre_relu, wa.pre_group, wa.groups = 0, 0, 1, g_
+                    wa.bias_grad = _p(grad_buffer(bias)) if (want_bias and coff == 0) else None  # bias gradient once, with the x half
+                    call("dgmr_conv_wgrad_plan", ctypes.byref(wa))
+                    ns = wa.nsplit
+                    partial = torch.empty(ns * ch * k, device=dev, dtype=torch.float32)
+                    wa.partial = _p(partial)
+                    call("dgmr_conv_wgrad", ctypes.byref(wa), st)
+                    call("dgmr_wgrad_reduce_slice", _p(partial), ns, g_, ch, taps, cin, ct, coff, _p(w), _p(inv_s), _p(g), _p(dot), st)
+                call("dgmr_sn_wgrad_finalize", _p(g), _p(grad_buffer(w)), _p(dot), _p(inv_s), _p(u_), _p(v_), ch, ct, taps, g_, 1, st)
+
+        if _WGRAD_STREAM:
+            keep = [buf, rh, dpr, dpu, dpc, x_all, isr, ur, vr, isu, uu, vu, isc, uc, vc]
+            if x_shared:
+                keep += [x_rep] + dsum
+            _on_side_stream(dev, weight_grads, keep)
+        else:
+            weight_grads()
         # ---- x-part data gradient, batched over the T steps (each step with its own 1/sigma) ----
         dx_all = None
         if ctx.needs_input_grad[0] and x_shared:
@@ -1220,37 +1261,6 @@ class ConvGRUFn(Function):
                 _launch_conv(dp, _p(_flipped_weight(w, 0, cx)), None, inv_s, dst, tb, 1, hh, ww, ch, cx, 1, kh, kw, residual=res,
                              scale_group=tb // g_, w_split=_split_planes(w, True, 0, cx))
             dx_all = tmp
-        # ---- weight / bias gradients, batched over T ----
-        hprev_all = buf  # rows [0, T*B) are h_{-1} .. h_{T-2}
-        for ki, (w, bias, dp, inv_s, u_, v_, g_, hsrc) in enumerate(((wr, br, dpr, isr, ur, vr, gr, hprev_all),
-                                                                     (wu, bu, dpu, isu, uu, vu, gu, hprev_all),
-                                                                     (wc, bc, dpc, isc, uc, vc, gc, rh))):
-            m = tb * hh * ww
-            want_bias = bias is not None and bias.requires_grad
-            if not w.requires_grad:
-                if want_bias:
-                    tmpd = torch.empty(2 * ch, device=dev, dtype=torch.float64)
-                    call("dgmr_colsum", _p(dp), _p(grad_buffer(bias)), _p(tmpd), m, ch, 1, st)
-                continue
-            g = torch.empty(ch * taps * ct, device=dev, dtype=torch.float32)
-            dot = torch.zeros(g_, device=dev, dtype=torch.float32)
-            # x half: T*B maps, or (shared x) the T per-step sums against T copies of the one map; h half: always T*B maps
-            x_half = (x_rep, dsum[ki], TD, cx, 0) if x_shared else (x_all, dp, tb, cx, 0)
-            for src, dy, nimg, cin, coff in (x_half, (hsrc, dp, tb, ch, cx)):
-                k = taps * cin
-                wa = WgradArgs()
-                wa.x, wa.dy = _p(src), _p(dy)
-                wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = nimg, 1, hh, ww, cin, ch
-                wa.KD, wa.KH, wa.KW = 1, kh, kw
-                wa.upsample, wa.pre_relu, wa.pre_group, wa.groups = 0, 0, 1, g_
-                wa.bias_grad = _p(grad_buffer(bias)) if (want_bias and coff == 0) else None  # bias gradient once, with the x half
-                call("dgmr_conv_wgrad_plan", ctypes.byref(wa))
-                ns = wa.nsplit
-                partial = torch.empty(ns * ch * k, device=dev, dtype=torch.float32)
-                wa.partial = _p(partial)
-                call("dgmr_conv_wgrad", ctypes.byref(wa), st)
-                call("dgmr_wgrad_reduce_slice", _p(partial), ns, g_, ch, taps, cin, ct, coff, _p(w), _p(inv_s), _p(g), _p(dot), st)
-            call("dgmr_sn_wgrad_finalize", _p(g), _p(grad_buffer(w)), _p(dot), _p(inv_s), _p(u_), _p(v_), ch, ct, taps, g_, 1, st)
         return dx_all, dh0, None, None, None, None, None, None
 
 
