@@ -221,10 +221,15 @@ def main():
     if not args.no_roofline:
         # one extra step with HIP events around every conv launch (recorded on the launch stream inside the library)
         lib = _lib.load()
+        # per-kernel durations must not include a co-running kernel: the weight gradients, which the timed steps run on a second
+        # stream beside the data-gradient chain, are issued in line for this one instrumented step
+        side = S.ops._WGRAD_STREAM
+        S.ops._WGRAD_STREAM = False
         lib.dgmr_profile_enable(1)
         model.training_step(batch, args.warmup + args.steps)
         torch.cuda.synchronize()
         lib.dgmr_profile_enable(0)
+        S.ops._WGRAD_STREAM = side
         nv = lib.dgmr_profile_variants()
         ms = (ctypes.c_double * nv)()
         fl = (ctypes.c_double * nv)()
