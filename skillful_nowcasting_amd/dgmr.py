@@ -208,8 +208,18 @@ class DGMR(
         ##########################
         # Optimize Discriminator #
         ##########################
+        # The discriminator's optimiser step is issued as late as its results are needed: the generator forward that follows a D
+        # backward does not read D's parameters, so it runs beside the tail of D's weight gradients (second stream, ops.py) and the
+        # step comes after it.  Same operations, same RNG order, same results as "backward; step; forward".
+        d_step_pending = False
+
+        def finish_d_step():
+            ops.join_side_streams()
+            if self.grad_sync is not None:
+                self.grad_sync.sync("d")
+            d_opt.step()
+
         for _ in range(2):
-            d_opt.zero_grad()
             if strict:
                 # reference: predictions = checkpoint(self.forward, images), NOT detached (dgmr.py:150-157).  Its D-loss
                 # backward therefore (a) re-runs the generator forward once (checkpoint recompute, same RNG state -> same z),
@@ -221,15 +231,18 @@ class DGMR(
                     predictions = self.generator.forward_draws(images, 2, zs=torch.cat([z, z], dim=0))[:b]
             else:
                 predictions = self._generate(images, 1, grad=False)
+            if d_step_pending:
+                finish_d_step()
+            d_opt.zero_grad()
             discriminator_loss = self._disc_losses(images, future_images, predictions)
-            self.manual_backward(discriminator_loss)
-            if self.grad_sync is not None:
-                self.grad_sync.sync("d")
-            d_opt.step()
+            with ops.defer_side_join():
+                self.manual_backward(discriminator_loss)
+            d_step_pending = True
         ######################
         # Optimize Generator #
         ######################
         predictions = self._generate(images, self.generation_steps, grad=True)
+        finish_d_step()
         # D's parameter gradients from this pass are never read (the next d_opt.zero_grad() clears them): not computed
         d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
         for p in d_params:

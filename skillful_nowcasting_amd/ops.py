@@ -90,7 +90,34 @@ _SIDE_PENDING = {}
 _SIDE_KEEP = []  # (event after the side work, tensors it reads)
 
 
+_DEFER_JOIN = [0]
+
+
+class defer_side_join:
+    """Inside: the end of a backward pass does NOT make the main stream wait for the weight-gradient stream; the caller does, with
+    join_side_streams(), before it reads a .grad - after putting work that does not need the gradients in between
+    (DGMR.training_step: the generator forward of the next discriminator iteration runs beside the tail of the weight gradients)."""
+
+    def __enter__(self):
+        _DEFER_JOIN[0] += 1
+
+    def __exit__(self, *exc):
+        _DEFER_JOIN[0] -= 1
+
+
+def join_side_streams():
+    """The current stream waits for everything issued on the weight-gradient stream (no host synchronisation)."""
+    cur = torch.cuda.current_stream()
+    for idx, side in _SIDE_STREAMS.items():
+        if cur.device.index == idx:
+            cur.wait_stream(side)
+    _SIDE_PENDING.clear()
+    _SIDE_KEEP.clear()
+
+
 def _join_side_streams():
+    if _DEFER_JOIN[0]:
+        return
     for idx, main in list(_SIDE_PENDING.items()):
         main.wait_stream(_SIDE_STREAMS[idx])
     _SIDE_PENDING.clear()
@@ -117,9 +144,10 @@ def _on_side_stream(dev, fn, tensors):
     # nobody else holds it (InputBuffer) - e.g. the gradient this conv hands to its residual - and would overwrite dy on the main
     # stream under the weight-gradient kernel still reading it here.
     _SIDE_KEEP.append((side.record_event(), tensors))
-    if idx not in _SIDE_PENDING:
-        _SIDE_PENDING[idx] = main
-        torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+    # a callback per call (the first to run joins, the rest find nothing pending): a backward pass that died on an exception must
+    # not leave a stale "callback already queued" state behind
+    _SIDE_PENDING[idx] = main
+    torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
 
 
 _GRU_KEEP_ALWAYS = bool(int(__import__("os").environ.get("DGMR_GRU_KEEP_ALWAYS", "0")))  # measurement switch
