@@ -106,9 +106,9 @@ class defer_side_join:
 
 
 def join_side_streams():
-    """The current stream waits for everything issued on the weight-gradient stream (no host synchronisation)."""
+    """The current stream waits for everything issued on the weight-gradient streams (no host synchronisation)."""
     cur = torch.cuda.current_stream()
-    for idx, side in _SIDE_STREAMS.items():
+    for (idx, _lane), side in _SIDE_STREAMS.items():
         if cur.device.index == idx:
             cur.wait_stream(side)
     _SIDE_PENDING.clear()
@@ -118,16 +118,25 @@ def join_side_streams():
 def _join_side_streams():
     if _DEFER_JOIN[0]:
         return
-    for idx, main in list(_SIDE_PENDING.items()):
-        main.wait_stream(_SIDE_STREAMS[idx])
+    for key, main in list(_SIDE_PENDING.items()):
+        main.wait_stream(_SIDE_STREAMS[key])
     _SIDE_PENDING.clear()
     _SIDE_KEEP.clear()  # everything the main stream does from here on is ordered behind the side work
 
 
-def _on_side_stream(dev, fn, tensors):
-    """Run fn() (kernel launches through _stream()) on the device's side stream, ordered after everything issued so far on the current
-    stream; `tensors`: what fn reads that the caller may free right after (kept alive for the side stream's work)."""
+_SIDE_LANES = int(__import__("os").environ.get("DGMR_WGRAD_LANES", "1"))  # more lanes measured no gain (1051-1060 ms for 1, 2, 3)
+_side_rr = [0]
+
+
+def _on_side_stream(dev, fn, tensors, lane=None):
+    """Run fn() (kernel launches through _stream()) on one of the device's side streams, ordered after everything issued so far on
+    the current stream; `tensors`: what fn reads that the caller may free right after (kept alive for the side stream's work).
+    lane: a fixed stream for work that shares a scratch buffer (the pair-sum planes: lane 0); None: round robin."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if lane is None:
+        _side_rr[0] = (_side_rr[0] + 1) % _SIDE_LANES
+        lane = _side_rr[0]
+    idx = (idx, lane)
     main = torch.cuda.current_stream(dev)
     side = _SIDE_STREAMS.get(idx)
     if side is None:
@@ -680,7 +689,7 @@ class ConvFn(Function):
                         call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), None, None, None, None, cout, cin, taps, 1, 1, st)
 
             if _WGRAD_STREAM and ctx.needs_input_grad[0]:
-                _on_side_stream(dev, weight_grad, (x, dy, scale, bn_a, bn_b, sn_u, sn_v))
+                _on_side_stream(dev, weight_grad, (x, dy, scale, bn_a, bn_b, sn_u, sn_v), lane=0 if spec.upsample else None)
             else:
                 weight_grad()
         # ---- input ----
