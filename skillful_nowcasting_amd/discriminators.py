@@ -23,8 +23,22 @@ class Discriminator(torch.nn.Module, PyTorchModelHubMixin):
         if x.shape[0] % calls:
             raise RuntimeError(f"discriminator: batch {x.shape[0]} is not divisible into {calls} calls")
         with SNScope(self, (tuple(x.shape), calls)):  # all spectral-norm iterations of both discriminators up front
-            spatial_loss = self.spatial_discriminator(x, calls=calls)
-            temporal_loss = self.temporal_discriminator(x, calls=calls)
+            aux = ops.branch_stream(x.device) if x.is_cuda else None
+            if aux is None:
+                spatial_loss = self.spatial_discriminator(x, calls=calls)
+                temporal_loss = self.temporal_discriminator(x, calls=calls)
+            else:
+                # the two discriminators share nothing but x: the temporal one runs on a second stream beside the spatial one (its
+                # deep layers are small, latency-bound launches; autograd runs its backward there too).  The spatial discriminator
+                # draws its random frames on the host in the reference's order either way.
+                main = torch.cuda.current_stream(x.device)
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    temporal_loss = self.temporal_discriminator(x, calls=calls)
+                x.record_stream(aux)
+                spatial_loss = self.spatial_discriminator(x, calls=calls)
+                main.wait_stream(aux)
+                temporal_loss.record_stream(main)
         return torch.cat([spatial_loss, temporal_loss], dim=1)
 
 
