@@ -206,6 +206,16 @@ def main():
         model.training_step(batch, i)
     dt, step_ms = time_steps(model, batch, args.warmup, args.steps, barrier)
     step_host = list(time_steps.host)
+    # data parallel: every rank must hold bit-identical parameters after the timed steps (same all-reduced gradients, same Adam)
+    replicas_in_sync = None
+    if world > 1:
+        cs = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        if backend != "nccl":
+            lo, hi = lo.cpu(), hi.cpu()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_in_sync = bool((lo == hi).all().item())
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -309,6 +319,8 @@ def main():
                                     "strict: every observable effect of the reference step (losses, both Adam updates, u/v / BN / RNG "
                                     "state incl. checkpoint-recompute and logging forwards); never-read gradients are not computed"},
         }
+        if replicas_in_sync is not None:
+            out["replicas_in_sync"] = replicas_in_sync  # parameter checksums agree bit for bit across the ranks after the timed steps
         if roofline:
             out["roofline"] = roofline
         if also:
