@@ -43,6 +43,11 @@ SHAPES = [
     ("gru4.h-step B4", 4, 1, 64, 64, 48, 48, (1, 3, 3), False, False),
     ("gru3.h-step B16", 16, 1, 32, 32, 96, 96, (1, 3, 3), False, False),
     ("gru2.x-part T18B4", 72, 1, 16, 16, 384, 192, (1, 3, 3), False, False),
+    # pointwise convs of the sampler at the full draw batch (HBM-bound)
+    ("pw gru_1x1_4 full", 1728, 1, 64, 64, 48, 96, (1, 1, 1), False, False),
+    ("pw gru_1x1_3 full", 1728, 1, 32, 32, 96, 192, (1, 1, 1), False, False),
+    ("pw up_g4.conv_1x1 full", 1728, 1, 64, 64, 96, 48, (1, 1, 1), False, False),
+    ("pw up_g3.conv_1x1 full", 1728, 1, 32, 32, 192, 96, (1, 1, 1), False, False),
     # recurrent step convs with the six draws batched (96 samples per step)
     ("gru4.h-step B96", 96, 1, 64, 64, 48, 48, (1, 3, 3), False, False),
     ("gru3.h-step B96", 96, 1, 32, 32, 96, 96, (1, 3, 3), False, False),
