@@ -288,6 +288,7 @@ const char* const kVariantNames[V_COUNT] = {
 int g_precision = 0;
 // dgmr_conv_tune(): -1 = automatic
 int g_tune_variant = -1, g_tune_ksplit = -1, g_tune_window = -1, g_tune_wgrad_window = -1;
+bool g_m16_auto = true;  // 16-column blocks for <= 48 output channels: measured +14 ... +28 % on the 48-channel layers (tune window 3 = the 64-column tile)
 
 // WM x WN: wave grid of the f32 kernel; WMB x WNB: of the bf16 kernels (two register stages: 128x128 needs 8 waves to fit)
 template <int BM, int BN, int WM, int WN, int WMB = WM, int WNB = WN>
@@ -593,6 +594,9 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     w->tw_shift = small8 ? 3 : (p.W == 16 ? 4 : 5);
     w->g_shift = small8 ? 1 : 0;
     w->bnw = C % 128 == 0 ? 128 : (C % 96 == 0 ? 96 : (C <= 64 ? 64 : 128));
+    // <= 48 output channels in 16-column blocks (v_mfma_f32_16x16x32): three blocks instead of two 32-column ones, a quarter less
+    // matrix work (LDS-DMA kernel, 128-pixel tiles)
+    if (glds_ok && C <= 48 && C % 16 == 0 && (g_tune_window == 5 || (g_tune_window < 0 && g_m16_auto))) w->bnw = 48;
     // few pixels, many channels (the ConvGRU steps on 8x8 / 16x16 maps: 6144 pixels x 384 channels): 128-column tiles would leave
     // half the CUs without a workgroup - 64-column tiles double the grid (measured 146 -> see profiles/README.md, us per step conv)
     if (g_tune_window < 0 && C % 64 == 0 && (M64 / 128) * ((C + w->bnw - 1) / w->bnw) * (p.reserved0 ? 4 : 1) < 256) w->bnw = 64;
@@ -602,7 +606,7 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     // 96- / 64-channel layers of the sampler at T x B maps (gpurun r2o), -10 ... -20 % on launches of a few hundred workgroups:
     // automatic only when the 256-pixel tiles still fill the chip four times over
     const int64_t big_wgs = (M64 / 256) * ((C + w->bnw - 1) / w->bnw) * (p.reserved0 ? 4 : 1);
-    w->big = !small8 && w->bnw != 128 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 &&
+    w->big = !small8 && w->bnw != 128 && w->bnw != 48 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 &&
              (g_tune_window == 2 || (g_tune_window < 0 && big_wgs >= 2048));
     w->glds = glds_ok || w->big;
     const int TWv = 1 << w->tw_shift, THv = ((w->big ? 256 : 128) >> w->tw_shift) >> w->g_shift;
@@ -766,7 +770,13 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         else                                                                                                                                \
             hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 1, 128, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
     } while (0)
-                if (bnw == 128 && g_tune_window == 4) DGMR_GLDS_PRIV(128, 1, 4);
+                if (bnw == 48) {
+                    if (g_precision == 1)
+                        hipLaunchKernelGGL((conv3x3_glds_kernel<48, 4, 1, 3, 128, false, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
+                    else
+                        hipLaunchKernelGGL((conv3x3_glds_kernel<48, 4, 1, 1, 128, false, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
+                }
+                else if (bnw == 128 && g_tune_window == 4) DGMR_GLDS_PRIV(128, 1, 4);
                 else if (bnw == 64 && g_tune_window == 4) DGMR_GLDS_PRIV(64, 2, 2);
                 else if (bnw == 128) DGMR_GLDS(128, 2, 2);
                 else if (bnw == 96) DGMR_GLDS(96, 4, 1);
@@ -1103,7 +1113,7 @@ extern "C" int dgmr_set_precision(int mode) {
 extern "C" int dgmr_get_precision(void) { return g_precision; }
 
 extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window) {
-    DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 4 && wgrad_window >= -1 &&
+    DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 5 && wgrad_window >= -1 &&
                        wgrad_window <= 1,
                    "dgmr_conv_tune: variant %d ksplit %d window %d wgrad_window %d", variant, ksplit, window, wgrad_window);
     g_tune_variant = variant;

@@ -38,11 +38,23 @@ __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" 
 // BM: output pixels per workgroup.  256 (8 x 32 or 16 x 16 pixels of one image) gives every wave twice the pixels per weight
 // fragment: (TM + TN) * planes LDS reads feed TM * TN * terms MFMAs, half the barriers per MFMA, a 1.33x instead of 1.59x halo - at
 // two workgroups per CU instead of three (68 KB of LDS, ~170 registers).
+template <bool M16, typename ACC>
+__device__ __forceinline__ ACC mfma_blk(const bf16x8_t& a, const bf16x8_t& b, const ACC& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (M16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
+    return c;
+#endif
+}
+
 // PRIV: every wave streams ITS OWN 32 x TN output-channel slice of the weights into a private double buffer and nothing but the
 // activation halo is shared: no barrier between taps (one pair per 32-channel chunk, when the halo is replaced), the waves of a
 // workgroup drift apart and the SIMDs interleave them freely - the per-tap barrier made every workgroup wait for its slowest SIMD
 // nine times per chunk (PMC: 37 % of the wave cycles parked, matrix pipe 50 % busy).
-template <int BN, int WM, int WN, int NS, int BM = 128, bool PRIV = false>
+// M16: the wave's tile is made of 16 x 16 blocks (v_mfma_f32_16x16x32_bf16: one instruction per 32-channel chunk and block) instead
+// of 32 x 32 ones: 48 output channels are three blocks - the 64-column tile spent a quarter of its matrix work on padding.
+template <int BN, int WM, int WN, int NS, int BM = 128, bool PRIV = false, bool M16 = false>
 __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift,
                                                                                           const int tiles_w, const int tiles_hw,
                                                                                           const int g_shift) {
@@ -52,7 +64,11 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
     constexpr int ROW = CK / 2;  // dwords per LDS row
     constexpr int NP = NS == 3 ? 2 : 1;
     constexpr bool SPLIT = NS == 3;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int MB = M16 ? 16 : 32;   // edge of an MFMA block
+    constexpr int RPB = M16 ? 4 : 16;   // accumulator registers per block
+    constexpr int TM = BM / WM / MB, TN = BN / WN / MB;
+    static_assert(!M16 || (!PRIV && BN % 16 == 0 && BM == 128), "M16 tile");
+    typedef float accv_t __attribute__((ext_vector_type(RPB)));
     constexpr int AMAX = BM == 256 ? 10 * 34 : 6 * 34;  // halo pixels: 6 x 34 / 10 x 18 (BM 128), 10 x 34 / 18 x 18 (BM 256)
     constexpr int APASS = (AMAX * 8 + 255) / 256;
     constexpr int BUNITS = BN * 4 * NP;  // 16-byte units of one weight stage
@@ -192,19 +208,19 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
         }
     };
 
-    f32x16 acc[TM][TN];
+    accv_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < RPB; ++r) acc[i][j][r] = 0.f;
 
     // halo pixel of this lane under each filter row / column: pix = rowpix[dy] + colpix[dx] (the taps are unrolled below)
     int rowpix[TM][3], colpix[TM][3];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int q = wm * TM * 32 + i * 32 + (lane & 31);
+        const int q = wm * TM * MB + i * MB + (lane & (MB - 1));
         const int prow = (q >> tw_shift) & (TH - 1), pcol = q & (TW - 1), pbase = (q >> sub_shift) * HP;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -212,9 +228,9 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
             colpix[i][d] = ((w0 + pcol + d + px - 1) >> us) - ow;                  //  there d = 0, 1 are its two taps per axis)
         }
     }
-    const int kg = lane >> 5;
-    const int bsw = (lane >> 2) & 3;  // swizzle of this lane's weight rows (row = 32 j + (lane & 31))
-    const uint32_t* Bb0 = PRIV ? Bs + wid * WSLICE + (lane & 31) * ROW : Bs + (wn * TN * 32 + (lane & 31)) * ROW;
+    const int kg = M16 ? lane >> 4 : lane >> 5;  // this lane's 16-byte k-slot inside a 16-channel step (M16: inside the 32-channel chunk)
+    const int bsw = (lane >> 2) & 3;  // swizzle of this lane's weight rows (row = MB j + (lane & (MB - 1)))
+    const uint32_t* Bb0 = PRIV ? Bs + wid * WSLICE + (lane & 31) * ROW : Bs + (wn * TN * MB + (lane & (MB - 1))) * ROW;
     constexpr int BPLANE = PRIV ? TN * 32 : BN;  // rows between the hi and the lo plane of a stage
     // half: the chunk holds <= 16 real channels (Cin = 48, 144: the last chunk) - its second 16-channel step is all zeros, skipped
     const bool tail16 = (p.Cin & (CK - 1)) != 0 && (p.Cin & (CK - 1)) <= 16;
@@ -229,9 +245,9 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
         }
         const uint32_t* Bb = Bb0 + stage * BSTAGE;
 #pragma unroll
-        for (int kk = 0; kk < CK / 16; ++kk) {
+        for (int kk = 0; kk < (M16 ? 1 : CK / 16); ++kk) {
             if (kk == 1 && half) break;  // (wave-uniform)
-            const int ks = kk * 2 + kg;  // logical 16-byte k-slot of this lane's fragment
+            const int ks = M16 ? kg : kk * 2 + kg;  // logical 16-byte k-slot of this lane's fragment
             bf16x8_t ah[TM], bh[TN], al[TM], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -242,24 +258,24 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
             const int ob = (ks ^ bsw) << 2;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + j * 32 * ROW + ob));
-                if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BPLANE + j * 32) * ROW + ob));
+                bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + j * MB * ROW + ob));
+                if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BPLANE + j * MB) * ROW + ob));
             }
             __builtin_amdgcn_s_setprio(1);
             if (SPLIT) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma_blk<M16>(al[i], bh[j], acc[i][j]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma_blk<M16>(ah[i], bl[j], acc[i][j]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_blk<M16>(ah[i], bh[j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
         }
     };
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
     int colj[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        colj[j] = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        colj[j] = n0 + wn * TN * MB + j * MB + (lane & (MB - 1));
         bj[j] = (p.bias && colj[j] < p.Cout) ? p.bias[colj[j]] : 0.f;
     }
     float maj[TN], mbj[TN];  // affine of the BatchNorm whose relu is being back-propagated through (data gradient), per column
@@ -370,8 +386,10 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        for (int r = 0; r < RPB; ++r) {
+            // accumulator register r of this lane: block row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) [32 x 32] / 4 (lane >> 4) + r [16 x 16]
+            const int q = M16 ? wm * TM * 16 + i * 16 + 4 * (lane >> 4) + r
+                              : wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int ni = n + (q >> sub_shift);
             const int hh = ((h0 + ((q >> tw_shift) & (TH - 1))) << pshift) + py, ww = ((w0 + (q & (TW - 1))) << pshift) + px;
             const size_t mrow = (size_t)((ni * oH + hh) * oW + ww) * p.Cout;
@@ -439,8 +457,12 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
         for (int j = 0; j < TN; ++j) {
             st0[j] += __shfl_xor(st0[j], 32, 64);
             st1[j] += __shfl_xor(st1[j], 32, 64);
-            if (lane < 32) {
-                const int cl = wn * TN * 32 + j * 32 + lane;
+            if (M16) {  // four lane groups hold the same column
+                st0[j] += __shfl_xor(st0[j], 16, 64);
+                st1[j] += __shfl_xor(st1[j], 16, 64);
+            }
+            if (lane < MB) {
+                const int cl = wn * TN * MB + j * MB + lane;
                 red[(wm * BN + cl) * 2 + 0] = st0[j];
                 red[(wm * BN + cl) * 2 + 1] = st1[j];
             }

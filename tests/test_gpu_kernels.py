@@ -36,6 +36,9 @@ CONV_CASES = [
     (2, 32, 32, 40, 96, False, False, False),
     (2, 32, 32, 24, 200, True, True, True),
     (2, 64, 64, 96, 128, False, False, False),
+    (3, 32, 32, 96, 48, False, True, True),      # 48 output channels: three 16-column blocks in mode 5
+    (2, 64, 32, 72, 32, True, False, True),      # 32 output channels, upsample-on-load, ragged chunk
+    (6, 16, 16, 48, 16, False, True, False),     # one 16-column block
 ]
 
 
@@ -58,7 +61,8 @@ def test_window_conv_variants_agree(tuned, n, h, w, cin, cout, up, bn, res):
     ys = {}
     # register-staged window, LDS-DMA window, the same with private per-wave weight slices (no barrier between taps; 128- and
     # 64-column tiles), with 256-pixel tiles (where eligible), implicit GEMM
-    for mode in (1, 3, 4, 2, 0):
+    # 5: 16 x 16 MFMA blocks for <= 48 output channels (another block shape, i.e. another fp32 summation order: compared to 1e-6)
+    for mode in (1, 3, 4, 2, 5, 0):
         tuned(-1, -1, mode, -1)
         y = torch.full((n * h * w * cout,), float("nan"), device=DEV)
         ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, 1, h, w, cin, cout, 1, 3, 3, upsample=up, pre_a=a if bn else None,
@@ -71,6 +75,9 @@ def test_window_conv_variants_agree(tuned, n, h, w, cin, cout, up, bn, res):
     assert torch.equal(ys[4], ys[3]), f"private-slice window kernel differs: max {float((ys[4] - ys[3]).abs().max()):.3e}"
     tol = 2e-6 * float(ys[0].abs().max())
     assert float((ys[3] - ys[0]).abs().max()) <= tol
+    assert not torch.isnan(ys[5]).any()
+    assert float((ys[5] - ys[0]).abs().max()) <= tol, f"16-column-block kernel: {float((ys[5] - ys[0]).abs().max()):.3e} vs {tol:.3e}"
+    assert float((ys[5] - ys[3]).abs().max()) <= 0.5 * tol
 
 
 # n, h, w (output), cin, cout, batchnorm-on-load, residual
