@@ -606,7 +606,7 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     // 96- / 64-channel layers of the sampler at T x B maps (gpurun r2o), -10 ... -20 % on launches of a few hundred workgroups:
     // automatic only when the 256-pixel tiles still fill the chip four times over
     const int64_t big_wgs = (M64 / 256) * ((C + w->bnw - 1) / w->bnw) * (p.reserved0 ? 4 : 1);
-    w->big = !small8 && w->bnw != 128 && w->bnw != 48 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 &&
+    w->big = !small8 && w->bnw != 128 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 &&
              (g_tune_window == 2 || (g_tune_window < 0 && big_wgs >= 2048));
     w->glds = glds_ok || w->big;
     const int TWv = 1 << w->tw_shift, THv = ((w->big ? 256 : 128) >> w->tw_shift) >> w->g_shift;
@@ -752,6 +752,12 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
             hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 1, 256>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
     } while (0)
                 if (bnw == 96) DGMR_GLDS_BIG(96, 4, 1);
+                else if (bnw == 48) {
+                    if (g_precision == 1)
+                        hipLaunchKernelGGL((conv3x3_glds_kernel<48, 4, 1, 3, 256, false, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
+                    else
+                        hipLaunchKernelGGL((conv3x3_glds_kernel<48, 4, 1, 1, 256, false, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
+                }
                 else DGMR_GLDS_BIG(64, 4, 1);
 #undef DGMR_GLDS_BIG
             }

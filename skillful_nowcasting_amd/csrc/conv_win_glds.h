@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
     constexpr int MB = M16 ? 16 : 32;   // edge of an MFMA block
     constexpr int RPB = M16 ? 4 : 16;   // accumulator registers per block
     constexpr int TM = BM / WM / MB, TN = BN / WN / MB;
-    static_assert(!M16 || (!PRIV && BN % 16 == 0 && BM == 128), "M16 tile");
+    static_assert(!M16 || (!PRIV && BN % 16 == 0), "M16 tile");
     typedef float accv_t __attribute__((ext_vector_type(RPB)));
     constexpr int AMAX = BM == 256 ? 10 * 34 : 6 * 34;  // halo pixels: 6 x 34 / 10 x 18 (BM 128), 10 x 34 / 18 x 18 (BM 256)
     constexpr int APASS = (AMAX * 8 + 255) / 256;
