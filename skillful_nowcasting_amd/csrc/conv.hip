@@ -466,8 +466,10 @@ __global__ void flip_weights_kernel(const float* __restrict__ w, float* __restri
 constexpr int WG_MAX_GROUPS = 128;
 // Partial element i = (co, tap, ci) of a [Cout][taps][cs] slab lands at j = (co*taps + tap)*ct + coff + ci of g / w
 // (cs == ct, coff == 0: j == i).
+// (two workgroups per CU = 256 registers per lane: the MAXG running dot products plus the 16-byte lanes spilled 636 bytes per lane
+//  under the compiler's own occupancy target of four)
 template <int MAXG, bool VEC4 = true>
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int groups, size_t numel,
+__global__ __launch_bounds__(256, 2) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int groups, size_t numel,
                                     const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ g,
                                     float* __restrict__ dot, int taps, int cs, int ct, int coff) {
     __shared__ float red[MAXG][4];
