@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGMR_ABI_VERSION 7
+#define DGMR_ABI_VERSION 8
 
 int dgmr_abi_version(void);
 const char* dgmr_last_error(void);
@@ -80,8 +80,9 @@ typedef struct dgmr_conv_args {
     float* splitk_ws;      /* NULL, or scratch for split-K partial sums */
     int64_t splitk_ws_bytes;
     const uint16_t* w_split; /* NULL, or the SAME weights (of the slice, if w_cin/w_coff select one) pre-split into dense bf16
-                                planes [2][Cout][KH*KW][Cin] by dgmr_split_weights: lets the bf16 modes run 3x3 convs of the big
-                                feature maps through the LDS-window kernel */
+                                planes [P][Cout][KH*KW][Cin] by dgmr_split_weights (P = 2 in the modes bf16x3 / bf16, 3 in bf16x6 - the
+                                library reads as many planes as the mode set when the launch is issued): lets the bf16 modes run 3x3
+                                convs of the big feature maps through the LDS-window kernel */
     int32_t residual_up;     /* 1: residual is [N][H/2][W/2][Cout], added with nearest-2x upsampling (the 1x1 shortcut of an upsampling
                                 G-block evaluated before the upsample: conv1x1(up(x)) == up(conv1x1(x)), common.py:142-143,154) */
     int32_t reserved0;       /* must be 0 (library-internal) */
@@ -148,18 +149,26 @@ int dgmr_conv_stats_rows(const dgmr_conv_args* a);
 #define DGMR_EPI_GRU_GATE 1  /* pre_out = v ; y = sigmoid(v) * gru_h                              (ConvGRU.py:69-71,78) */
 #define DGMR_EPI_GRU_BLEND 2 /* pre_out = v ; y = s*gru_h + (1-s)*relu(v), s = sigmoid(gru_pu)     (ConvGRU.py:80-84) */
 
-/* out[0][i] = bf16(w_i), out[1][i] = bf16(w_i - out[0][i]) for the [rows][Cin] slice [w_coff, w_coff+Cin) of a [rows][w_cin]
- * weight matrix (rows = Cout * taps; w_cin == 0: dense).  Cin must be even.  Valid until the weights change. */
-int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, int w_cin, int w_coff, void* stream);
+/* out[k][i] = bf16(w_i - out[0][i] - ... - out[k-1][i]), k < planes, for the [rows][Cin] slice [w_coff, w_coff+Cin) of a
+ * [rows][w_cin] weight matrix (rows = Cout * taps; w_cin == 0: dense).  Cin must be even.  planes: 2 for DGMR_PREC_BF16X3 /
+ * DGMR_PREC_BF16, 3 for DGMR_PREC_BF16X6 (three bf16 hold all 24 mantissa bits: the planes sum to w exactly).  Valid until the
+ * weights change.  (ABI 8: `planes` added.) */
+int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, int w_cin, int w_coff, int planes, void* stream);
 
 /* Arithmetic of the forward / data-gradient contraction (process-wide; tensors in HBM stay fp32, accumulation is fp32):
  *   DGMR_PREC_F32     exact fp32 on v_mfma_f32_32x32x2_f32 (157 TF peak) -- the parity mode
- *   DGMR_PREC_BF16X3  each operand split into two bf16 terms, 3 x v_mfma_f32_32x32x16_bf16 per product: ~2^-16 relative error
- *                     per product (fp32-class), 833 TF effective peak
- *   DGMR_PREC_BF16    operands rounded to bf16 (BASELINE.json configs[1]): 2.5 PF peak, ~3 significant digits */
+ *   DGMR_PREC_BF16X3  each operand split into two bf16 terms, 3 x v_mfma_f32_32x32x16_bf16 per product: products carry 16
+ *                     significant bits (~2^-16 relative error per product - NOT fp32 arithmetic), 833 TF effective peak
+ *   DGMR_PREC_BF16    operands rounded to bf16 (BASELINE.json configs[1]): 2.5 PF peak, ~3 significant digits
+ *   DGMR_PREC_BF16X6  (ABI 8) three bf16 terms per operand (exact: 3 x 8 bits = the fp32 mantissa), the six products a_i * b_j with
+ *                     i + j <= 2 on six MFMAs: the dropped terms are <= 2^-25 |ab|, below the rounding of an fp32 product -
+ *                     fp32-faithful contractions at 417 TF effective peak (2.6 x the exact-f32 MFMA's)
+ * A caller may switch the mode between launches (it is read when a launch is issued): the module layer runs the discriminator
+ * forward in BF16X6 inside a BF16X3 step (skillful_nowcasting_amd.ops.set_precision). */
 #define DGMR_PREC_F32 0
 #define DGMR_PREC_BF16X3 1
 #define DGMR_PREC_BF16 2
+#define DGMR_PREC_BF16X6 3
 int dgmr_set_precision(int mode);
 int dgmr_get_precision(void);
 

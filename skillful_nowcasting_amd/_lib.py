@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdgmr_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 P = c_void_p  # every device pointer and the stream travel as void*
 
@@ -112,7 +112,7 @@ SIGNATURES = {
     "dgmr_head_bwd_sums": [P, P, P, P, P, P, P, P, P, L, L, i, P],
     "dgmr_head_bwd_apply": [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, i, i, P],
     "dgmr_conv_pool2_supported": [POINTER(ConvArgs)],
-    "dgmr_split_weights": [P, P, L, i, i, i, P],
+    "dgmr_split_weights": [P, P, L, i, i, i, i, P],
     "dgmr_set_precision": [i],
     "dgmr_get_precision": [],
     "dgmr_profile_enable": [i],

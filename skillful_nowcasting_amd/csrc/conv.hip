@@ -14,10 +14,9 @@
 #include <mutex>
 #include <vector>
 
-#include "conv_bf16.h"
-#include "wgrad_win.h"
-#include "conv_win_glds.h"
+#include "conv_bf16.h"  // split_weights_kernel (the bf16 MFMA kernels themselves are instantiated in tu_*.hip, see conv_launch.h)
 #include "conv_device.h"
+#include "conv_launch.h"
 
 namespace {
 
@@ -278,20 +277,23 @@ struct ProfScope {
     }
 };
 
-enum { V_F128x128 = 0, V_F64x64, V_F128x96, V_F128x64, V_F128x32, V_W128, V_W64, V_W32, V_WIN128, V_WIN96, V_WIN64, V_COUNT };
 const char* const kVariantNames[V_COUNT] = {
     "conv_fwd_dgrad<128,128>", "conv_fwd_dgrad<64,64>", "conv_fwd_dgrad<128,96>", "conv_fwd_dgrad<128,64>",
     "conv_fwd_dgrad<128,32>",  "conv_wgrad<128|96,128>", "conv_wgrad<64,128>", "conv_wgrad<32,128>",
     "conv_fwd_dgrad_win3x3<128px,128>", "conv_fwd_dgrad_win3x3<128px,96>", "conv_fwd_dgrad_win3x3<128px,64>"};
 
-// 0: exact fp32 (v_mfma_f32_32x32x2_f32)   1: bf16x3 split (fp32-class accuracy on the bf16 matrix cores)   2: plain bf16
+// 0: exact fp32 (v_mfma_f32_32x32x2_f32)   1: bf16x3 (two bf16 planes per operand, three MFMAs per product: 16-bit products)
+// 2: plain bf16   3: bf16x6 (three planes, six MFMAs: products as accurate as an fp32 product's own rounding)
 int g_precision = 0;
+
+#define DGMR_BY_NS(fn, ...) \
+    (g_precision == 1 ? dgmr_tu::fn##_ns3(__VA_ARGS__) : (g_precision == 2 ? dgmr_tu::fn##_ns1(__VA_ARGS__) : dgmr_tu::fn##_ns6(__VA_ARGS__)))
 // dgmr_conv_tune(): -1 = automatic
 int g_tune_variant = -1, g_tune_ksplit = -1, g_tune_window = -1, g_tune_wgrad_window = -1;
 bool g_m16_auto = true;  // 16-column blocks for <= 48 output channels: measured +14 ... +28 % on the 48-channel layers (tune window 3 = the 64-column tile)
 
-// WM x WN: wave grid of the f32 kernel; WMB x WNB: of the bf16 kernels (two register stages: 128x128 needs 8 waves to fit)
-template <int BM, int BN, int WM, int WN, int WMB = WM, int WNB = WN>
+// WM x WN: wave grid of the f32 kernel (the bf16 kernels of the same tile: tu_gemm.hip)
+template <int VARIANT, int BM, int BN, int WM, int WN>
 int launch_conv(const dgmr_conv_args& a, int M, int Ktot, hipStream_t s) {
     const int BK = 32;
     const int nk = (Ktot + BK - 1) / BK;
@@ -299,10 +301,8 @@ int launch_conv(const dgmr_conv_args& a, int M, int Ktot, hipStream_t s) {
     const int per = (nk + S - 1) / S;
     const int Seff = (nk + per - 1) / per;  // no empty splits
     dim3 grid((M + BM - 1) / BM, (a.Cout + BN - 1) / BN, Seff);
-    if (g_precision == 1)
-        hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, 32, WMB, WNB, 3>), grid, dim3(64 * WMB * WNB), 0, s, a, M, Ktot, per);
-    else if (g_precision == 2)
-        hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, 32, WMB, WNB, 1>), grid, dim3(64 * WMB * WNB), 0, s, a, M, Ktot, per);
+    if (g_precision != 0)
+        DGMR_BY_NS(launch_gemm, VARIANT, a, M, Ktot, per, grid, s);
     else
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32, WM, WN>), grid, dim3(64 * WM * WN), 0, s, a, M, Ktot, per);
     if (Seff > 1) {
@@ -575,10 +575,6 @@ __global__ void zero_n_kernel(float* p, int n) {
 }  // namespace
 
 // Which LDS-window 3x3 kernel (if any) takes a conv, and with which tiling: shared by the launch and by dgmr_conv_stats_rows.
-struct WinPlan {
-    int tw_shift, g_shift, tiles_w, tiles_hw, bnw, grid_x;
-    bool big, glds;  // 256-pixel tiles; LDS-DMA kernel (has the fused output statistics)
-};
 static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     const int64_t M64 = (int64_t)p.N * p.D * p.H * p.W;
     const int C = p.Cout;
@@ -608,7 +604,7 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     // 96- / 64-channel layers of the sampler at T x B maps (gpurun r2o), -10 ... -20 % on launches of a few hundred workgroups:
     // automatic only when the 256-pixel tiles still fill the chip four times over
     const int64_t big_wgs = (M64 / 256) * ((C + w->bnw - 1) / w->bnw) * (p.reserved0 ? 4 : 1);
-    w->big = !small8 && w->bnw != 128 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 &&
+    w->big = !small8 && w->bnw != 128 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 && g_precision != 3 &&  // (bf16x6: 102 KB of LDS)
              (g_tune_window == 2 || (g_tune_window < 0 && big_wgs >= 2048));
     w->glds = glds_ok || w->big;
     const int TWv = 1 << w->tw_shift, THv = ((w->big ? 256 : 128) >> w->tw_shift) >> w->g_shift;
@@ -730,89 +726,11 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     DGMR_CHECK_ARG(!p.stats_out || (window_plan(p, &wp) && wp.glds && p.epi_mode == DGMR_EPI_PLAIN),
                    "dgmr_conv_fwd: stats_out given but the dispatched kernel has no fused statistics (ask dgmr_conv_stats_rows first)");
     if (window_plan(p, &wp)) {
-        {
-            const int tw_shift = wp.tw_shift, g_shift = wp.g_shift, tiles_w = wp.tiles_w, tiles_hw = wp.tiles_hw, bnw = wp.bnw;
-            const bool big = wp.big, glds_ok = wp.glds && !wp.big;
-            const dim3 grid((unsigned)wp.grid_x * (phases ? 4u : 1u), (unsigned)((C + bnw - 1) / bnw));
-            const int v = bnw == 128 ? V_WIN128 : (bnw == 96 ? V_WIN96 : V_WIN64);
-            ProfScope ps(v, flops, s, (phases || p.reserved0 == 2) ? 16.0 / 36.0 : 1.0);
-#define DGMR_WIN(BN_, WM_, WN_)                                                                                              \
-    do {                                                                                                                     \
-        if (g_precision == 1)                                                                                                \
-            hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
-        else                                                                                                                 \
-            hipLaunchKernelGGL((conv3x3_win_kernel<BN_, WM_, WN_, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
-    } while (0)
-            // bf16x3: weight stages by LDS-DMA (conv_win_glds.h; measured +4..17 %
-            // over the register-staged kernel below, bit-identical results)
-            if (big) {
-#define DGMR_GLDS_BIG(BN_, WM_, WN_)                                                                                                  \
-    do {                                                                                                                              \
-        if (g_precision == 1)                                                                                                         \
-            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 3, 256>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 1, 256>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
-    } while (0)
-                if (bnw == 96) DGMR_GLDS_BIG(96, 4, 1);
-                else if (bnw == 48) {
-                    if (g_precision == 1)
-                        hipLaunchKernelGGL((conv3x3_glds_kernel<48, 4, 1, 3, 256, false, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
-                    else
-                        hipLaunchKernelGGL((conv3x3_glds_kernel<48, 4, 1, 1, 256, false, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
-                }
-                else DGMR_GLDS_BIG(64, 4, 1);
-#undef DGMR_GLDS_BIG
-            }
-            else if (glds_ok && !big) {
-#define DGMR_GLDS(BN_, WM_, WN_)                                                                                                      \
-    do {                                                                                                                              \
-        if (g_precision == 1)                                                                                                         \
-            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 3>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 1>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
-    } while (0)
-#define DGMR_GLDS_PRIV(BN_, WM_, WN_)                                                                                                       \
-    do {                                                                                                                                    \
-        if (g_precision == 1)                                                                                                               \
-            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 3, 128, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
-        else                                                                                                                                \
-            hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, 1, 128, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift); \
-    } while (0)
-                if (bnw == 48) {
-                    if (g_precision == 1)
-                        hipLaunchKernelGGL((conv3x3_glds_kernel<48, 4, 1, 3, 128, false, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
-                    else
-                        hipLaunchKernelGGL((conv3x3_glds_kernel<48, 4, 1, 1, 128, false, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
-                }
-                else if (bnw == 128 && g_tune_window == 4) DGMR_GLDS_PRIV(128, 1, 4);
-                else if (bnw == 64 && g_tune_window == 4) DGMR_GLDS_PRIV(64, 2, 2);
-                else if (bnw == 128) DGMR_GLDS(128, 2, 2);
-                else if (bnw == 96) DGMR_GLDS(96, 4, 1);
-                else DGMR_GLDS(64, 4, 1);
-#undef DGMR_GLDS_PRIV
-#undef DGMR_GLDS
-            }
-            else if (bnw == 128) {
-                // bf16x3: one weight stage + halo fetched at the chunk boundary = 53 KB of LDS and <= 168 VGPRs -> three workgroups per CU
-                // (measured 320 -> 350 TF); plain bf16 keeps the two-stage pipeline
-                if (g_precision == 1)
-                    hipLaunchKernelGGL((conv3x3_win_kernel<128, 2, 2, 3, 1, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
-                else DGMR_WIN(128, 2, 2);
-            }
-            else if (bnw == 96) {
-                // bf16x3 at 96 channels: ONE weight stage and the halo fetched at the chunk boundary (48 KB of LDS instead of 63, no
-                // spill at 168 VGPRs) let three workgroups share a CU, which is worth more than the saved barrier (measured
-                // 261 -> 286 TF); plain bf16 already fits three with two stages
-                if (g_precision == 1)
-                    hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 3, 1, true>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
-                else
-                    hipLaunchKernelGGL((conv3x3_win_kernel<96, 4, 1, 1, 2>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift);
-            }
-            else DGMR_WIN(64, 4, 1);
-#undef DGMR_WIN
-            DGMR_CHECK_LAUNCH();
-            return 0;
-        }
+        const int v = wp.bnw == 128 ? V_WIN128 : (wp.bnw == 96 ? V_WIN96 : V_WIN64);
+        ProfScope ps(v, flops, s, (phases || p.reserved0 == 2) ? 16.0 / 36.0 : 1.0);
+        if (DGMR_BY_NS(launch_window, p, wp, phases, g_tune_window, s) != 0) return -1;
+        DGMR_CHECK_LAUNCH();
+        return 0;
     }
     // Split-K when the output grid cannot fill the 256 CUs (ConvGRU steps, latent stack, deep discriminator layers): the k
     // loop is the only parallelism left.  Needs a workspace; chosen so that grid * ksplit ~ 512 workgroups, >= 4 k-tiles each.
@@ -839,11 +757,11 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     {
         ProfScope ps(variant, flops, s);
         switch (variant) {
-            case V_F128x128: launch_conv<128, 128, 2, 2, 2, 4>(p, M, Ktot, s); break;
-            case V_F64x64: launch_conv<64, 64, 2, 2>(p, M, Ktot, s); break;
-            case V_F128x96: launch_conv<128, 96, 4, 1>(p, M, Ktot, s); break;
-            case V_F128x64: launch_conv<128, 64, 4, 1>(p, M, Ktot, s); break;
-            default: launch_conv<128, 32, 4, 1>(p, M, Ktot, s); break;
+            case V_F128x128: launch_conv<V_F128x128, 128, 128, 2, 2>(p, M, Ktot, s); break;
+            case V_F64x64: launch_conv<V_F64x64, 64, 64, 2, 2>(p, M, Ktot, s); break;
+            case V_F128x96: launch_conv<V_F128x96, 128, 96, 4, 1>(p, M, Ktot, s); break;
+            case V_F128x64: launch_conv<V_F128x64, 128, 64, 4, 1>(p, M, Ktot, s); break;
+            default: launch_conv<V_F128x32, 128, 32, 4, 1>(p, M, Ktot, s); break;
         }
     }
     DGMR_CHECK_LAUNCH();
@@ -938,45 +856,15 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
         const int tiles_per_split = (tiles_per_group + spg - 1) / spg;
         const bool b96 = a->Cout % 96 == 0;
         const dim3 grid((a->Cin + 31) / 32, b96 ? a->Cout / 96 : (a->Cout + 63) / 64, a->nsplit);
-#define DGMR_WGW(BI_, NS_)                                                                                                     \
-    do {                                                                                                                       \
-        if (tw_shift == 5)                                                                                                     \
-            hipLaunchKernelGGL((conv_wgrad_win_kernel<BI_, NS_, 5>), grid, dim3(192), 0, s, p, tiles_w, tiles_hw, tiles_per_split, spg, \
-                               tiles_per_group);                                                                               \
-        else                                                                                                                   \
-            hipLaunchKernelGGL((conv_wgrad_win_kernel<BI_, NS_, 4>), grid, dim3(192), 0, s, p, tiles_w, tiles_hw, tiles_per_split, spg, \
-                               tiles_per_group);                                                                               \
-    } while (0)
-        if (b96) {
-            if (g_precision == 1) DGMR_WGW(96, 3);
-            else DGMR_WGW(96, 1);
-        } else {
-            if (g_precision == 1) DGMR_WGW(64, 3);
-            else DGMR_WGW(64, 1);
-        }
-#undef DGMR_WGW
+        DGMR_BY_NS(launch_wgrad_window, p, grid, tw_shift, tiles_w, tiles_hw, tiles_per_split, spg, tiles_per_group, s);
         DGMR_CHECK_LAUNCH();
         return 0;
     }
     if (g_precision != 0) {
-        const dim3 blk(256);
-        if (a->Cout <= 32) {
-            const dim3 grid(kt, (a->Cout + 31) / 32, a->nsplit);
-            if (g_precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<32, 1, 4, 3>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
-            else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<32, 1, 4, 1>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
-        } else if (a->Cout <= 64) {
-            const dim3 grid(kt, (a->Cout + 63) / 64, a->nsplit);
-            if (g_precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<64, 2, 2, 3>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
-            else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<64, 2, 2, 1>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
-        } else if (a->Cout % 96 == 0 && a->Cout % 128 != 0) {  // 96 / 192 / 288 output channels: no idle MFMA rows
-            const dim3 grid(kt, a->Cout / 96, a->nsplit);
-            if (g_precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<96, 1, 4, 3>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
-            else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<96, 1, 4, 1>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
-        } else {
-            const dim3 grid(kt, (a->Cout + 127) / 128, a->nsplit);
-            if (g_precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<128, 2, 2, 3>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
-            else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<128, 2, 2, 1>), grid, blk, 0, s, p, M, Ktot, rows, spg, rows_per_group);
-        }
+        // output-channel tile: 32 / 64 / 96 (96, 192, 288 channels: no idle MFMA rows) / 128
+        const int bi = a->Cout <= 32 ? 32 : (a->Cout <= 64 ? 64 : ((a->Cout % 96 == 0 && a->Cout % 128 != 0) ? 96 : 128));
+        const dim3 grid(kt, (a->Cout + bi - 1) / bi, a->nsplit);
+        DGMR_BY_NS(launch_wgrad_gemm, p, bi, grid, M, Ktot, rows, spg, rows_per_group, s);
     } else if (a->Cout <= 32) {
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), dim3(kt, (a->Cout + 31) / 32, a->nsplit), dim3(256), 0, s, p, M,
                            Ktot, rows, spg, rows_per_group);
@@ -1099,8 +987,9 @@ extern "C" int dgmr_upsample_phase_weights(const float* w, float* out, int Cout,
     return 0;
 }
 
-extern "C" int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, int w_cin, int w_coff, void* stream) {
+extern "C" int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, int w_cin, int w_coff, int planes, void* stream) {
     DGMR_CHECK_ARG(w && out && rows > 0 && Cin > 0 && Cin % 2 == 0, "dgmr_split_weights: bad args (Cin=%d must be even)", Cin);
+    DGMR_CHECK_ARG(planes >= 1 && planes <= 3, "dgmr_split_weights: planes=%d (1 .. 3)", planes);
     if (w_cin == 0) {
         w_cin = Cin;
         w_coff = 0;
@@ -1108,13 +997,13 @@ extern "C" int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, i
     DGMR_CHECK_ARG(w_coff >= 0 && w_coff + Cin <= w_cin, "dgmr_split_weights: bad slice");
     const int64_t total = rows * Cin;
     const int blocks = (int)std::min<int64_t>((total / 2 + 255) / 256, 2048);
-    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, total, Cin, w_cin, w_coff);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, total, Cin, w_cin, w_coff, planes);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int dgmr_set_precision(int mode) {
-    DGMR_CHECK_ARG(mode >= 0 && mode <= 2, "dgmr_set_precision: mode %d (0 f32, 1 bf16x3, 2 bf16)", mode);
+    DGMR_CHECK_ARG(mode >= 0 && mode <= 3, "dgmr_set_precision: mode %d (0 f32, 1 bf16x3, 2 bf16, 3 bf16x6)", mode);
     g_precision = mode;
     return 0;
 }

@@ -5,11 +5,16 @@
 //            formed as a*b + a*b' + a'*b on three MFMAs: products carry ~16 mantissa bits (error ~2^-16 |ab|, far inside the
 //            1e-3 parity bound; per-block tests hold 1e-4), at an effective 2.5 PF / 3 = 833 TF ceiling instead of 157 TF.
 //   NS == 1  plain bf16 operands (BASELINE.json configs[1]): 2.5 PF ceiling, ~3 significant digits.
+//   NS == 6  "bf16x6": three planes a = a0 + a1 + a2 (exact: 3 x 8 significant bits hold an fp32 mantissa) and the six products
+//            a_i * b_j with i + j <= 2; the dropped ones (a1 b2, a2 b1, a2 b2) are <= 2^-25 |ab|, i.e. below the rounding of an
+//            fp32 product - fp32-faithful contractions at 2.5 PF / 6 = 417 TF instead of the 157 TF of the exact-f32 MFMA.
 //
 // Same tiling, staging and fused prologue / epilogue as conv_igemm_kernel (conv.hip); what differs is the LDS image: two bf16
 // planes (hi, lo) per operand, rows of BK bf16 padded by 16 bytes so that the 16-byte fragment reads (lane = row, 8 consecutive
 // k) of a 16-lane group land on 16 distinct 16-byte slots of the 256-byte bank row.
 #pragma once
+#include <type_traits>
+
 #include "conv_device.h"
 
 namespace {
@@ -25,19 +30,41 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // round-to-n
     return __builtin_bit_cast(uint32_t, r);
 }
 
-// 4 floats -> 4 bf16 "hi" (2 dwords) and, when SPLIT, the 4 bf16 residuals "lo"
-template <bool SPLIT>
-__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
-    hi[0] = pack_bf16(v[0], v[1]);
-    hi[1] = pack_bf16(v[2], v[3]);
-    if (SPLIT) {
-        const float r0 = v[0] - __uint_as_float(hi[0] << 16);
-        const float r1 = v[1] - __uint_as_float(hi[0] & 0xffff0000u);
-        const float r2 = v[2] - __uint_as_float(hi[1] << 16);
-        const float r3 = v[3] - __uint_as_float(hi[1] & 0xffff0000u);
-        lo[0] = pack_bf16(r0, r1);
-        lo[1] = pack_bf16(r2, r3);
+// bf16 planes per operand of arithmetic mode NS (= MFMAs per product): 1 -> 1, 3 -> 2 (hi, lo), 6 -> 3 (hi, mid, lo)
+template <int NS>
+struct planes_of {
+    static_assert(NS == 1 || NS == 3 || NS == 6, "NS");
+    static constexpr int value = NS == 1 ? 1 : (NS == 3 ? 2 : 3);
+};
+
+// 4 floats -> NP planes of 4 bf16 (2 dwords each): plane k = bf16(v - plane 0 - ... - plane k-1); every residual is exact in fp32
+template <int NP>
+__device__ __forceinline__ void split_planes4(f32x4 v, u32x2 (&pl)[NP]) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        pl[k][0] = pack_bf16(v[0], v[1]);
+        pl[k][1] = pack_bf16(v[2], v[3]);
+        if (k + 1 < NP) {
+            v[0] -= __uint_as_float(pl[k][0] << 16);
+            v[1] -= __uint_as_float(pl[k][0] & 0xffff0000u);
+            v[2] -= __uint_as_float(pl[k][1] << 16);
+            v[3] -= __uint_as_float(pl[k][1] & 0xffff0000u);
+        }
     }
+}
+
+// The products of a split contraction, small terms first: planes (i, j) with i + j = NP - 1, then NP - 2, ... , (0, 0).
+// NP 2: (1,0) (0,1) (0,0) = the three terms of bf16x3;  NP 3: (2,0) (1,1) (0,2) (1,0) (0,1) (0,0) = bf16x6.
+// (compile-time plane indices: the fragments live in register arrays)
+template <int T, int I, typename F>
+__device__ __forceinline__ void product_step(F& f) {
+    f(std::integral_constant<int, I>{}, std::integral_constant<int, T - I>{});
+    if constexpr (I > 0) product_step<T, I - 1>(f);
+    else if constexpr (T > 0) product_step<T - 1, T - 1>(f);
+}
+template <int NP, typename F>
+__device__ __forceinline__ void for_each_product(F&& f) {
+    product_step<NP - 1, NP - 1>(f);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NS>
@@ -49,8 +76,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
     constexpr int AP = BM / RPP, BP = BN / RPP;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDW = BK / 2 + 4;      // row stride in dwords: BK bf16 + 16 bytes of padding
-    constexpr int NP = NS == 3 ? 2 : 1;  // bf16 planes per operand
-    constexpr bool SPLIT = NS == 3;
+    constexpr int NP = planes_of<NS>::value;  // bf16 planes per operand
     static_assert(AP >= 1 && BP >= 1 && TM >= 1 && TN >= 1 && BM % RPP == 0 && BN % RPP == 0, "bad tile");
     static_assert(BK % 16 == 0, "BK must be a multiple of the MFMA k (16)");
 
@@ -168,20 +194,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
             v = ((s.vmask >> i) & 1u) ? v : zero4;
-            u32x2 hi, lo;
-            split4<SPLIT>(v, hi, lo);
+            u32x2 pl[NP];
+            split_planes4<NP>(v, pl);
             uint32_t* dst = As + ((buf * NP) * BM + i * RPP + lrow) * LDW + kq * 2;
-            *reinterpret_cast<u32x2*>(dst) = hi;
-            if (SPLIT) *reinterpret_cast<u32x2*>(dst + BM * LDW) = lo;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * BM * LDW) = pl[q];
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             const f32x4 v = ((s.bmask >> i) & 1u) ? s.b[i] : zero4;
-            u32x2 hi, lo;
-            split4<SPLIT>(v, hi, lo);
+            u32x2 pl[NP];
+            split_planes4<NP>(v, pl);
             uint32_t* dst = Bs + ((buf * NP) * BN + i * RPP + lrow) * LDW + kq * 2;
-            *reinterpret_cast<u32x2*>(dst) = hi;
-            if (SPLIT) *reinterpret_cast<u32x2*>(dst + BN * LDW) = lo;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * BN * LDW) = pl[q];
         }
     };
 
@@ -199,33 +225,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
         const uint32_t* Bb = Bs + ((cur * NP) * BN + wn * TN * 32 + (lane & 31)) * LDW + (lane >> 5) * 4;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8_t ah[TM], bh[TN], al[TM], bl[TN];
+            bf16x8_t af[NP][TM], bf[NP][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab + i * 32 * LDW + kk * 8));
-                if (SPLIT) al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab + (BM + i * 32) * LDW + kk * 8));
-            }
+            for (int q = 0; q < NP; ++q) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDW + kk * 8));
-                if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BN + j * 32) * LDW + kk * 8));
+                for (int i = 0; i < TM; ++i)
+                    af[q][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab + (q * BM + i * 32) * LDW + kk * 8));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[q][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (q * BN + j * 32) * LDW + kk * 8));
             }
             // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); small terms first
             __builtin_amdgcn_s_setprio(1);  // the co-resident workgroup is usually in its load / store phase: matrix pipe first
-            if (SPLIT) {
+            for_each_product<NP>([&](auto qa, auto qb) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][i], bf[qb][j], acc[i][j], 0, 0, 0);
+            });
             __builtin_amdgcn_s_setprio(0);
         }
     };
@@ -305,8 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const dgmr_wgra
                                                                  const int rows_per_group) {
     constexpr int BJ = 128, BR = 32;
     constexpr int LDW = BR / 2 + 4;  // dwords per LDS row: 32 bf16 pixels + 16 bytes of padding
-    constexpr int NP = NS == 3 ? 2 : 1;
-    constexpr bool SPLIT = NS == 3;
+    constexpr int NP = planes_of<NS>::value;
     constexpr int TM = BI / WI / 32, TN = BJ / WJ / 32;
     static_assert(WI * WJ == 4 && TM >= 1 && TN >= 1, "bad tile");
 
@@ -385,17 +401,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const dgmr_wgra
         // transpose: channel c of the 4 pixels -> one 8-byte group of 4 consecutive pixels
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            u32x2 hi, lo;
+            u32x2 pl[NP];
             if (cg * 4 < BI) {
-                split4<SPLIT>((f32x4){ry[0][c], ry[1][c], ry[2][c], ry[3][c]}, hi, lo);
+                split_planes4<NP>((f32x4){ry[0][c], ry[1][c], ry[2][c], ry[3][c]}, pl);
                 uint32_t* dst = Ys + ((buf * NP) * BI + cg * 4 + c) * LDW + mg * 2;
-                *reinterpret_cast<u32x2*>(dst) = hi;
-                if (SPLIT) *reinterpret_cast<u32x2*>(dst + BI * LDW) = lo;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * BI * LDW) = pl[q];
             }
-            split4<SPLIT>((f32x4){rx[0][c], rx[1][c], rx[2][c], rx[3][c]}, hi, lo);
+            split_planes4<NP>((f32x4){rx[0][c], rx[1][c], rx[2][c], rx[3][c]}, pl);
             uint32_t* dst = Xs + ((buf * NP) * BJ + cg * 4 + c) * LDW + mg * 2;
-            *reinterpret_cast<u32x2*>(dst) = hi;
-            if (SPLIT) *reinterpret_cast<u32x2*>(dst + BJ * LDW) = lo;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * BJ * LDW) = pl[q];
         }
     };
 
@@ -420,33 +436,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const dgmr_wgra
         const uint32_t* Xb = Xs + ((cur * NP) * BJ + wj * TN * 32 + (lane & 31)) * LDW + (lane >> 5) * 4;
 #pragma unroll
         for (int kk = 0; kk < BR / 16; ++kk) {
-            bf16x8_t yh[TM], xh[TN], yl[TM], xl[TN];
+            bf16x8_t yf[NP][TM], xf[NP][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                yh[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Yb + i * 32 * LDW + kk * 8));
-                if (SPLIT) yl[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Yb + (BI + i * 32) * LDW + kk * 8));
-            }
+            for (int q = 0; q < NP; ++q) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                xh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Xb + j * 32 * LDW + kk * 8));
-                if (SPLIT) xl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Xb + (BJ + j * 32) * LDW + kk * 8));
+                for (int i = 0; i < TM; ++i)
+                    yf[q][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Yb + (q * BI + i * 32) * LDW + kk * 8));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    xf[q][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Xb + (q * BJ + j * 32) * LDW + kk * 8));
             }
             // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); small terms first
             __builtin_amdgcn_s_setprio(1);  // the co-resident workgroup is usually in its load / store phase: matrix pipe first
-            if (SPLIT) {
+            for_each_product<NP>([&](auto qa, auto qb) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[i], xh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[i], xl[j], acc[i][j], 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[i], xh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[qa][i], xf[qb][j], acc[i][j], 0, 0, 0);
+            });
             __builtin_amdgcn_s_setprio(0);
         }
         if (it + 1 < nr) store(cur ^ 1);
@@ -507,8 +514,7 @@ __global__ __launch_bounds__(256, (NSTAGE == 1 && BM == 128) ? 3 : 2) void conv3
     constexpr int LOG_BM = BM == 256 ? 8 : 7;
     static_assert(BM == 128 || BM == 256, "BM");
     constexpr int LDW = CK / 2 + 4;  // 80-byte rows
-    constexpr int NP = NS == 3 ? 2 : 1;
-    constexpr bool SPLIT = NS == 3;
+    constexpr int NP = planes_of<NS>::value;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AMAX = BM == 256 ? 10 * 34 : 6 * 34;  // halo pixels: 6 x 34 (TW = 32) or 10 x 18 (TW = 16); BM 256: 10 x 34 / 18 x 18
     constexpr int APASS = (AMAX * 8 + 255) / 256;     // 16-byte fp32 items of the halo per thread
@@ -587,12 +593,12 @@ __global__ __launch_bounds__(256, (NSTAGE == 1 && BM == 128) ? 3 : 2) void conv3
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
             v = (a_kok && ((a_valid >> i) & 1u)) ? v : zero4;
-            u32x2 hi, lo;
-            split4<SPLIT>(v, hi, lo);
+            u32x2 pl[NP];
+            split_planes4<NP>(v, pl);
             if (pix < AMAX) {
                 uint32_t* dst = As + pix * LDW + cq * 2;
-                *reinterpret_cast<u32x2*>(dst) = hi;
-                if (SPLIT) *reinterpret_cast<u32x2*>(dst + AMAX * LDW) = lo;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * AMAX * LDW) = pl[q];
             }
         }
     };
@@ -660,33 +666,24 @@ __global__ __launch_bounds__(256, (NSTAGE == 1 && BM == 128) ? 3 : 2) void conv3
         const uint32_t* Bb = Bs + ((stage * NP) * BN + wn * TN * 32 + (lane & 31)) * LDW + (lane >> 5) * 4;
 #pragma unroll
         for (int kk = 0; kk < CK / 16; ++kk) {
-            bf16x8_t ah[TM], bh[TN], al[TM], bl[TN];
+            bf16x8_t af[NP][TM], bf[NP][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab[i] + kk * 8));
-                if (SPLIT) al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab[i] + AMAX * LDW + kk * 8));
-            }
+            for (int q = 0; q < NP; ++q) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDW + kk * 8));
-                if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BN + j * 32) * LDW + kk * 8));
+                for (int i = 0; i < TM; ++i)
+                    af[q][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab[i] + q * AMAX * LDW + kk * 8));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[q][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (q * BN + j * 32) * LDW + kk * 8));
             }
             // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); small terms first
             __builtin_amdgcn_s_setprio(1);  // the co-resident workgroup is usually in its load / store phase: matrix pipe first
-            if (SPLIT) {
+            for_each_product<NP>([&](auto qa, auto qb) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][i], bf[qb][j], acc[i][j], 0, 0, 0);
+            });
             __builtin_amdgcn_s_setprio(0);
         }
     };
@@ -769,18 +766,21 @@ __global__ __launch_bounds__(256, (NSTAGE == 1 && BM == 128) ? 3 : 2) void conv3
     }
 }
 
-// out[plane][i] for plane 0 (bf16(w)) and 1 (bf16(w - plane0)); i runs over (co, tap, ci) of the slice [w_coff, w_coff+Cin)
+// out[plane][i], plane k = bf16(w - plane 0 - ... - plane k-1), `planes` of them (2: bf16x3 / bf16, 3: bf16x6); i runs over
+// (co, tap, ci) of the slice [w_coff, w_coff+Cin)
 __global__ void split_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int64_t total, int Cin, int w_cin,
-                                     int w_coff) {
+                                     int w_coff, int planes) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total / 2; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e = i * 2;  // Cin is even: the pair never straddles a row
         const int64_t row = e / Cin;
         const int ci = (int)(e - row * Cin);
-        const float a = w[row * w_cin + w_coff + ci], b = w[row * w_cin + w_coff + ci + 1];
-        const uint32_t hi = pack_bf16(a, b);
-        const uint32_t lo = pack_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
-        reinterpret_cast<uint32_t*>(out)[i] = hi;
-        reinterpret_cast<uint32_t*>(out + total)[i] = lo;
+        float a = w[row * w_cin + w_coff + ci], b = w[row * w_cin + w_coff + ci + 1];
+        for (int k = 0; k < planes; ++k) {
+            const uint32_t q = pack_bf16(a, b);
+            reinterpret_cast<uint32_t*>(out + (int64_t)k * total)[i] = q;
+            a -= __uint_as_float(q << 16);
+            b -= __uint_as_float(q & 0xffff0000u);
+        }
     }
 }
 

@@ -55,15 +55,14 @@ __device__ __forceinline__ ACC mfma_blk(const bf16x8_t& a, const bf16x8_t& b, co
 // M16: the wave's tile is made of 16 x 16 blocks (v_mfma_f32_16x16x32_bf16: one instruction per 32-channel chunk and block) instead
 // of 32 x 32 ones: 48 output channels are three blocks - the 64-column tile spent a quarter of its matrix work on padding.
 template <int BN, int WM, int WN, int NS, int BM = 128, bool PRIV = false, bool M16 = false>
-__global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift,
+__global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift,
                                                                                           const int tiles_w, const int tiles_hw,
                                                                                           const int g_shift) {
     constexpr int CK = 32;
     constexpr int LOG_BM = BM == 256 ? 8 : 7;
     static_assert(BM == 128 || BM == 256, "BM");
     constexpr int ROW = CK / 2;  // dwords per LDS row
-    constexpr int NP = NS == 3 ? 2 : 1;
-    constexpr bool SPLIT = NS == 3;
+    constexpr int NP = planes_of<NS>::value;
     constexpr int MB = M16 ? 16 : 32;   // edge of an MFMA block
     constexpr int RPB = M16 ? 4 : 16;   // accumulator registers per block
     constexpr int TM = BM / WM / MB, TN = BN / WN / MB;
@@ -168,12 +167,12 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
             v = ((valid >> i) & 1u) ? v : zero4;
-            u32x2 hi, lo;
-            split4<SPLIT>(v, hi, lo);
+            u32x2 pl[NP];
+            split_planes4<NP>(v, pl);
             if (pix < AMAX) {
                 uint32_t* dst = As + pix * ROW + ((((cq >> 1) ^ (pix >> 2)) & 3) << 2) + (cq & 1) * 2;
-                *reinterpret_cast<u32x2*>(dst) = hi;
-                if (SPLIT) *reinterpret_cast<u32x2*>(dst + AMAX * ROW) = lo;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * AMAX * ROW) = pl[q];
             }
         }
     };
@@ -248,34 +247,24 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV) ? 2 : 3) void
         for (int kk = 0; kk < (M16 ? 1 : CK / 16); ++kk) {
             if (kk == 1 && half) break;  // (wave-uniform)
             const int ks = M16 ? kg : kk * 2 + kg;  // logical 16-byte k-slot of this lane's fragment
-            bf16x8_t ah[TM], bh[TN], al[TM], bl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int o = (ks ^ asw[i]) << 2;
-                ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab[i] + o));
-                if (SPLIT) al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab[i] + AMAX * ROW + o));
-            }
+            bf16x8_t af[NP][TM], bf[NP][TN];
             const int ob = (ks ^ bsw) << 2;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + j * MB * ROW + ob));
-                if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (BPLANE + j * MB) * ROW + ob));
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[q][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab[i] + q * AMAX * ROW + ((ks ^ asw[i]) << 2)));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[q][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (q * BPLANE + j * MB) * ROW + ob));
             }
             __builtin_amdgcn_s_setprio(1);
-            if (SPLIT) {
+            for_each_product<NP>([&](auto qa, auto qb) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma_blk<M16>(al[i], bh[j], acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma_blk<M16>(ah[i], bl[j], acc[i][j]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_blk<M16>(ah[i], bh[j], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma_blk<M16>(af[qa][i], bf[qb][j], acc[i][j]);
+            });
             __builtin_amdgcn_s_setprio(0);
         }
     };

@@ -30,8 +30,7 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad
                                                                 const int tiles_per_split, const int splits_per_group,
                                                                 const int tiles_per_group) {
     constexpr int NT = 192, CK = 32;
-    constexpr int NP = NS == 3 ? 2 : 1;
-    constexpr bool SPLIT = NS == 3;
+    constexpr int NP = planes_of<NS>::value;
     // dwords per input channel: 4 halo rows of 48 bf16 slots (TW = 32) or 6 rows of 32 slots (TW = 16), column c at slot 8 + c of
     // its row, + 16 bytes of padding
     constexpr int XLD = 4 * 24 + 4;
@@ -159,11 +158,11 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                u32x2 hi, lo;
-                split4<SPLIT>((f32x4){rx[i][0][c], rx[i][1][c], rx[i][2][c], rx[i][3][c]}, hi, lo);
+                u32x2 pl[NP];
+                split_planes4<NP>((f32x4){rx[i][0][c], rx[i][1][c], rx[i][2][c], rx[i][3][c]}, pl);
                 uint32_t* dst = Xs + (x_ci[i] + c) * XLD + x_r[i] * ROWDW + 2 + 2 * x_g[i];
-                *reinterpret_cast<u32x2*>(dst) = hi;
-                if (SPLIT) *reinterpret_cast<u32x2*>(dst + CK * XLD) = lo;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * CK * XLD) = pl[q];
             }
         }
 #pragma unroll
@@ -176,11 +175,11 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                u32x2 hi, lo;
-                split4<SPLIT>((f32x4){ry[i][0][c], ry[i][1][c], ry[i][2][c], ry[i][3][c]}, hi, lo);
+                u32x2 pl[NP];
+                split_planes4<NP>((f32x4){ry[i][0][c], ry[i][1][c], ry[i][2][c], ry[i][3][c]}, pl);
                 uint32_t* dst = Ys + (y_co[i] + c) * YLD + y_pg[i] * 2;
-                *reinterpret_cast<u32x2*>(dst) = hi;
-                if (SPLIT) *reinterpret_cast<u32x2*>(dst + BI * YLD) = lo;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * BI * YLD) = pl[q];
             }
         }
         __syncthreads();
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad
             const int hrow = ((kk * 16) >> tw_shift) + wid;  // its halo row under the wave's dy
             const uint32_t* xb = Xs + (lane & 31) * XLD + hrow * ROWDW + 4 + (((kk * 16) & (TW - 1)) >> 1) + kg * 4;
             const uint32_t* yb = Ys + (lane & 31) * YLD + kk * 8 + kg * 4;
-            bf16x8_t xh[3], xl[3], yh[CB], yl[CB];
+            bf16x8_t xf[NP][3], yf[NP][CB];
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
                 const u32x4 q = *reinterpret_cast<const u32x4*>(xb + pl * CK * XLD);
@@ -202,36 +201,20 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_win_kernel(const dgmr_wgrad
                                   __builtin_amdgcn_alignbit(q[2], q[1], 16), __builtin_amdgcn_alignbit(q[3], q[2], 16)};
                 const u32x4 p1 = {__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
                                   __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(dr, q[3], 16)};
-                if (pl == 0) {
-                    xh[0] = __builtin_bit_cast(bf16x8_t, m1);
-                    xh[1] = __builtin_bit_cast(bf16x8_t, q);
-                    xh[2] = __builtin_bit_cast(bf16x8_t, p1);
-                } else {
-                    xl[0] = __builtin_bit_cast(bf16x8_t, m1);
-                    xl[1] = __builtin_bit_cast(bf16x8_t, q);
-                    xl[2] = __builtin_bit_cast(bf16x8_t, p1);
-                }
-            }
+                xf[pl][0] = __builtin_bit_cast(bf16x8_t, m1);
+                xf[pl][1] = __builtin_bit_cast(bf16x8_t, q);
+                xf[pl][2] = __builtin_bit_cast(bf16x8_t, p1);
 #pragma unroll
-            for (int c = 0; c < CB; ++c) {
-                yh[c] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(yb + c * 32 * YLD));
-                if (SPLIT) yl[c] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(yb + (BI + c * 32) * YLD));
+                for (int c = 0; c < CB; ++c)
+                    yf[pl][c] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(yb + (pl * BI + c * 32) * YLD));
             }
             __builtin_amdgcn_s_setprio(1);
-            if (SPLIT) {
+            for_each_product<NP>([&](auto qa, auto qb) {
 #pragma unroll
                 for (int c = 0; c < CB; ++c)
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[c], xh[d], acc[c][d], 0, 0, 0);
-#pragma unroll
-                for (int c = 0; c < CB; ++c)
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[c], xl[d], acc[c][d], 0, 0, 0);
-            }
-#pragma unroll
-            for (int c = 0; c < CB; ++c)
-#pragma unroll
-                for (int d = 0; d < 3; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[c], xh[d], acc[c][d], 0, 0, 0);
+                    for (int d = 0; d < 3; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[qa][c], xf[qb][d], acc[c][d], 0, 0, 0);
+            });
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();

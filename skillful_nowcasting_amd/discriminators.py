@@ -22,7 +22,8 @@ class Discriminator(torch.nn.Module, PyTorchModelHubMixin):
         frame draw, spectral-norm sigmas and BatchNorm1d batch statistics, all advanced in call order."""
         if x.shape[0] % calls:
             raise RuntimeError(f"discriminator: batch {x.shape[0]} is not divisible into {calls} calls")
-        with SNScope(self, (tuple(x.shape), calls)):  # all spectral-norm iterations of both discriminators up front
+        # (ops.set_precision: the discriminator forward may run in a finer arithmetic mode than the rest of the step)
+        with ops.discriminator_forward_precision(), SNScope(self, (tuple(x.shape), calls)):  # all spectral-norm iterations up front
             aux = ops.branch_stream(x.device) if x.is_cuda else None
             if aux is None:
                 spatial_loss = self.spatial_discriminator(x, calls=calls)

@@ -36,24 +36,69 @@ def weights_epoch() -> int:
     return _WEIGHTS_EPOCH
 
 
-PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x6": 3}
+_PLANES = {0: 0, 1: 2, 2: 2, 3: 3}  # bf16 planes per pre-split weight tensor in each mode (dgmr_split_weights)
+# "mixed": the generator and every backward pass in bf16x3, the discriminator's FORWARD in bf16x6.  The discriminator heads put a
+# BatchNorm1d over the batch in front of the last linear layer (dgmr/discriminators.py:102,129,194,218); on a batch of similar
+# sequences (iid-noise frames: bench.py's synthetic data) it divides by a spread ~1e-3 of the features and amplifies the forward's
+# rounding error ~1e3-fold into every discriminator gradient: 2^-16 products (bf16x3) then cost 10-25 % of the gradient, fp32-grade
+# products keep it at the reference's own fp32 level (tests/test_gpu_fullsize.py, iid-noise case).  Backward kernels are not
+# amplified that way (the BatchNorm1d backward itself is exact fp32 VALU arithmetic on the forward's features).
+_ALIASES = {"mixed": ("bf16x3", "bf16x6")}
+_D_FORWARD_CODE = None  # precision code of the discriminator forward, None: the global mode
 
 
-def set_precision(mode: str):
-    """Arithmetic of the forward / data-gradient contractions (tensors stay fp32 in HBM, accumulation is fp32):
-    "f32" exact fp32 MFMA (parity mode, default) | "bf16x3" split-bf16, fp32-class accuracy at 5x the ceiling | "bf16"."""
+def _set_code(code: int):
     global _PRECISION_CODE
-    if mode not in PRECISIONS:
-        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {mode!r}")
-    call("dgmr_set_precision", PRECISIONS[mode])
-    _PRECISION_CODE = PRECISIONS[mode]
+    call("dgmr_set_precision", code)
+    _PRECISION_CODE = code
+
+
+def set_precision(mode: str, discriminator_forward: Optional[str] = None):
+    """Arithmetic of the conv contractions (tensors stay fp32 in HBM, accumulation is fp32):
+    "f32"     exact fp32 MFMA (parity mode, the library default)
+    "bf16x6"  three bf16 planes per operand, six MFMAs per product: fp32-faithful products (<= 2^-25 dropped) at 2.6x the f32 ceiling
+    "bf16x3"  two planes, three MFMAs: products carry 16 significant bits (NOT fp32 arithmetic; forward within 1e-3 of fp32)
+    "bf16"    operands rounded to bf16
+    "mixed"   = set_precision("bf16x3", discriminator_forward="bf16x6"): bench.py's default (see _ALIASES above).
+    `discriminator_forward`: a second mode for the forward pass of `Discriminator` only."""
+    global _D_FORWARD_CODE
+    if mode in _ALIASES:
+        if discriminator_forward is not None:
+            raise ValueError(f"precision {mode!r} already names its discriminator-forward mode")
+        mode, discriminator_forward = _ALIASES[mode]
+    if mode not in PRECISIONS or (discriminator_forward is not None and discriminator_forward not in PRECISIONS):
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS) + sorted(_ALIASES)}, got {mode!r} / {discriminator_forward!r}")
+    _set_code(PRECISIONS[mode])
+    d = None if discriminator_forward is None else PRECISIONS[discriminator_forward]
+    _D_FORWARD_CODE = None if d == PRECISIONS[mode] else d
 
 
 def get_precision() -> str:
     from ._lib import load
 
     code = int(load().dgmr_get_precision())
-    return next(k for k, v in PRECISIONS.items() if v == code)
+    name = next(k for k, v in PRECISIONS.items() if v == code)
+    if _D_FORWARD_CODE is not None:
+        pair = (name, next(k for k, v in PRECISIONS.items() if v == _D_FORWARD_CODE))
+        return next((k for k, v in _ALIASES.items() if v == pair), f"{pair[0]}+d:{pair[1]}")
+    return name
+
+
+class discriminator_forward_precision:
+    """Inside: launches are issued in the discriminator-forward mode of set_precision (no-op when none is set).  The mode is
+    read by the library when a launch is ISSUED, so kernels already queued are unaffected; autograd runs the backward later,
+    outside this scope, in the global mode."""
+
+    def __enter__(self):
+        self.prev = None
+        if _D_FORWARD_CODE is not None and _D_FORWARD_CODE != _PRECISION_CODE:
+            self.prev = _PRECISION_CODE
+            _set_code(_D_FORWARD_CODE)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            _set_code(self.prev)
 
 
 def _stream():
@@ -489,16 +534,17 @@ def _split_planes(w: torch.Tensor, flipped: bool, coff: int = 0, cin: Optional[i
     rows_c, k_c = (cin, cout) if flipped else (cout, cin)  # rows of the matrix the kernel sees, and its input channels
     if k_c % 8:
         return None
-    key = (id(w), flipped, coff, cin)
+    planes = _PLANES[_PRECISION_CODE]
+    key = (id(w), flipped, coff, cin, planes)
     tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
     hit = _split_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
-    out = torch.empty(2 * cout * taps * cin, device=w.device, dtype=torch.int16)
+    out = torch.empty(planes * cout * taps * cin, device=w.device, dtype=torch.int16)
     if flipped:  # the flipped slice is already dense
-        call("dgmr_split_weights", _p(_flipped_weight(w, coff, cin)), _p(out), rows_c * taps, k_c, 0, 0, _stream())
+        call("dgmr_split_weights", _p(_flipped_weight(w, coff, cin)), _p(out), rows_c * taps, k_c, 0, 0, planes, _stream())
     else:
-        call("dgmr_split_weights", _p(w), _p(out), rows_c * taps, k_c, cin_total, coff, _stream())
+        call("dgmr_split_weights", _p(w), _p(out), rows_c * taps, k_c, cin_total, coff, planes, _stream())
     _split_cache[key] = (tag, out, weakref.ref(w, lambda _r, k=key: _split_cache.pop(k, None)))
     return out
 
@@ -513,15 +559,16 @@ def _phase_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
     if _PRECISION_CODE == 0 or _NO_PHASES or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[1] % 8:
         return None
     cout, cin = w.shape[0], w.shape[1]
-    key = id(w)
+    planes = _PLANES[_PRECISION_CODE]
+    key = (id(w), "phase", planes)
     tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
     hit = _phase_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
     sums = torch.empty(16 * cout * cin, device=w.device, dtype=torch.float32)
     call("dgmr_upsample_phase_weights", _p(w), _p(sums), cout, cin, _stream())
-    out = torch.empty(2 * 16 * cout * cin, device=w.device, dtype=torch.int16)
-    call("dgmr_split_weights", _p(sums), _p(out), 16 * cout, cin, 0, 0, _stream())
+    out = torch.empty(planes * 16 * cout * cin, device=w.device, dtype=torch.int16)
+    call("dgmr_split_weights", _p(sums), _p(out), 16 * cout, cin, 0, 0, planes, _stream())
     _phase_cache[key] = (tag, out, weakref.ref(w, lambda _r, k=key: _phase_cache.pop(k, None)))
     return out
 
@@ -532,15 +579,16 @@ def _pool2_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
     if _PRECISION_CODE == 0 or _NO_PHASES or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] % 8:
         return None
     cout, cin = w.shape[0], w.shape[1]
-    key = (id(w), "pool2")
+    planes = _PLANES[_PRECISION_CODE]
+    key = (id(w), "pool2", planes)
     tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
     hit = _phase_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
     sums = torch.empty(16 * cout * cin, device=w.device, dtype=torch.float32)
     call("dgmr_pool2_phase_weights", _p(_flipped_weight(w)), _p(sums), cin, cout, _stream())
-    out = torch.empty(2 * 16 * cout * cin, device=w.device, dtype=torch.int16)
-    call("dgmr_split_weights", _p(sums), _p(out), 16 * cin, cout, 0, 0, _stream())
+    out = torch.empty(planes * 16 * cout * cin, device=w.device, dtype=torch.int16)
+    call("dgmr_split_weights", _p(sums), _p(out), 16 * cin, cout, 0, 0, planes, _stream())
     _phase_cache[key] = (tag, out, weakref.ref(w, lambda _r, k=key: _phase_cache.pop(k, None)))
     return out
 

@@ -67,20 +67,37 @@ def cos_sim(a, b):
     return torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
 
 
+BAND_LOG = os.environ.get("DGMR_BAND_LOG", os.path.join(ROOT, "gpurun_out", "band_tables.log"))
+
+
+def _log_band(msg):
+    """Every band table of a run is appended to one file (gpurun_out/ travels back from the GPU box; the final tree's copy is
+    committed under profiles/): the measured errors are evidence whether or not a test fails."""
+    try:
+        os.makedirs(os.path.dirname(BAND_LOG), exist_ok=True)
+        with open(BAND_LOG, "a") as f:
+            f.write(msg + "\n\n")
+    except OSError:
+        pass
+
+
 def band_check(what, precision, tol, rows, factor=None):
     """rows: {name: (hip, ref32, ref64)}.  The HIP result must be within max(tol, 3 x the error of the reference's OWN fp32 arithmetic)
     of the float64 truth (max-abs error over the tensor's max magnitude; 1 - cosine within max(1e-4, 10 x fp32's)): where fp32
     itself is ill-conditioned (BatchNorm batch statistics over a handful of elements at B = 1, cancelling weight-gradient sums) a
     fixed 1e-3 would test the conditioning of the problem, not the kernels.  ref32 / ref64: the CPU oracle run in float32 (the
     reference's arithmetic) and in float64 on the same inputs and state.
-    `factor` (default 3; 10 for bf16x3): the exact-f32 kernels measure at 0.7 ... 1.7 x the fp32 oracle's own error everywhere
-    (profiles/r02_pytest_gpu.log); bf16x3 forms every product from 16 significant bits (2^-16 instead of 2^-24 per product), which
-    the same ill-conditioned backward amplifies to 2 ... 8 x the fp32 error on deep-layer gradients while the forward stays at
-    3e-4 - that is the price of running fp32 tensors on the bf16 matrix cores, stated here rather than hidden in a loose bound."""
+    `factor` (default 3; 10 where 16-bit products are involved: "bf16x3", "mixed"): the exact-f32 kernels measure at 0.7 ... 1.7 x the
+    fp32 oracle's own error everywhere; bf16x3 forms every product from 16 significant bits (2^-16 instead of 2^-24 per product),
+    which an ill-conditioned backward amplifies to 2 ... 8 x the fp32 error on deep-layer gradients while the forward stays at 3e-4.
+    Isolated ReLU-boundary flips: a pre-activation within ~1e-7 of zero falls on the other side of the kink under another fp32
+    summation order and its whole gradient toggles; behind batch-statistics BatchNorm over a handful of samples the gradients are
+    heavy-tailed, so ONE flipped element can move a max-abs comparison by 5e-2 while every other element agrees to 1e-6 (the
+    unmodified reference shows the same between CPU thread counts, tests/golden/training_steps_adv `noise.*`).  They are accepted
+    by COUNT, never by a norm: at most 0.1 % of a tensor's elements may exceed the bound, none by more than 100 x, and the cosine
+    criterion still applies - a uniform error of any size (every element beyond the bound) fails."""
     if factor is None:
-        factor = 10.0 if precision == "bf16x3" else 3.0
-    # A tensor passes on the max-abs criterion above, OR when it agrees in direction and in the l2 sense (1 - cosine <= 1e-4 and
-    # l2-relative error <= 3e-2) - the signature of a few isolated ReLU-boundary flips, see below.
+        factor = 10.0 if precision in ("bf16x3", "mixed") else 3.0
     table, bad = [], []
     for k, (hip, r32, r64) in rows.items():
         e_hip, e_ref = rel_err(hip, r64), rel_err(r32, r64)
@@ -88,18 +105,19 @@ def band_check(what, precision, tol, rows, factor=None):
         f_k = factor * (2.0 if r64.numel() == 1 else 1.0)  # a single element (attention gamma): nothing to take a max over
         bound = max(tol, f_k * e_ref)
         cbound = max(1e-4, 10.0 * factor * (1.0 - c_ref))
-        # l2-relative error: robust against ISOLATED ReLU-boundary flips.  A pre-activation within ~1e-7 of zero falls on the other
-        # side of the kink under another fp32 summation order and its whole gradient toggles; behind batch-statistics BatchNorm over
-        # a handful of samples the gradients are heavy-tailed (a few elements carry 100x the typical magnitude), so ONE flipped
-        # element can move a max-abs comparison by 5e-2 while every other element agrees to 1e-6 (tests/test_gpu_stages.py prints
-        # them; the unmodified reference shows the same between CPU thread counts, tests/golden/training_steps_adv `noise.*`).
+        scale = max(r64.double().abs().max().item(), 1e-300)
+        over = ((hip.double() - r64.double()).abs() / scale > bound)
+        n_over = int(over.sum().item())
+        allowed = int(1e-3 * r64.numel())
         l2 = ((hip.double() - r64.double()).pow(2).sum().sqrt() / r64.double().pow(2).sum().sqrt().clamp_min(1e-300)).item()
-        flips_only = l2 <= 3e-2 and 1.0 - c <= 1e-4
-        ok = (e_hip <= bound and 1.0 - c <= cbound) or flips_only
+        within = e_hip <= bound
+        flips = (not within) and n_over <= allowed and e_hip <= 100.0 * bound
+        ok = (within or flips) and 1.0 - c <= cbound
         table.append(f"  {k:88s} hip {e_hip:.2e}  ref-fp32 {e_ref:.2e}  bound {bound:.2e}  1-cos {1 - c:.1e} (ref-fp32 {1 - c_ref:.1e})  l2 {l2:.1e}"
-                     + ("" if e_hip <= bound else "  [beyond the max-abs bound: accepted as isolated flips]" if ok else "  FAIL"))
+                     + ("" if within else f"  [{n_over} of {r64.numel()} elements beyond the bound" + (": accepted as isolated flips]" if ok else "]  FAIL")))
         if not ok:
             bad.append(k)
     msg = f"{what} [{precision}] errors against the float64 oracle:\n" + "\n".join(table)
     print("\n" + msg)
+    _log_band(msg)
     assert not bad, f"beyond the bound: {bad}\n{msg}"

@@ -191,26 +191,45 @@ D_GRAD_KEYS = ["temporal_discriminator.d1.first_conv_3x3.parametrizations.weight
                "spatial_discriminator.fc.bias"]
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 1e-3), ("bf16x3", 2e-3)])
-def test_discriminator_fwd_bwd_paper_config(setup, precision, tol):
-    """Full-depth discriminator on 4 real + 4 generated 22-frame sequences at 256 x 256 (BatchNorm1d over 8 samples; the step itself
-    runs 32): scores, weight gradients AND the gradient with respect to the input frames - the tensor through which loss_hinge_gen
-    reaches the generator (dgmr/dgmr.py:186-196).  Same float64-anchored bound as the generator test."""
-    import skillful_nowcasting_amd as S
+@pytest.fixture(scope="module")
+def oracle_d_fwd_bwd(setup):
+    """Oracle discriminator forward + backward in float32 and float64 on the two input batches below (computed once per batch, shared
+    by the arithmetic modes)."""
+    cache = {}
+
+    def get(data):
+        if data not in cache:
+            cache[data] = _oracle_d(setup, data)
+        return cache[data]
+
+    return get
+
+
+def _d_inputs(data):
+    torch.manual_seed(31)
+    if data == "iid":
+        # eight iid uniform-noise sequences = what bench.py feeds (torch.rand frames).  A degenerate batch for the BatchNorm1d in front
+        # of the last linear layer: the pooled features of the eight samples agree to 1e-3 of their size (|mean| / batch std = 870
+        # median, 2600 at the 90th percentile, measured on the CPU oracle); the normalisation divides by that spread and every
+        # gradient of the spatial discriminator inherits the FORWARD's rounding error x ~1e3: 1.7e-1 with 16-bit products (bf16x3,
+        # profiles/r02_pytest_gpu_r2p.log), 2.4e-4 for the reference's own fp32.  This is why the bench's default mode ("mixed") runs
+        # the discriminator forward in bf16x6; plain bf16x3 is not held to this case.
+        seq = torch.rand(8, 22, 1, 256, 256)
+    else:
+        # eight DISTINCT sequences (per-sample amplitude and smooth structure), as a batch of real and generated radar is: ratio 2.8
+        amp = torch.linspace(0.15, 2.5, 8).view(8, 1, 1, 1, 1)
+        low = F.interpolate(torch.rand(8 * 22, 1, 8, 8), size=(256, 256), mode="bilinear", align_corners=False).view(8, 22, 1, 256, 256)
+        seq = amp * (0.5 * torch.rand(8, 22, 1, 256, 256) + low * torch.rand(8, 1, 1, 1, 1) * 2)
+    cot = torch.randn(8, 2, 1)
+    return seq, cot
+
+
+def _oracle_d(setup, data):
     from oracle import dgmr_oracle as O
 
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    model, sd_cpu, _, _ = setup
-    # Eight DISTINCT sequences (per-sample amplitude and smooth structure), as a batch of real and generated radar is.  Eight iid
-    # uniform-noise sequences are a degenerate batch for the BatchNorm1d in front of the last linear layer: their pooled features
-    # agree to 1e-3 of their size (|mean| / batch std = 870 median, 2600 at the 90th percentile, measured on the CPU oracle), the
-    # normalisation divides by that tiny spread and every gradient of the spatial discriminator inherits the forward rounding error
-    # x ~1e3: 1.7e-1 in bf16x3, 2.4e-4 even for the reference's own fp32 (profiles/r02_pytest_gpu_r2p.log).  Here the ratio is 2.8.
-    torch.manual_seed(31)
-    amp = torch.linspace(0.15, 2.5, 8).view(8, 1, 1, 1, 1)
-    low = F.interpolate(torch.rand(8 * 22, 1, 8, 8), size=(256, 256), mode="bilinear", align_corners=False).view(8, 22, 1, 256, 256)
-    seq = amp * (0.5 * torch.rand(8, 22, 1, 256, 256) + low * torch.rand(8, 1, 1, 1, 1) * 2)
-    cot = torch.randn(8, 2, 1)
+    _, sd_cpu, _, _ = setup
+    seq, cot = _d_inputs(data)
     torch.manual_seed(3)
     idxs = torch.randint(0, 22, (8,)).tolist()
     ref = {}
@@ -224,6 +243,21 @@ def test_discriminator_fwd_bwd_paper_config(setup, precision, tol):
         o = O.discriminator(sd, "", s_, idxs, True)
         (o * cot.to(dt)).sum().backward()
         ref[dt] = (o.detach(), {k: sd[k].grad.clone() for k in d_keys if sd[k].grad is not None}, s_.grad.clone())
+    return ref
+
+
+@pytest.mark.parametrize("precision,tol,data", [("f32", 1e-3, "distinct"), ("bf16x3", 2e-3, "distinct"), ("mixed", 2e-3, "distinct"),
+                                                ("f32", 1e-3, "iid"), ("mixed", 2e-3, "iid"), ("bf16x6", 1e-3, "iid")])
+def test_discriminator_fwd_bwd_paper_config(setup, oracle_d_fwd_bwd, precision, tol, data):
+    """Full-depth discriminator on 4 real + 4 generated 22-frame sequences at 256 x 256 (BatchNorm1d over 8 samples; the step itself
+    runs 32): scores, weight gradients AND the gradient with respect to the input frames - the tensor through which loss_hinge_gen
+    reaches the generator (dgmr/dgmr.py:186-196).  Same float64-anchored bound as the generator test.  `iid`: bench.py's own input
+    distribution, in exact f32, in the bench's default mode ("mixed") and in bf16x6."""
+    import skillful_nowcasting_amd as S
+
+    model, sd_cpu, _, _ = setup
+    seq, cot = _d_inputs(data)
+    ref = oracle_d_fwd_bwd(data)
     model.load_state_dict(sd_cpu)
     S.ops.bump_weights_epoch()
     model.train()
@@ -246,7 +280,7 @@ def test_discriminator_fwd_bwd_paper_config(setup, precision, tol):
             continue  # (temporal fc.bias / conv biases in front of nothing: exactly zero on both sides)
         rows["grad " + k] = (named[k].grad.detach().cpu().float().reshape(g64[k].shape), g32[k], g64[k])
     assert all(k in g64 for k in D_GRAD_KEYS)
-    _band_check("discriminator fwd + bwd, paper config", precision, tol, rows)
+    _band_check(f"discriminator fwd + bwd, paper config, {data} sequences", precision, tol, rows)
 
 
 @pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("bf16x3", 1e-3)])
