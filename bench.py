@@ -23,6 +23,16 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak
+# algorithmic TFLOP of one training_step per sample, F_step = 20 F_g + 30 F_d
+F_STEP_TFLOP = {"paper": 11.50, "cfg2": 1.20, "cfg5": 46.0}
+DTYPE_TEXT = {
+    "f32": "f32 (exact: v_mfma_f32_32x32x2_f32; the reference's arithmetic)",
+    "bf16x6": "bf16x6 (fp32 tensors; operands split into three bf16 planes, six bf16 MFMAs per product: fp32-faithful products, fp32 accumulate)",
+    "mixed": "mixed: bf16x3 (fp32 tensors; operands split into two bf16 planes, three MFMAs per product: products carry 16 significant "
+             "bits, fp32 accumulate) for the generator and every backward pass, bf16x6 (fp32-faithful products) for the discriminator forward",
+    "bf16x3": "bf16x3 (fp32 tensors; two bf16 planes per operand, three MFMAs per product: 16-bit products, NOT fp32 arithmetic; fp32 accumulate)",
+    "bf16": "bf16 operands, fp32 accumulate",
+}
 
 
 def parse():
@@ -37,11 +47,15 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tune", default="", help="A/B switch for kernel development: variant,ksplit,window,wgrad_window for "
                                                "dgmr_conv_tune (-1 = the library's own choice, the default)")
-    ap.add_argument("--precision", default=os.environ.get("DGMR_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
-                    help="arithmetic of the conv forward/data-gradient contractions (tensors stay fp32 in HBM)")
+    ap.add_argument("--precision", default=os.environ.get("DGMR_PRECISION", "mixed"), choices=["f32", "bf16x6", "mixed", "bf16x3", "bf16"],
+                    help="arithmetic of the conv contractions (tensors stay fp32 in HBM, fp32 accumulation): f32 exact | bf16x6 "
+                         "fp32-faithful products on the bf16 pipe | mixed (default) = bf16x3 (16-bit products) with the discriminator "
+                         "forward in bf16x6 | bf16x3 | bf16")
     ap.add_argument("--also", default="auto", choices=["auto", "on", "off"],
-                    help="also time a few steps of the same build in the other arithmetic modes (exact f32, plain bf16) and report "
-                         "them in an `also` block; auto = on for single-GPU runs")
+                    help="also time the same build in the other arithmetic modes and report them in an `also` block: exact f32 (the "
+                         "reference's arithmetic: >= 10 steps after 3 warm-ups, with its own roofline block), bf16x6 and plain bf16 "
+                         "(a few steps each); auto = on for single-GPU runs")
+    ap.add_argument("--also-f32-steps", type=int, default=10)
     return ap.parse_args()
 
 
@@ -67,13 +81,10 @@ WORKLOADS = {
 
 
 def cpu_baseline(kw, hw, T):
-    """Oracle (CPU restatement of the reference, `kind: port`) timed on this host on a bounded sample.
-
-    Sample: at the bench's model configuration, batch 1 — one generator forward+backward and one discriminator
-    forward+backward on a (real, generated) pair.  The reference's step executes, per sample, 17 G forwards,
-    8 G backwards, 16 D sequence-forwards and 16 D sequence-backwards, i.e.
-    t_step ~= 9*t_Gf + 8*t_Gfb + 8*t_Dfb(2 seq); frames/s = (4+T)/t_step.
-    """
+    """Oracle (CPU restatement of the reference, `kind: port`) timed on this host on a bounded sample: ONE whole
+    `training_step` (oracle.training_step = dgmr/dgmr.py:137-218 as written: 17 generator forwards, 8 generator backwards, 16
+    discriminator sequence forwards and backwards, both Adam updates) at the bench's model configuration and batch 1.
+    frames/s = (4 + T) / t_step.  The generator forward is timed twice beside it as a spread indicator."""
     import torch
 
     import skillful_nowcasting_amd as S
@@ -88,32 +99,27 @@ def cpu_baseline(kw, hw, T):
     model = S.DGMR(**kw)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items() if k.startswith(("generator.", "discriminator."))}
     del model
-    for k in O.param_keys(sd, "generator.") + O.param_keys(sd, "discriminator."):
-        sd[k].requires_grad_(True)
     x = torch.rand(1, 4, 1, hw, hw)
     y = torch.rand(1, T, 1, hw, hw)
     z = O.draw_latent((8, hw // 32, hw // 32))
+    t_gf = []
     with torch.no_grad():
         O.generator(sd, "generator.", x, z, T, True)  # warm-up (thread pool, oneDNN primitive caches)
+        for _ in range(2):
+            t0 = time.perf_counter()
+            O.generator(sd, "generator.", x, z, T, True)
+            t_gf.append(time.perf_counter() - t0)
+    hp = dict(forecast_steps=T, generation_steps=kw.get("generation_steps", 6), grid_lambda=20.0, gen_lr=5e-5, disc_lr=2e-4, beta1=0.0,
+              beta2=0.999, precip_weight_cap=24.0, latent_shape=(8, hw // 32, hw // 32), num_spatial_frames=8)
     t0 = time.perf_counter()
-    with torch.no_grad():
-        O.generator(sd, "generator.", x, z, T, True)
-    t_gf = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    pred = O.generator(sd, "generator.", x, z, T, True)
-    pred.square().mean().backward()
-    t_gfb = time.perf_counter() - t0
-    seq = torch.cat([torch.cat([x, y], 1), torch.cat([x, pred.detach()], 1)], 0)
-    t0 = time.perf_counter()
-    out = O.discriminator(sd, "discriminator.", seq, torch.randint(0, 4 + T, (8,)).tolist(), True)
-    out.sum().backward()
-    t_dfb = time.perf_counter() - t0
-    t_step = 9 * t_gf + 8 * t_gfb + 8 * t_dfb
+    O.training_step(sd, x, y, hp, {"step": {}, "m": {}, "v": {}})
+    t_step = time.perf_counter() - t0
     return {
         "value": (4 + T) / t_step, "unit": "radar frames/s", "cores": torch.get_num_threads(), "kind": "port",
         "host_cpus": os.cpu_count(),
-        "sample": f"oracle (torch-CPU fp32 restatement of the reference) at its best thread count on this host, batch 1: G fwd {t_gf:.2f}s, G fwd+bwd {t_gfb:.2f}s, "
-                  f"D fwd+bwd(2 seq) {t_dfb:.2f}s; step = 9*Gf + 8*Gfb + 8*Dfb = {t_step:.1f}s (reference op counts, SURVEY §3.1)",
+        "sample": f"oracle.training_step (torch-CPU fp32 restatement of the reference's step, as written: 17 G fwd, 8 G bwd, 16 D "
+                  f"seq fwd+bwd, 2 Adam) at its best thread count on this host, batch 1, ONE measured step of {t_step:.1f} s (no "
+                  f"extrapolation); generator forward alone {t_gf[0]:.2f} / {t_gf[1]:.2f} s in two repeats",
     }
 
 
@@ -227,16 +233,15 @@ def main():
     ms_median = step_ms_sorted[len(step_ms_sorted) // 2] if len(step_ms_sorted) % 2 else \
         0.5 * (step_ms_sorted[len(step_ms_sorted) // 2 - 1] + step_ms_sorted[len(step_ms_sorted) // 2])
 
-    roofline = None
-    if not args.no_roofline:
-        # one extra step with HIP events around every conv launch (recorded on the launch stream inside the library)
+    def measure_roofline(precision, ms_step, first_idx):
+        """One extra step with HIP events around every conv launch (recorded on the launch stream inside the library)."""
         lib = _lib.load()
         # per-kernel durations must not include a co-running kernel: the weight gradients, which the timed steps run on a second
         # stream beside the data-gradient chain, are issued in line for this one instrumented step
         side = S.ops._WGRAD_STREAM
         S.ops._WGRAD_STREAM = False
         lib.dgmr_profile_enable(1)
-        model.training_step(batch, args.warmup + args.steps)
+        model.training_step(batch, first_idx)
         torch.cuda.synchronize()
         lib.dgmr_profile_enable(0)
         S.ops._WGRAD_STREAM = side
@@ -249,25 +254,30 @@ def main():
         rows = [dict(kernel=lib.dgmr_profile_variant_name(i).decode(), launches=int(cnt[i]), total_ms=ms[i],
                      avg_us=(1e3 * ms[i] / cnt[i]) if cnt[i] else 0.0, tflops=(fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] > 0 else 0.0,
                      flops_per_launch=(fl[i] / cnt[i]) if cnt[i] else 0.0) for i in range(nv)]
-        # every conv kernel (forward, data gradient, weight gradient) runs in the selected arithmetic mode
-        mult = {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
+        peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_BF16_MFMA_TFLOPS
         for i_row, r in enumerate(rows):
-            r["peak_tflops"] = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
-            # matrix-pipe work really issued: phase / pooled launches of the upsampling convs execute 16/36 of their algorithmic MACs
-            r["mfma_executed_tflops"] = (ex[i_row] / (r["total_ms"] * 1e-3) / 1e12 * mult) if r["total_ms"] > 0 else 0.0
+            r["peak_tflops"] = peak
+            # matrix-pipe work really issued (counted by the library per launch): x 3 / x 6 MFMAs per product in bf16x3 / bf16x6 launches,
+            # x 16/36 for the phase / pooled launches of the upsampling convs
+            r["mfma_executed_tflops"] = (ex[i_row] / (r["total_ms"] * 1e-3) / 1e12) if r["total_ms"] > 0 else 0.0
             r["frac"] = r["tflops"] / r["peak_tflops"]
         dom = max(rows, key=lambda r: r["total_ms"])
         tot_ms = sum(r["total_ms"] for r in rows)
         tot_fl = sum(fl[i] for i in range(nv))
-        roofline = {
+        roof = {
             "bound": "mfma", "achieved": dom["tflops"], "peak": dom["peak_tflops"], "unit": "TFLOP/s",
             "frac": dom["tflops"] / dom["peak_tflops"], "traffic": None, "kernel": dom["kernel"],
             "mfma_executed_tflops": dom["mfma_executed_tflops"], "mfma_executed_frac": dom["mfma_executed_tflops"] / dom["peak_tflops"],
-            "note": "achieved = algorithmic 2*M*K*Cout per launch / HIP-event time of that launch, summed over the step; in bf16x3 "
-                    "every product costs three bf16 MFMAs (mfma_executed_*), peak is the dense bf16 MFMA rate",
+            "note": "achieved = algorithmic 2*M*K*Cout per launch / HIP-event time of that launch, summed over the step; a product "
+                    "costs three bf16 MFMAs in bf16x3 and six in bf16x6 (mfma_executed_*), peak is the dense MFMA rate of the mode "
+                    "(bf16 pipe 2.5 PF; exact f32 157.3 TF)",
             "launches_per_step": dom["launches"], "avg_launch_us": dom["avg_us"], "flops_per_launch": dom["flops_per_launch"],
             "all_conv_kernels": {"tflops": tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0, "ms_per_step": tot_ms,
-                                 "frac_of_step": tot_ms / ms_per_step},
+                                 "frac_of_step": tot_ms / ms_step},
+            "whole_step": {"algorithmic_tflop_per_sample": F_STEP_TFLOP.get(args.workload),
+                           "tflops": (F_STEP_TFLOP[args.workload] * B / (ms_step * 1e-3)) if args.workload in F_STEP_TFLOP else None,
+                           "frac": (F_STEP_TFLOP[args.workload] * B / (ms_step * 1e-3) / peak) if args.workload in F_STEP_TFLOP else None,
+                           "note": "SURVEY.md §8(d): F_step = 20 F_g + 30 F_d per sample, over the whole step time"},
             "per_kernel": rows,
         }
         # HBM traffic of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs, FETCH_SIZE doubled per
@@ -278,28 +288,39 @@ def main():
         pmc_path = cands[-1] if cands else ""
         if pmc_path:
             pmc = json.load(open(pmc_path))
-            if pmc.get("precision") == args.precision and dom["kernel"] in pmc.get("kernel", ""):
-                roofline["traffic"] = pmc["traffic_bytes"]
-                roofline["traffic_detail"] = {k: pmc[k] for k in ("shape", "launch_us", "algorithmic_bytes", "traffic_over_algorithmic",
-                                                                  "hbm_gbps", "mfma_util", "valu_per_mfma", "traffic_note")}
-                roofline["traffic_detail"]["source"] = (f"profiles/{os.path.basename(pmc_path)} (+ raw counters in profiles/*_pmc_*.csv): "
-                                                        "PMC passes cannot run inside this process; the number is the committed "
-                                                        "measurement of one representative launch of this kernel, not of this run")
+            if pmc.get("precision") in (precision, {"mixed": "bf16x3"}.get(precision)) and dom["kernel"] in pmc.get("kernel", ""):
+                roof["traffic"] = pmc["traffic_bytes"]
+                roof["traffic_detail"] = {k: pmc[k] for k in ("shape", "launch_us", "algorithmic_bytes", "traffic_over_algorithmic",
+                                                              "hbm_gbps", "mfma_util", "valu_per_mfma", "traffic_note")}
+                roof["traffic_detail"]["source"] = (f"profiles/{os.path.basename(pmc_path)} (+ raw counters in profiles/*_pmc_*.csv): "
+                                                    "PMC passes cannot run inside this process; the number is the committed "
+                                                    "measurement of one representative launch of this kernel, not of this run")
+        return roof
 
-    # the same build in the other arithmetic modes, a few steps each: the exact-fp32 number (the reference's precision) and the
-    # plain-bf16 number (BASELINE.json configs[1]'s dtype) ride along with the headline so that they are witnessed by the same run
+    roofline = None
+    if not args.no_roofline:
+        roofline = measure_roofline(args.precision, ms_per_step, args.warmup + args.steps)
+
+    # The same build in the other arithmetic modes, witnessed by the same run.  The exact-f32 leg is the reference's own arithmetic
+    # (train/run.py:232 precision=32): a first-class line of >= 10 steps after 3 warm-ups with its own per-kernel roofline block
+    # (peak 157.3 TF).  bf16x6 (fp32-faithful products on the bf16 pipe) and plain bf16 (BASELINE.json configs[1]'s dtype) ride along.
     also = None
     if (args.also == "on" or (args.also == "auto" and world == 1)) and not args.fast:
         also = {}
-        for mode in ("f32", "bf16"):
+        legs = {"f32": (3, max(1, args.also_f32_steps)), "bf16x6": (2, 5), "bf16": (2, 5)}
+        for mode, (w_m, n) in legs.items():
             if mode == args.precision:
                 continue
             S.set_precision(mode)
-            n = 2 if mode == "f32" else 3
-            model.training_step(batch, 10_000)  # warm-up: weight planes / plans of this mode
-            dt_m, ms_m = time_steps(model, batch, 10_001, n, barrier)
-            also[mode] = {"ms_per_step": 1e3 * dt_m / n, "radar_frames_per_s": frames * n / dt_m, "steps": n, "warmup": 1,
-                          "dtype": {"f32": "f32 (exact: v_mfma_f32_32x32x2_f32)", "bf16": "bf16 operands, fp32 accumulate"}[mode]}
+            for i in range(w_m):
+                model.training_step(batch, 10_000 + i)  # warm-up: weight planes / plans / allocator state of this mode
+            dt_m, ms_m = time_steps(model, batch, 10_100, n, barrier)
+            ms_sorted = sorted(ms_m)
+            med = ms_sorted[n // 2] if n % 2 else 0.5 * (ms_sorted[n // 2 - 1] + ms_sorted[n // 2])
+            also[mode] = {"ms_per_step": 1e3 * dt_m / n, "ms_per_step_median": med, "radar_frames_per_s": frames * n / dt_m,
+                          "steps": n, "warmup": w_m, "step_ms": [round(v, 1) for v in ms_m], "dtype": DTYPE_TEXT[mode]}
+            if mode == "f32" and not args.no_roofline:
+                also[mode]["roofline"] = measure_roofline("f32", 1e3 * dt_m / n, 10_200)
         S.set_precision(args.precision)
 
     if rank == 0:
@@ -311,7 +332,7 @@ def main():
                     "reserved_gb": round(torch.cuda.memory_reserved() / 2**30, 1),
                     "alloc_retries": torch.cuda.memory_stats().get("num_alloc_retries", 0)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 tensors, split-bf16 MFMA operands, fp32 accumulate)", "bf16": "bf16"}[args.precision],
+            "dtype": DTYPE_TEXT[args.precision],
             "data": "synthetic torch.rand frames, random-init weights",
             "config": {"workload": f"DGMR.training_step {args.workload}: {kw}, H=W={hw}", "per_gpu_batch": B, "global_batch": world * B,
                        "frames_per_sample": 4 + T, "parallelism": f"dp{world}",
@@ -321,6 +342,7 @@ def main():
         }
         if replicas_in_sync is not None:
             out["replicas_in_sync"] = replicas_in_sync  # parameter checksums agree bit for bit across the ranks after the timed steps
+            out["process_group"] = {"backend": backend, "world_size_reported": dist.get_world_size()}
         if roofline:
             out["roofline"] = roofline
         if also:

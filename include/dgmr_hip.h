@@ -419,9 +419,9 @@ int dgmr_profile_enable(int on);
 int dgmr_profile_variants(void);
 const char* dgmr_profile_variant_name(int variant);
 int dgmr_profile_collect(double* total_ms, double* total_flops, int64_t* launches, int n);
-/* The same plus executed_flops[v]: 2 x the multiply-accumulates the launches really performed - 16/36 of the algorithmic figure for
- * upsampling convs run as phase convs / pooled data gradients (w_phase); equal to total_flops otherwise (bf16x3's three MFMAs per
- * product are NOT included in either: multiply by 3 for matrix-pipe work). */
+/* The same plus executed_flops[v]: the flops the matrix pipe really issued - 16/36 of the algorithmic figure for upsampling convs run
+ * as phase convs / pooled data gradients (w_phase), times the MFMAs per product of the mode the launch was issued in (3 in
+ * DGMR_PREC_BF16X3, 6 in DGMR_PREC_BF16X6; ABI 8: this factor used to be the caller's to apply). */
 int dgmr_profile_collect2(double* total_ms, double* total_flops, double* executed_flops, int64_t* launches, int n);
 /* Dispatch override for tools/conv_bench.py's tile / split-K sweeps (process-wide; -1 = the library's own choice, which is
  * also the state at load): variant = index of a conv_fwd_dgrad<..> tile as listed by dgmr_profile_variant_name, ksplit = number

@@ -354,7 +354,7 @@ def param_keys(sd: SD, prefix: str) -> List[str]:
     return [k for k in sd if k.startswith(prefix) and not k.endswith(_BUFFER_SUFFIXES)]
 
 
-def training_step(sd: SD, images: torch.Tensor, future: torch.Tensor, hp: dict, opt: dict):
+def training_step(sd: SD, images: torch.Tensor, future: torch.Tensor, hp: dict, opt: dict, capture: Optional[dict] = None):
     """One `DGMR.training_step` on the state dict `sd` (keys under ``generator.`` and ``discriminator.``).
 
     Restates dgmr/dgmr.py:137-218 literally, including activation checkpointing of the generator
@@ -363,6 +363,9 @@ def training_step(sd: SD, images: torch.Tensor, future: torch.Tensor, hp: dict, 
     `hp`: forecast_steps, generation_steps, grid_lambda, gen_lr, disc_lr, beta1, beta2, precip_weight_cap,
     latent_shape, num_spatial_frames.  `opt`: {"step": {key: int}, "m": {key: t}, "v": {key: t}} (Adam state).
     Returns (d_loss, g_loss, grid_loss) as floats; `sd` and `opt` are updated in place.
+    `capture` (tests): receives "backward_losses" (the three losses `manual_backward` is called on, dgmr.py:163,196), "d_grads" (one
+    dict per discriminator pass: the gradients `d_opt.step()` consumes, :165) and "g_grads" (those of `g_opt.step()`, :200).
+    `sd` may be float64 (the latent draw is cast to the images' dtype; the RNG stream is the same).
     """
     from torch.utils.checkpoint import checkpoint
 
@@ -372,12 +375,15 @@ def training_step(sd: SD, images: torch.Tensor, future: torch.Tensor, hp: dict, 
     T = hp["forecast_steps"]
 
     def gen(x):
-        z = draw_latent(hp["latent_shape"])
+        z = draw_latent(hp["latent_shape"]).to(x.dtype)
         return generator(sd, "generator.", x, z, T, True)
 
     def disc(x):
         idxs = torch.randint(low=0, high=x.size(1), size=(hp.get("num_spatial_frames", 8),))
         return discriminator(sd, "discriminator.", x, idxs.tolist(), True)
+
+    if capture is not None:
+        capture.update(backward_losses=[], d_grads=[], g_grads={})
 
     def adam(keys, lr):
         for k in keys:
@@ -402,6 +408,9 @@ def training_step(sd: SD, images: torch.Tensor, future: torch.Tensor, hp: dict, 
         s_real, s_gen = out[:b], out[b:]
         d_loss = loss_hinge_disc(s_gen[:, 0:1], s_real[:, 0:1]) + loss_hinge_disc(s_gen[:, 1:2], s_real[:, 1:2])
         d_loss.backward()
+        if capture is not None:
+            capture["backward_losses"].append(float(d_loss.detach()))
+            capture["d_grads"].append({k: sd[k].grad.detach().clone() for k in dp if sd[k].grad is not None})
         adam(dp, hp["disc_lr"])
     predictions = [checkpoint(gen, images, use_reentrant=False) for _ in range(hp["generation_steps"])]
     gen_mean = torch.stack(predictions, dim=0).mean(dim=0)
@@ -414,6 +423,9 @@ def training_step(sd: SD, images: torch.Tensor, future: torch.Tensor, hp: dict, 
     for k in gp:
         sd[k].grad = None
     g_loss.backward()
+    if capture is not None:
+        capture["backward_losses"].append(float(g_loss.detach()))
+        capture["g_grads"] = {k: sd[k].grad.detach().clone() for k in gp if sd[k].grad is not None}
     adam(gp, hp["gen_lr"])
     gen(images)  # the logging forward (dgmr.py:213): advances u/v, BN statistics and the CPU RNG
     return float(d_loss.detach()), float(g_loss.detach()), float(grid.detach())

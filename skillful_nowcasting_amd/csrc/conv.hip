@@ -233,10 +233,12 @@ __global__ void splitk_reduce4_kernel(const dgmr_conv_args p, const int M, const
 // Optional per-launch timing (bench.py's roofline leg): HIP events recorded on the launch stream around every
 // conv / wgrad kernel, grouped by tile variant.  Off by default; never used inside the timed region.
 // ------------------------------------------------------------------------------------------------
+int g_precision = 0;  // (documented below, with the dispatch switches)
 struct ProfRec {
     int variant;
     double flops;     // algorithmic: 2 * MACs of the dense convolution as the reference states it
-    double executed;  // multiply-accumulates x 2 the launch really performs (phase / pooled decompositions: 16/36 of the above)
+    double executed;  // flops the matrix pipe really issues: x 16/36 for the phase / pooled decompositions, x MFMAs per product (3 in
+                      // bf16x3, 6 in bf16x6) - the mode is the launch's own, a step may mix them
     hipEvent_t e0, e1;
 };
 bool g_prof_on = false;
@@ -264,7 +266,7 @@ struct ProfScope {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         r.variant = variant;
         r.flops = flops;
-        r.executed = flops * exec_frac;
+        r.executed = flops * exec_frac * (g_precision == 1 ? 3.0 : (g_precision == 3 ? 6.0 : 1.0));
         r.e0 = prof_event();
         r.e1 = prof_event();
         (void)hipEventRecord(r.e0, s);
@@ -284,7 +286,7 @@ const char* const kVariantNames[V_COUNT] = {
 
 // 0: exact fp32 (v_mfma_f32_32x32x2_f32)   1: bf16x3 (two bf16 planes per operand, three MFMAs per product: 16-bit products)
 // 2: plain bf16   3: bf16x6 (three planes, six MFMAs: products as accurate as an fp32 product's own rounding)
-int g_precision = 0;
+// (int g_precision: defined above ProfRec)
 
 #define DGMR_BY_NS(fn, ...) \
     (g_precision == 1 ? dgmr_tu::fn##_ns3(__VA_ARGS__) : (g_precision == 2 ? dgmr_tu::fn##_ns1(__VA_ARGS__) : dgmr_tu::fn##_ns6(__VA_ARGS__)))

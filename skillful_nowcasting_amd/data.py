@@ -9,7 +9,9 @@ The reference's `TFDataset.__getitem__` takes a dataset row's `radar_frames` ([T
     quarter of the PCIe bytes of fp32),
   * two staging slots alternate: while the step runs on batch k, batch k+1 is uploaded on a side stream
     (`non_blocking` copies from pinned memory), converted to fp32 and laid out [B, T, C, H, W] on the device,
-  * the consumer only waits on an event, never on the host.
+  * the consumer only waits on an event, never on the host; the PRODUCER waits (on the host) for a slot's previous upload before
+    it overwrites that slot - a `non_blocking` copy reads the pinned buffer asynchronously, and nothing else stops the host from
+    running two batches ahead of the copy engine.
 
 No HIP kernel of ours is involved: layout moves and dtype conversion are torch copy kernels (plumbing, not the hot path).
 """
@@ -61,6 +63,7 @@ class RadarBatchLoader:
         self.n_in, self.n_out = num_input_frames, num_target_frames
         self.scale, self.offset, self.drop_last = float(scale), float(offset), drop_last
         self._slots = [None, None]
+        self._slot_uploaded = [None, None]  # event recorded right after the H2D copy out of each slot
         self._stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
 
     # -- host side: rows -> one staging slot ------------------------------------------------------------------------------
@@ -69,6 +72,9 @@ class RadarBatchLoader:
         first = np.asarray(batch_rows[0]["radar_frames"] if isinstance(batch_rows[0], dict) else batch_rows[0])
         shape = (len(batch_rows), t) + tuple(first.shape[1:])  # [B, T, H, W, C] in the rows' dtype
         dtype = torch.from_numpy(first[:1]).dtype
+        if self._slot_uploaded[slot] is not None:
+            self._slot_uploaded[slot].synchronize()  # the previous upload from this slot has left the pinned buffer
+            self._slot_uploaded[slot] = None
         buf = self._slots[slot]
         if buf is None or tuple(buf.shape) != shape or buf.dtype != dtype:
             buf = torch.empty(shape, dtype=dtype, pin_memory=self.device.type == "cuda")
@@ -81,12 +87,15 @@ class RadarBatchLoader:
         return buf
 
     # -- device side: staging slot -> fp32 [B, T, C, H, W] -----------------------------------------------------------------
-    def _upload(self, buf):
+    def _upload(self, buf, slot: int):
         if self._stream is None:
             dev = buf.to(self.device)
             return self._finish(dev), None
         with torch.cuda.stream(self._stream):
             dev = buf.to(self.device, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self._stream)
+            self._slot_uploaded[slot] = copied
             out = self._finish(dev)
             ev = torch.cuda.Event()
             ev.record(self._stream)
@@ -106,13 +115,13 @@ class RadarBatchLoader:
             chunk.append(row)
             if len(chunk) < self.batch_size:
                 continue
-            nxt = self._upload(self._stage(chunk, slot))
+            nxt = self._upload(self._stage(chunk, slot), slot)
             chunk, slot = [], slot ^ 1
             if pending is not None:
                 yield self._ready(pending)
             pending = nxt
         if chunk and not self.drop_last:
-            nxt = self._upload(self._stage(chunk, slot))
+            nxt = self._upload(self._stage(chunk, slot), slot)
             if pending is not None:
                 yield self._ready(pending)
             pending = nxt

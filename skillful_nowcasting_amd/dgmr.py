@@ -49,10 +49,12 @@ except Exception:  # pragma: no cover - depends on the environment
             return self._optimizers
 
         @classmethod
-        def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict: bool = True, **overrides):
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict: bool = True, weights_only: bool = True, **overrides):
             """Lightning `.ckpt` files (`{"state_dict": ..., "hyper_parameters": ...}`) without Lightning installed: the model is
-            built from the stored hyper-parameters (keyword overrides win) and the state dict loaded into it."""
-            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+            built from the stored hyper-parameters (keyword overrides win) and the state dict loaded into it.
+            `weights_only=True` (default) unpickles tensors and plain containers only; a checkpoint that carries other Python
+            objects needs `weights_only=False`, which executes whatever the pickle contains - only for files you trust."""
+            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=weights_only)
             if "state_dict" not in ckpt:
                 raise KeyError(f"{checkpoint_path}: not a Lightning checkpoint (no 'state_dict' entry)")
             import inspect

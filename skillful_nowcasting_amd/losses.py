@@ -25,16 +25,17 @@ class GridCellLoss(nn.Module):
 
     def __init__(self, weight_fn=None, precip_weight_cap=24.0):
         """`weight_fn(targets, precip_weight_cap)`: dgmr.dgmr.weight_fn (the default of DGMR) is evaluated inside the loss kernel;
-        any other callable is called on the targets and its result handed to the kernel as explicit weights.  None is rejected:
-        the reference's module cannot run without one either (losses.py:171 wraps it in a lambda that is never None, so
-        `difference * None` raises on the first call)."""
+        any other callable is called on the targets and its result handed to the kernel as explicit weights.  None constructs, as
+        in the reference (losses.py:161-171), and fails at the first call like the reference does: its lambda wrapper is never
+        None, so `difference * None` raises TypeError there (losses.py:187-190)."""
         super().__init__()
-        if weight_fn is None:
-            raise ValueError("GridCellLoss needs a weight_fn (the reference's forward fails without one, dgmr/losses.py:171,187-190)")
         self.precip_weight_cap = precip_weight_cap
         self.weight_fn = weight_fn
 
     def _weights(self, targets):
+        if self.weight_fn is None:
+            raise TypeError("GridCellLoss was built without a weight_fn: unsupported operand type(s) for *: 'Tensor' and 'NoneType' "
+                            "(the reference fails the same way, dgmr/losses.py:171,187-190)")
         if getattr(self.weight_fn, "fused_in_kernel", False):
             return None
         with torch.no_grad():

@@ -180,8 +180,11 @@ def _relayout_hook(module, incompatible_keys=None):
 def _export_hook(module, state_dict, prefix, local_metadata):
     """state_dict post-hook: conv weights leave in the standard contiguous (OIHW) layout, like the reference's, so that
     safetensors / torch.save files interchange with it (safetensors refuses non-contiguous tensors outright).  The parameter itself
-    stays channels-last (what the kernels index).  One copy per parameter and call: DGMR lists its generator parts twice
-    (`sampler.*` and `generator.sampler.*`), both names must keep pointing at ONE tensor or a checkpoint would store it twice."""
+    stays channels-last (what the kernels index).  One copy per parameter and state_dict() CALL: DGMR lists its generator parts
+    twice (`sampler.*` and `generator.sampler.*`), both names must keep pointing at ONE tensor or a checkpoint would store it twice.
+    Nothing is reused across calls: the optimiser kernels write parameters without touching torch's version counter, so a copy
+    kept from an earlier call would be stale (a dict from an earlier call keeps its own, older, tensors - like a checkpoint).
+    A call is recognised by its destination dict, which torch hands to every module's hook of that call."""
     import weakref
 
     for name in ("original", "weight"):
@@ -191,10 +194,10 @@ def _export_hook(module, state_dict, prefix, local_metadata):
             continue
         cache = module.__dict__.setdefault("_export_refs", {})
         hit = cache.get(name)
-        copy = hit[1]() if hit is not None and hit[0] == (t._version, t.data_ptr()) else None
+        copy = hit[1]() if hit is not None and hit[0]() is state_dict else None
         if copy is None:
             copy = t.detach().contiguous()
-            cache[name] = ((t._version, t.data_ptr()), weakref.ref(copy))
+            cache[name] = (weakref.ref(state_dict), weakref.ref(copy))
         state_dict[key] = copy
 
 

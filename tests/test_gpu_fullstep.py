@@ -1,0 +1,168 @@
+"""One whole `DGMR.training_step` at the BENCHMARKED configuration (paper config: 4 -> 18 frames, 256 x 256, latent 768 / context 384,
+6 generator draws) on the HIP path against the CPU oracle's `training_step` (oracle/dgmr_oracle.py, a restatement of
+dgmr/dgmr.py:137-218 pinned to the unmodified reference by tests/test_training_step.py::test_oracle_training_step_matches_reference).
+
+The step goldens under tests/golden/ are T = 2 / 128 x 128 / 2 draws by necessity (they are committed files); the per-network tests of
+tests/test_gpu_fullsize.py run the benchmarked shapes but not the step's orchestration.  This test closes that gap: 2 discriminator
+passes, 6 activation-checkpointed generator draws batched into one launch set and recomputed in reverse order, 6 discriminator calls
+as one batch of call groups, the two Adam updates, the logging forward - i.e. the call-group ordering of every spectral-norm u / v
+and BatchNorm running statistic over 6 x 18 sampler calls and 6 x (8 + 5) discriminator head calls - at the size bench.py times,
+in exact f32 AND in bench.py's default arithmetic ("mixed").
+
+Per-GPU batch 2 instead of bench.py's 16: the CPU oracle needs ~1 min per sample in float32 and ~2.5 min in float64 on the GPU
+box's host.  (B = 1 is degenerate: the discriminator heads' BatchNorm1d over the 2 rows real / generated maps every feature to
++-1/sqrt(1 + eps/var) and the gradients below it vanish; with 4 rows it is a regular batch.)
+
+What is compared (float32 oracle = the reference's arithmetic, float64 oracle = truth):
+  * the three losses `manual_backward` is called on (dgmr.py:163,196) and the returned / logged losses: 1e-3 relative;
+  * every discriminator gradient of the FIRST discriminator pass (the state before any optimiser update) and the generator's
+    last layer (sampler.bn, sampler.conv_1x1): conftest.band_check (within max(tol, factor x the fp32 oracle's own error) of float64);
+  * the discriminator gradients of the second pass (after one Adam update, whose +-lr steps on noise elements differ between any two
+    fp32 implementations): cosine >= 0.9999 and 2e-2 of max;
+  * every buffer after the step (u, v, BatchNorm running mean / var / num_batches_tracked): 1e-3 of the tensor's max - this is what
+    pins the call-group ORDER at the benchmarked size;
+  * the 12 parameters the reference never gives a gradient are untouched.
+"""
+import pytest
+import torch
+
+from conftest import band_check, cos_sim, rel_err
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(forecast_steps=18, output_shape=256, latent_channels=768, context_channels=384, generation_steps=6)
+B = 2
+HP = dict(forecast_steps=18, generation_steps=6, grid_lambda=20.0, gen_lr=5e-5, disc_lr=2e-4, beta1=0.0, beta2=0.999,
+          precip_weight_cap=24.0, latent_shape=(8, 8, 8), num_spatial_frames=8)
+BUFFER_SUFFIXES = ("._u", "._v", "running_mean", "running_var", "num_batches_tracked")
+G_LAST = ("generator.sampler.bn.", "generator.sampler.conv_1x1.")
+
+
+@pytest.fixture(scope="module")
+def initial():
+    import skillful_nowcasting_amd as S
+
+    torch.manual_seed(0)
+    model = S.DGMR(**KW)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(5)
+    x = torch.rand(B, 4, 1, 256, 256)
+    y = torch.rand(B, 18, 1, 256, 256)
+    return model, sd, x, y
+
+
+@pytest.fixture(scope="module")
+def oracle_step(initial):
+    """`O.training_step` from the same state, batch and RNG seed in float32 and float64: losses, captured gradients, post-step state."""
+    from oracle import dgmr_oracle as O
+
+    torch.set_num_threads(min(16, torch.get_num_threads()))  # torch's CPU convs are slowest at the GPU box's default of 128 threads
+    _, sd0, x, y = initial
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        sd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()
+              if k.startswith(("generator.", "discriminator."))}
+        cap = {}
+        torch.manual_seed(44)
+        losses = O.training_step(sd, x.to(dt), y.to(dt), HP, {"step": {}, "m": {}, "v": {}}, cap)
+        keep = {k: g for k, g in cap["g_grads"].items() if k.startswith(G_LAST)}
+        res[dt] = dict(losses=losses, backward_losses=cap["backward_losses"], d_grads=cap["d_grads"], g_last=keep,
+                       g_touched=set(cap["g_grads"]), buffers={k: v.detach().clone() for k, v in sd.items() if k.endswith(BUFFER_SUFFIXES)})
+        del cap
+    return res
+
+
+def _close(got, ref, tol, what):
+    assert abs(got - ref) <= 1e-6 + tol * abs(ref), f"{what}: {got} vs {ref}"
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-3), ("mixed", 2e-3)])
+def test_training_step_paper_config_vs_oracle(initial, oracle_step, precision, tol):
+    import skillful_nowcasting_amd as S
+
+    model, sd0, x, y = initial
+    model = model.to("cuda")
+    model.load_state_dict(sd0)
+    S.ops.bump_weights_epoch()
+    model.train()
+    model.global_iteration = 0
+    if hasattr(model, "_optimizers"):
+        del model._optimizers  # fresh Adam state
+    for p in model.parameters():
+        p.grad = None
+    bw = []
+    orig_backward = model.manual_backward
+    model.manual_backward = lambda loss: (bw.append(loss.detach()), orig_backward(loss))
+    named = {("generator." + k if not k.startswith("discriminator.") else k): p for k, p in model.named_parameters()
+             if not k.startswith("generator.")}
+    g_opt, d_opt = model.optimizers()
+    d_grads, g_grads = [], {}
+
+    def wrap(opt, prefix, sink):
+        orig = opt.step
+
+        def step(*a, **k):
+            snap = {kk: p.grad.detach().clone() for kk, p in named.items() if kk.startswith(prefix) and p.grad is not None}
+            sink(snap)
+            return orig(*a, **k)
+
+        opt.step = step
+
+    wrap(d_opt, "discriminator.", d_grads.append)
+    wrap(g_opt, "generator.", g_grads.update)
+    S.set_precision(precision)
+    try:
+        torch.manual_seed(44)
+        out = model.training_step((x.cuda(), y.cuda()), 0)
+        torch.cuda.synchronize()
+    finally:
+        S.set_precision("f32")
+        model.manual_backward = orig_backward
+    r32, r64 = oracle_step[torch.float32], oracle_step[torch.float64]
+    # ---- losses ----
+    got_bw = [float(v) for v in bw]
+    assert len(got_bw) == 3
+    for i, (g, r) in enumerate(zip(got_bw, r32["backward_losses"])):
+        _close(g, r, 1e-3, f"backward loss {i} (all: {got_bw} vs {r32['backward_losses']})")
+    _close(float(out["d_loss"]), r32["losses"][0], 1e-3, "d_loss")
+    _close(float(out["g_loss"]), r32["losses"][1], 1e-3, "g_loss")
+    _close(float(out["grid_loss"]), r32["losses"][2], 1e-3, "grid_loss")
+    # ---- gradients: first discriminator pass + the generator's last layer, float64-anchored band ----
+    assert len(d_grads) == 2
+    rows = {}
+    for k, g64 in r64["d_grads"][0].items():
+        if g64.abs().max().item() == 0.0:
+            assert k not in d_grads[0] or d_grads[0][k].abs().max().item() == 0.0, k
+            continue
+        rows["D pass 1 " + k[len("discriminator."):]] = (d_grads[0][k].cpu().float().reshape(g64.shape), r32["d_grads"][0][k], g64)
+    for k, g64 in r64["g_last"].items():
+        rows["G " + k[len("generator."):]] = (g_grads[k].cpu().float().reshape(g64.shape), r32["g_last"][k], g64)
+    band_check(f"training_step, paper config, B = {B}", precision, tol, rows)
+    # ---- second discriminator pass (after one Adam update) ----
+    worst = (0.0, 1.0, "")
+    for k, g64 in r64["d_grads"][1].items():
+        if g64.abs().max().item() == 0.0:
+            continue
+        got = d_grads[1][k].cpu().float().reshape(g64.shape)
+        e, c = rel_err(got, g64), cos_sim(got, g64)
+        if e > worst[0]:
+            worst = (e, c, k)
+        assert e <= 2e-2 and c >= 0.9999, f"D pass 2 {k}: rel err {e:.2e}, cosine {c}"
+    print(f"\nD pass 2 [{precision}]: worst gradient {worst[2]} rel err {worst[0]:.2e} (cosine {worst[1]:.7f})")
+    # ---- the same parameters receive gradients; the 12 the reference never touches stay untouched ----
+    assert {k for k in g_grads} == {k for k in r32["g_touched"]}, "generator parameters with a gradient differ from the reference's"
+    dead = [k for k, p in model.named_parameters() if p.grad is None]
+    assert len(dead) == 12, dead
+    # ---- every buffer after the step ----
+    sd1 = model.state_dict()
+    bad = []
+    for k, ref in r32["buffers"].items():
+        got = sd1[k].detach().cpu()
+        if not ref.is_floating_point():
+            assert torch.equal(got, ref), f"{k}: {got} vs {ref}"
+            continue
+        scale = ref.abs().max().item()
+        err = (got.float() - ref).abs().max().item()
+        if err > 1e-3 * scale + 1e-6:
+            bad.append((k, err / max(scale, 1e-30)))
+    assert not bad, f"{len(bad)} buffers beyond 1e-3 of their max after the step: {sorted(bad, key=lambda t: -t[1])[:8]}"

@@ -203,6 +203,56 @@ def test_radar_batch_loader_cpu(dtype):
     assert len(list(data.RadarBatchLoader(rows, batch_size=2))) == 2  # drop_last
 
 
+@pytest.mark.gpu
+def test_radar_batch_loader_gpu_matches_cpu_path():
+    """The device path of the loader (pinned double-buffered slots, H2D copies on a side stream, fp32 conversion on the device;
+    reference semantics train/run.py:118-158) against the CPU path, on uint8 rows and enough batches for every slot to be REUSED
+    several times while earlier uploads may still be in flight (the host waits for a slot's previous copy before refilling it)."""
+    from skillful_nowcasting_amd import data
+
+    rng = np.random.default_rng(3)
+    rows = [{"radar_frames": rng.integers(0, 255, (26, 64, 64, 1), dtype=np.uint8)} for _ in range(6 * 8 + 3)]
+    cpu = list(data.RadarBatchLoader(rows, batch_size=8, scale=1 / 32.0, drop_last=False))
+    dev = []
+    for images, future in data.RadarBatchLoader(rows, batch_size=8, device="cuda", scale=1 / 32.0, drop_last=False):
+        assert images.is_cuda and images.dtype == torch.float32
+        # a consumer that lags behind the producer: the loader has already refilled the other slot when this batch is read
+        torch.cuda._sleep(20_000_000)
+        dev.append((images.clone(), future.clone()))
+    torch.cuda.synchronize()
+    assert len(dev) == len(cpu) == 7
+    for (ci, cf), (di, df) in zip(cpu, dev):
+        assert torch.equal(ci, di.cpu()) and torch.equal(cf, df.cpu())
+
+
+def test_state_dict_is_current_after_an_optimiser_update_while_an_older_dict_is_alive():
+    """conv weights are exported as contiguous copies; a copy kept alive by an earlier state_dict() must not be handed
+    out again after the parameters changed (the optimiser kernels write parameters without bumping torch's version counter)."""
+    torch.manual_seed(0)
+    conv = S.common.DBlock(4, 8)
+    sd1 = conv.state_dict()
+    key = next(k for k in sd1 if k.endswith("first_conv_3x3.parametrizations.weight.original"))
+    before = sd1[key].clone()
+    with torch.no_grad():
+        conv.first_conv_3x3.weight_orig.data.add_(1.0)  # out-of-band write: no version bump, exactly what the Adam kernel does
+    sd2 = conv.state_dict()
+    assert sd2[key] is not sd1[key]
+    assert torch.equal(sd2[key], before + 1.0) and torch.equal(sd1[key], before)
+    assert sd2[key].is_contiguous()
+    # within ONE call the aliased names of DGMR still share a tensor (a checkpoint must not store the generator twice)
+    model = S.DGMR(forecast_steps=2, output_shape=128, latent_channels=384, context_channels=192, generation_steps=2)
+    sd = model.state_dict()
+    k = "sampler.g1.first_conv_3x3.parametrizations.weight.original"
+    assert sd[k] is sd["generator." + k]
+
+
+def test_grid_cell_loss_without_weight_fn_constructs_like_the_reference():
+    """dgmr/losses.py:161-190: GridCellLoss() constructs; its forward fails with a TypeError (`difference * None`)."""
+    loss = S.losses.GridCellLoss()
+    with pytest.raises(TypeError):
+        loss(torch.zeros(1, 2, 1, 4, 4), torch.zeros(1, 2, 1, 4, 4))
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # visualisation (dgmr/dgmr.py:302-327)
 # ------------------------------------------------------------------------------------------------------------------------------
