@@ -237,6 +237,8 @@ class DGMR(
                 finish_d_step()
             d_opt.zero_grad()
             discriminator_loss = self._disc_losses(images, future_images, predictions)
+            if self.grad_sync is not None:
+                self.grad_sync.begin("d")  # gradient buckets are all-reduced as the backward pass completes them (ddp.py)
             with ops.defer_side_join():
                 self.manual_backward(discriminator_loss)
             d_step_pending = True
@@ -252,6 +254,8 @@ class DGMR(
         try:
             generator_loss, grid_cell_reg = self._gen_losses(images, future_images, predictions)
             g_opt.zero_grad()
+            if self.grad_sync is not None:
+                self.grad_sync.begin("g")
             self.manual_backward(generator_loss)
             if self.grad_sync is not None:
                 self.grad_sync.sync("g")
@@ -295,11 +299,12 @@ class DGMR(
         out = self._generate(images.float(), k, grad=False)
         return out.view(k, images.shape[0], *out.shape[1:])
 
-    def attach_data_parallel(self, process_group=None, chunk_mb: int = 64):
-        """One-process-per-GPU data parallelism: flat gradient buffers + RCCL all-reduce after each backward."""
+    def attach_data_parallel(self, process_group=None, chunk_mb: int = 64, overlap: bool = True):
+        """One-process-per-GPU data parallelism: flat gradient buffers, RCCL all-reduce of 64 MB buckets launched while the backward
+        pass is still running (`overlap`), buffers broadcast from rank 0 once per step."""
         from .ddp import GradSync
 
-        self.grad_sync = GradSync(self, process_group, chunk_mb)
+        self.grad_sync = GradSync(self, process_group, chunk_mb, overlap)
         g_opt, d_opt = self.optimizers()
         g_opt.flat_grads = self.grad_sync.gen
         d_opt.flat_grads = self.grad_sync.disc

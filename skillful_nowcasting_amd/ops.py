@@ -297,10 +297,28 @@ def _dims(x: torch.Tensor):
     return n, c, d, h, w
 
 
+_GRAD_TOUCH_HOOK = [None]
+
+
+def set_grad_touch_hook(fn):
+    """fn(p) is called whenever a kernel is about to accumulate into p.grad (None: off).  ddp.GradSync uses the sequence of these
+    "touches" to launch each gradient bucket's all-reduce as soon as the backward pass is done with it."""
+    _GRAD_TOUCH_HOOK[0] = fn
+
+
+def side_streams(device) -> List["torch.cuda.Stream"]:
+    """The weight-gradient / branch streams of `device` that exist so far (ddp: a collective must be ordered behind them)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return [st for (i, _lane), st in _SIDE_STREAMS.items() if i == idx] + [st for i, st in _BRANCH_STREAMS.items() if i == idx]
+
+
 def grad_buffer(p: torch.Tensor) -> torch.Tensor:
-    """``p.grad`` with p's physical layout, zero-initialised on first touch."""
+    """``p.grad`` with p's physical layout, zero-initialised on first touch.  THE way a kernel launch obtains the destination of a
+    parameter gradient (see set_grad_touch_hook)."""
     if p.grad is None:
         p.grad = torch.zeros_like(p)  # preserve_format: same strides as the parameter
+    if _GRAD_TOUCH_HOOK[0] is not None:
+        _GRAD_TOUCH_HOOK[0](p)
     return p.grad
 
 

@@ -5,7 +5,11 @@ What is checked (no kernel runs: gradients are filled by hand, as the HIP kernel
   * ``sync('d')`` averages ONLY the discriminator buffer, ``sync('g')`` only the generator's;
   * the 12 parameters that never receive a gradient stay zero and do not stall anything;
   * ``broadcast_parameters`` / ``broadcast_buffers`` make rank 1 identical to rank 0;
-  * ``FusedAdam.zero_grad`` keeps the views attached.
+  * ``FusedAdam.zero_grad`` keeps the views attached;
+  * overlap: the first backward of a kind records the order in which kernels obtain their gradient destinations
+    (``ops.grad_buffer``); in the next one every bucket is all-reduced as soon as the recorded sequence has passed it, the result is
+    identical to the post-backward reduction (``check_exchange`` verifies every bucket bit for bit), a backward that deviates from
+    the recording falls back to the late reduction, and a write into an already-launched bucket raises.
 """
 import os
 import socket
@@ -89,6 +93,69 @@ def _worker(rank, world, port, q):
         sync.gen.flat.copy_(torch.arange(sync.gen.flat.numel(), dtype=torch.float32) * (rank + 1))
         sync.sync("g")
         assert torch.allclose(sync.gen.flat, torch.arange(sync.gen.flat.numel(), dtype=torch.float32) * 1.5)
+        # --- overlapped exchange: buckets launched during the "backward" in the order the recorded touch sequence completes them
+        from skillful_nowcasting_amd import ops
+
+        sync.chunk = 200_000  # several buckets per network
+        sync.check_exchange = True
+        g_params = [p for p in sync.gen.params if id(p) not in dead_ids]
+        order = list(reversed(g_params))  # a backward pass walks the layers back to front
+
+        def backward(params, val):
+            for i, p in enumerate(params):
+                ops.grad_buffer(p).add_(val * (1.0 + (i % 7)))  # the touch, then the "kernel"
+
+        nb = sync._nbuckets(sync.gen)
+        assert nb >= 4
+        for it in range(3):
+            g_opt.zero_grad()
+            sync.begin("g")
+            backward(order, float(rank + 1))
+            launched_early = len(sync._launched)
+            sync.sync("g")
+            expect = torch.zeros_like(sync.gen.flat)
+            for i, p in enumerate(order):
+                off = sync.gen.offset[id(p)]
+                expect[off:off + p.numel()] = 1.5 * (1.0 + (i % 7))
+            assert torch.allclose(sync.gen.flat, expect), f"pass {it}: overlapped exchange differs from the mean over ranks"
+            if it == 0:
+                assert launched_early == 0 and sync._passes["g"].recorded is not None  # recording pass: nothing launched early
+            else:
+                assert launched_early >= nb - 2, (it, launched_early, nb)  # all but the front buckets went out during the backward
+        assert sync.stats["overlapped_buckets"] > 0 and sync.stats["deviations"] == 0
+        # --- a backward in another order: falls back to the late reduction, same result
+        g_opt.zero_grad()
+        sync.begin("g")
+        backward(g_params, float(rank + 1))  # front to back: deviates at the first touch
+        sync.sync("g")
+        assert sync.stats["deviations"] == 1
+        expect = torch.zeros_like(sync.gen.flat)
+        for i, p in enumerate(g_params):
+            off = sync.gen.offset[id(p)]
+            expect[off:off + p.numel()] = 1.5 * (1.0 + (i % 7))
+        assert torch.allclose(sync.gen.flat, expect)
+        # --- a write into a bucket whose all-reduce is already under way must raise, never pass silently
+        g_opt.zero_grad()
+        sync.begin("g")
+        backward(order, 1.0)
+        raised = False
+        try:
+            ops.grad_buffer(order[0])  # the last layer again, long after its bucket went out
+        except RuntimeError as e:
+            raised = "after its all-reduce had been launched" in str(e)
+        assert raised
+        sync.sync("g")
+        # --- buffers are views of one flat tensor: ONE broadcast, and the modules see the result
+        with torch.no_grad():
+            for b in sync._buffers:
+                b.add_(float(rank))
+        sync.broadcast_buffers()
+        bufs = torch.cat([b.reshape(-1).float() for b in sync._buffers])
+        refb = bufs.clone()
+        dist.broadcast(refb, src=0)
+        assert torch.equal(bufs, refb)
+        assert all(b.data_ptr() >= sync._buf_flat.data_ptr() and b.data_ptr() < sync._buf_flat.data_ptr() + 4 * sync._buf_flat.numel()
+                   for b in sync._buffers)
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
