@@ -429,6 +429,10 @@ int dgmr_profile_collect2(double* total_ms, double* total_flops, double* execute
  * 256-pixel tiles / 3 the LDS-DMA window kernel where eligible (what -1 picks, but also below the automatic size threshold);
  * wgrad_window = 0 never / 1 (= automatic) the LDS-window weight-gradient kernel wherever the geometry allows. */
 int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window);
+/* Kernel-phase timing switches for tools/conv_bench.py (process-wide, 0 at load and in every product launch): bit 0 = the LDS-window
+ * conv kernels return before their epilogue, bit 1 = they stage only their first input halo.  Outputs are then garbage by design;
+ * only the launch duration is meaningful (how much of a launch is operand staging / matrix work / epilogue). */
+int dgmr_debug_flags(int flags);
 
 #ifdef __cplusplus
 }

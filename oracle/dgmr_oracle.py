@@ -103,6 +103,18 @@ def batchnorm(sd: SD, prefix: str, x: torch.Tensor, train: bool, eps: float = 1e
 # --------------------------------------------------------------------------------------
 # blocks — dgmr/common.py
 # --------------------------------------------------------------------------------------
+# Tests only: RELU_HOOK(x, tag) replaces relu at the discriminator's kinks (tag = "<block prefix>in" / "<block prefix>mid" /
+# "<discriminator prefix>head").  tests/conftest.py::KinkAligner uses it to evaluate the oracle on the SAME linear piece the
+# implementation under test was on (x * mask with the implementation's own mask): a pre-activation within fp32 rounding of zero
+# otherwise puts two correct implementations on different pieces of a piecewise-linear function, and behind the heads' BatchNorm1d
+# that one element moves every gradient below it.  None (the default) = plain relu, i.e. the reference's arithmetic.
+RELU_HOOK = None
+
+
+def _relu(x: torch.Tensor, tag: str) -> torch.Tensor:
+    return F.relu(x) if RELU_HOOK is None else RELU_HOOK(x, tag)
+
+
 def dblock(sd: SD, p: str, x: torch.Tensor, train: bool, first_relu: bool = True, keep_same_output: bool = False):
     """dgmr/common.py:220-238 (DBlock.forward), 2-D and "3d" variants (AvgPool2d/3d k=2)."""
     w = sd[p + "first_conv_3x3.parametrizations.weight.original"]
@@ -114,9 +126,9 @@ def dblock(sd: SD, p: str, x: torch.Tensor, train: bool, first_relu: bool = True
             x1 = pool(x1)
     else:
         x1 = x
-    h = F.relu(x) if first_relu else x
+    h = _relu(x, p + "in") if first_relu else x
     h = sn_conv(sd, p + "first_conv_3x3.", h, train)
-    h = F.relu(h)
+    h = _relu(h, p + "mid")
     h = sn_conv(sd, p + "last_conv_3x3.", h, train)
     if not keep_same_output:
         h = pool(h)
@@ -264,7 +276,7 @@ def _count_children(sd: SD, prefix: str) -> int:
 
 
 def _d_head(sd: SD, p: str, rep: torch.Tensor, train: bool):
-    rep = torch.sum(F.relu(rep), dim=[2, 3])
+    rep = torch.sum(_relu(rep, p + "head"), dim=[2, 3])
     rep = batchnorm(sd, p + "bn.", rep, train)
     w = sn_weight(sd, p + "fc.", train)
     return F.linear(rep, w, sd[p + "fc.bias"])

@@ -114,6 +114,7 @@ SIGNATURES = {
     "dgmr_conv_pool2_supported": [POINTER(ConvArgs)],
     "dgmr_split_weights": [P, P, L, i, i, i, i, P],
     "dgmr_set_precision": [i],
+    "dgmr_debug_flags": [i],
     "dgmr_get_precision": [],
     "dgmr_profile_enable": [i],
     "dgmr_conv_tune": [i, i, i, i],

@@ -292,6 +292,7 @@ const char* const kVariantNames[V_COUNT] = {
     (g_precision == 1 ? dgmr_tu::fn##_ns3(__VA_ARGS__) : (g_precision == 2 ? dgmr_tu::fn##_ns1(__VA_ARGS__) : dgmr_tu::fn##_ns6(__VA_ARGS__)))
 // dgmr_conv_tune(): -1 = automatic
 int g_tune_variant = -1, g_tune_ksplit = -1, g_tune_window = -1, g_tune_wgrad_window = -1;
+int g_debug_flags = 0;  // dgmr_debug_flags(): kernel-phase timing switches of tools/conv_bench.py, 0 in every product launch
 bool g_m16_auto = true;  // 16-column blocks for <= 48 output channels: measured +14 ... +28 % on the 48-channel layers (tune window 3 = the 64-column tile)
 
 // WM x WN: wave grid of the f32 kernel (the bf16 kernels of the same tile: tu_gemm.hip)
@@ -664,6 +665,7 @@ extern "C" int dgmr_conv_pool2_supported(const dgmr_conv_args* a) {
 
 static void conv_args_defaults(dgmr_conv_args& p) {
     p.reserved0 = 0;
+    p.reserved1 = g_debug_flags;
     if (p.scale_group < 1) p.scale_group = 1;
     if (p.pre_group < 1) p.pre_group = 1;
     if (p.mask_group < 1) p.mask_group = 1;
@@ -1019,6 +1021,12 @@ extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_win
     g_tune_ksplit = ksplit;
     g_tune_window = window;
     g_tune_wgrad_window = wgrad_window;
+    return 0;
+}
+
+extern "C" int dgmr_debug_flags(int flags) {
+    DGMR_CHECK_ARG(flags >= 0 && flags <= 3, "dgmr_debug_flags: %d", flags);
+    g_debug_flags = flags;
     return 0;
 }
 

@@ -141,8 +141,14 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
     const uint32_t grp_off = (uint32_t)(smp / p.pre_group) * p.Cin;
     const uint32_t plane_elems = (uint32_t)Hs * Ws * p.Cin;
 
+    // measurement switches (dgmr_debug_flags, tools/conv_bench.py --dbg=): 1 = return before the epilogue, 2 = stage only the first halo -
+    // the MFMA loop then runs on stale LDS contents; results are garbage, only the timing is meaningful.  0 in every product launch.
+    const int dbg = p.reserved1;
+    bool staged_once = false;
     // fetch, transform and store one 32-channel halo (latency covered by the other workgroups); kd: depth tap of a 3-D conv
     auto stage_a = [&](int chunk, int kd, uint32_t view_off = 0u) {  // view_off: element offset of a parity plane (pooled mode)
+        if ((dbg & 2) && staged_once) return;
+        staged_once = true;
         f32x4 ra[APASS];
         const int cb = chunk * CK + cq * 4;
         const int dz = KD == 3 ? kd - 1 : 0;
@@ -343,6 +349,15 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
     }
 
     // ---- epilogue (conv3x3_win_kernel's) ----
+    if (dbg & 1) {  // (the accumulators must stay live: a store that never happens for finite sums)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) t += acc[i][j][0];
+        if (t == 123456.789f) p.y[0] = t;
+        return;
+    }
     const float sc = p.scale ? p.scale[smp / p.scale_group] : 1.f;
     float bj[TN];
     int colj[TN];

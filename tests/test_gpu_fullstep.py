@@ -16,11 +16,17 @@ box's host.  (B = 1 is degenerate: the discriminator heads' BatchNorm1d over the
 What is compared (float32 oracle = the reference's arithmetic, float64 oracle = truth):
   * the three losses `manual_backward` is called on (dgmr.py:163,196) and the returned / logged losses: 1e-3 relative;
   * every discriminator gradient of the FIRST discriminator pass (the state before any optimiser update) and the generator's
-    last layer (sampler.bn, sampler.conv_1x1): conftest.band_check (within max(tol, factor x the fp32 oracle's own error) of float64);
+    last layer (sampler.bn, sampler.conv_1x1): conftest.band_check (within max(tol, factor x the fp32 oracle's own error) of float64;
+    relu flips by count with a one-channel allowance - the oracle's step cannot be re-run on the implementation's relu masks per
+    arithmetic mode at ~8 min a run; the mask-aligned, allowance-free gradient check of the discriminator at this configuration is
+    tests/test_gpu_fullsize.py::test_discriminator_fwd_bwd_paper_config);
   * the discriminator gradients of the second pass (after one Adam update, whose +-lr steps on noise elements differ between any two
     fp32 implementations): cosine >= 0.9999 and 2e-2 of max;
-  * every buffer after the step (u, v, BatchNorm running mean / var / num_batches_tracked): 1e-3 of the tensor's max - this is what
-    pins the call-group ORDER at the benchmarked size;
+  * every buffer after the step (u, v, BatchNorm running mean / var / num_batches_tracked): within max(1e-3, factor x the distance
+    between the float32 and the float64 oracle) of the float64 oracle, relative to the tensor's max (the BatchNorm1d running variance
+    of the heads over 4 near-identical rows and the u / v of weights that took an Adam step of +-lr per element are the
+    ill-conditioned ones: the two oracles themselves differ by up to 2e-3 there) - this is what pins the call-group ORDER at the
+    benchmarked size: a swapped pair of calls moves u / v and the running statistics by 1e-1 ... 1;
   * the 12 parameters the reference never gives a gradient are untouched.
 """
 import pytest
@@ -137,7 +143,7 @@ def test_training_step_paper_config_vs_oracle(initial, oracle_step, precision, t
         rows["D pass 1 " + k[len("discriminator."):]] = (d_grads[0][k].cpu().float().reshape(g64.shape), r32["d_grads"][0][k], g64)
     for k, g64 in r64["g_last"].items():
         rows["G " + k[len("generator."):]] = (g_grads[k].cpu().float().reshape(g64.shape), r32["g_last"][k], g64)
-    band_check(f"training_step, paper config, B = {B}", precision, tol, rows)
+    band_check(f"training_step, paper config, B = {B}", precision, tol, rows, flips_row=True)
     # ---- second discriminator pass (after one Adam update) ----
     worst = (0.0, 1.0, "")
     for k, g64 in r64["d_grads"][1].items():
@@ -154,15 +160,20 @@ def test_training_step_paper_config_vs_oracle(initial, oracle_step, precision, t
     dead = [k for k, p in model.named_parameters() if p.grad is None]
     assert len(dead) == 12, dead
     # ---- every buffer after the step ----
+    factor = 10.0 if precision == "mixed" else 3.0
     sd1 = model.state_dict()
-    bad = []
-    for k, ref in r32["buffers"].items():
+    bad, worst = [], (0.0, "")
+    for k, ref in r64["buffers"].items():
         got = sd1[k].detach().cpu()
         if not ref.is_floating_point():
             assert torch.equal(got, ref), f"{k}: {got} vs {ref}"
             continue
-        scale = ref.abs().max().item()
-        err = (got.float() - ref).abs().max().item()
-        if err > 1e-3 * scale + 1e-6:
-            bad.append((k, err / max(scale, 1e-30)))
-    assert not bad, f"{len(bad)} buffers beyond 1e-3 of their max after the step: {sorted(bad, key=lambda t: -t[1])[:8]}"
+        scale = max(ref.abs().max().item(), 1e-30)
+        err = (got.double() - ref).abs().max().item() / scale
+        band = (r32["buffers"][k].double() - ref).abs().max().item() / scale
+        if err > worst[0]:
+            worst = (err, k)
+        if err > max(1e-3, factor * band) + 1e-9:
+            bad.append((k, err, band))
+    print(f"buffers after the step [{precision}]: worst {worst[1]} at {worst[0]:.2e} of its max")
+    assert not bad, f"{len(bad)} buffers beyond max(1e-3, {factor:g} x fp32 band) after the step: {sorted(bad, key=lambda t: -t[1])[:8]}"

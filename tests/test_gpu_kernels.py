@@ -57,7 +57,7 @@ def test_window_conv_variants_agree(tuned, n, h, w, cin, cout, up, bn, res):
     b = torch.randn(n * cin, device=DEV) * 0.1
     r = torch.randn(n * h * w * cout, device=DEV) if res else None
     wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
-    call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, ops._stream())
+    call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, 2, ops._stream())
     ys = {}
     # register-staged window, LDS-DMA window, the same with private per-wave weight slices (no barrier between taps; 128- and
     # 64-column tiles), with 256-pixel tiles (where eligible), implicit GEMM
@@ -113,7 +113,7 @@ def test_upsample_phases_match_upsampled_conv(n, h, w, cin, cout, bn, res, prec)
     S.set_precision(prec)
     try:
         wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
-        call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, ops._stream())
+        call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, 2, ops._stream())
         sums = torch.empty(16 * cout * cin, device=DEV)
         call("dgmr_upsample_phase_weights", wt.data_ptr(), sums.data_ptr(), cout, cin, ops._stream())
         # the tap sums themselves, against torch
@@ -124,7 +124,7 @@ def test_upsample_phases_match_upsampled_conv(n, h, w, cin, cout, bn, res, prec)
                             for py in (0, 1) for px in (0, 1)], 0)  # [4][Cout][2][2][Cin]
         assert torch.allclose(sums.view(4, cout, 2, 2, cin), want, rtol=0, atol=1e-6)
         wph = torch.empty(2 * sums.numel(), device=DEV, dtype=torch.int16)
-        call("dgmr_split_weights", sums.data_ptr(), wph.data_ptr(), 16 * cout, cin, 0, 0, ops._stream())
+        call("dgmr_split_weights", sums.data_ptr(), wph.data_ptr(), 16 * cout, cin, 0, 0, 2, ops._stream())
         ys = []
         for ph in (None, wph):
             y = torch.full((n * h * w * cout,), float("nan"), device=DEV)
@@ -167,7 +167,7 @@ def test_window_conv3d_matches_implicit_gemm(tuned, n, d, h, w, cin, cout, relu,
     scale = torch.rand(n, device=DEV) + 0.5
     r = torch.randn(n * d * h * w * cout, device=DEV) if res else None
     wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
-    call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 27, cin, 0, 0, ops._stream())
+    call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 27, cin, 0, 0, 2, ops._stream())
     ys = {}
     for mode in (3, 0):
         tuned(-1, -1, mode, -1)

@@ -69,6 +69,16 @@ SHAPES = [
     ("full up_g2.first", 1728, 1, 32, 32, 384, 384, (1, 3, 3), True, True),
     ("full up_g3.first", 1728, 1, 64, 64, 192, 192, (1, 3, 3), True, True),
     ("full up_g4.first", 1728, 1, 128, 128, 96, 96, (1, 3, 3), True, True),
+    # launch-size sweep of the dominant layer (308 TF at N = 1728 against 484 at N = 288 / 576 inside the step)
+    ("nsweep up_g4.first N576", 576, 1, 128, 128, 96, 96, (1, 3, 3), True, True),
+    ("nsweep up_g4.first N864", 864, 1, 128, 128, 96, 96, (1, 3, 3), True, True),
+    # plain 3x3 layers of the sampler at the full draw batch
+    ("full g4.first", 1728, 1, 64, 64, 96, 96, (1, 3, 3), False, True),
+    ("full up_g3.last", 1728, 1, 64, 64, 192, 96, (1, 3, 3), False, True),
+    ("full g3.first", 1728, 1, 32, 32, 192, 192, (1, 3, 3), False, True),
+    ("full g2.first", 1728, 1, 16, 16, 384, 384, (1, 3, 3), False, True),
+    ("full up_g4.last", 1728, 1, 128, 128, 96, 48, (1, 3, 3), False, True),
+    ("half up_g4.last", 576, 1, 128, 128, 96, 48, (1, 3, 3), False, True),
 ]
 
 
@@ -99,6 +109,8 @@ def main():
             ops.set_precision(a.split("=")[1])
         if a.startswith("--tune="):  # variant,ksplit,window for dgmr_conv_tune
             call("dgmr_conv_tune", *[int(v) for v in a.split("=")[1].split(",")])
+        if a.startswith("--dbg="):  # kernel-phase timing switches: 1 no epilogue, 2 one halo only, 3 both (dgmr_debug_flags)
+            call("dgmr_debug_flags", int(a.split("=")[1]))
     print("precision:", ops.get_precision(), flush=True)
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     
