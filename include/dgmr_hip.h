@@ -103,6 +103,14 @@ typedef struct dgmr_conv_args {
                                 writing the full-resolution gradient.  Needs w_phase = dgmr_pool2_phase_weights + dgmr_split_weights
                                 ([2][Cout][16][Cin]) and a conv the window kernel takes: ask dgmr_conv_pool2_supported. */
     int32_t reserved1;
+    /* -- ABI 8 -- DGMR_EPI_GRU_GATES2: the ConvGRU's read AND update gate convs in one launch (ConvGRU.py:69-76: both convolve the same
+       cat[x, h]); see the define below */
+    const float* scale2;     /* 1/sigma of the second (update) gate conv, indexed like `scale` */
+    const float* bias2;      /* [gru_split] */
+    const float* addend2;    /* [M][gru_split], or NULL */
+    float* y2;               /* [M][gru_split]: the update gate's pre-activation */
+    int32_t gru_split;       /* C: output columns [0, C) are the read gate's, [C, 2C) the update gate's; Cout == 2 C, C % 4 == 0 */
+    int32_t reserved2;
 } dgmr_conv_args;
 
 /* ---- the sampler's output layer: relu(BatchNorm(x)) -> 1x1 conv to 4 channels (generators.py:159-166), streaming fp32 kernels ----
@@ -139,6 +147,8 @@ int dgmr_pool2_phase_weights(const float* w, float* out, int Cout, int Cin, void
  * w + px - 1 + b) when the conv runs on the nearest-2x upsampled map at output pixel (2h + py, 2w + px): ky in {0} | {1,2} for py = 0,
  * a = 0 | 1; {0,1} | {2} for py = 1; kx likewise.  w: [Cout][3][3][Cin] fp32 (channels-last OIHW); out: [4*Cout][2][2][Cin] fp32. */
 int dgmr_upsample_phase_weights(const float* w, float* out, int Cout, int Cin, void* stream);
+/* 1 when dgmr_conv_fwd accepts these arguments with epi_mode = DGMR_EPI_GRU_GATES2 in the current arithmetic mode (host arithmetic only) */
+int dgmr_conv_gates2_supported(const dgmr_conv_args* a);
 
 /* Number of partial-sum rows dgmr_conv_fwd writes to stats_out for these arguments (host arithmetic, no launch): 0 when the kernel
  * the library would dispatch has no fused statistics (only the LDS-window 3x3 kernels of the bf16 modes do), then stats_out must
@@ -148,12 +158,21 @@ int dgmr_conv_stats_rows(const dgmr_conv_args* a);
 #define DGMR_EPI_PLAIN 0
 #define DGMR_EPI_GRU_GATE 1  /* pre_out = v ; y = sigmoid(v) * gru_h                              (ConvGRU.py:69-71,78) */
 #define DGMR_EPI_GRU_BLEND 2 /* pre_out = v ; y = s*gru_h + (1-s)*relu(v), s = sigmoid(gru_pu)     (ConvGRU.py:80-84) */
+/* Read and update gate of one ConvGRU step fused (ConvGRU.py:69-76): ONE conv with Cout = 2 C output columns whose weights (w_split
+ * rows) are the read gate's [0, C) followed by the update gate's [C, 2C) - the input halo (h, or cat[x, h]) is staged once for both.
+ * Every tensor of the epilogue has C channels per pixel:
+ *   column c <  C:  v = (acc + addend[m][c]) * scale[g] + bias[c];        pre_out[m][c] = v (if given);  y[m][c] = sigmoid(v) * gru_h[m][c]
+ *   column c >= C:  v = (acc + addend2[m][c-C]) * scale2[g] + bias2[c-C];  y2[m][c-C] = v
+ * Only for convs the LDS-DMA window kernel takes, with 16-byte aligned tensors: ask dgmr_conv_gates2_supported first. */
+#define DGMR_EPI_GRU_GATES2 3
 
 /* out[k][i] = bf16(w_i - out[0][i] - ... - out[k-1][i]), k < planes, for the [rows][Cin] slice [w_coff, w_coff+Cin) of a
  * [rows][w_cin] weight matrix (rows = Cout * taps; w_cin == 0: dense).  Cin must be even.  planes: 2 for DGMR_PREC_BF16X3 /
  * DGMR_PREC_BF16, 3 for DGMR_PREC_BF16X6 (three bf16 hold all 24 mantissa bits: the planes sum to w exactly).  Valid until the
- * weights change.  (ABI 8: `planes` added.) */
-int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, int w_cin, int w_coff, int planes, void* stream);
+ * weights change.  plane_stride: elements between two planes of `out` (0: dense, rows * Cin) - lets several weight tensors share one
+ * plane set (the fused ConvGRU gates: the read gate's rows followed by the update gate's).  (ABI 8: `planes`, `plane_stride` added.) */
+int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, int w_cin, int w_coff, int planes, int64_t plane_stride,
+                       void* stream);
 
 /* Arithmetic of the forward / data-gradient contraction (process-wide; tensors in HBM stay fp32, accumulation is fp32):
  *   DGMR_PREC_F32     exact fp32 on v_mfma_f32_32x32x2_f32 (157 TF peak) -- the parity mode

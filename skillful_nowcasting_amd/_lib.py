@@ -28,6 +28,7 @@ class ConvArgs(Structure):
         ("w_cin", c_int32), ("w_coff", c_int32), ("epi_mode", c_int32), ("ksplit", c_int32),
         ("gru_h", P), ("gru_pu", P), ("pre_out", P), ("splitk_ws", P), ("splitk_ws_bytes", c_int64), ("w_split", P),
         ("residual_up", c_int32), ("reserved0", c_int32), ("stats_out", P), ("w_phase", P), ("pool2", c_int32), ("reserved1", c_int32),
+        ("scale2", P), ("bias2", P), ("addend2", P), ("y2", P), ("gru_split", c_int32), ("reserved2", c_int32),
     ]
 
 
@@ -112,7 +113,8 @@ SIGNATURES = {
     "dgmr_head_bwd_sums": [P, P, P, P, P, P, P, P, P, L, L, i, P],
     "dgmr_head_bwd_apply": [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, i, i, P],
     "dgmr_conv_pool2_supported": [POINTER(ConvArgs)],
-    "dgmr_split_weights": [P, P, L, i, i, i, i, P],
+    "dgmr_split_weights": [P, P, L, i, i, i, i, L, P],
+    "dgmr_conv_gates2_supported": [POINTER(ConvArgs)],
     "dgmr_set_precision": [i],
     "dgmr_debug_flags": [i],
     "dgmr_get_precision": [],

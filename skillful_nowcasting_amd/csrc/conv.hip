@@ -669,7 +669,7 @@ static void conv_args_defaults(dgmr_conv_args& p) {
     p.reserved1 = g_debug_flags & 3;
     // bit 2: the window kernels may use their 16-byte epilogue (conv_win_glds.h) - four consecutive output channels per lane
     if (!(g_debug_flags & 8) && p.Cout % 4 == 0 && al16(p.y) && al16(p.bias) && al16(p.addend) && al16(p.residual) && al16(p.mask_src) &&
-        al16(p.mask_a) && al16(p.mask_b) && al16(p.gru_h) && al16(p.gru_pu) && al16(p.pre_out))
+        al16(p.mask_a) && al16(p.mask_b) && al16(p.gru_h) && al16(p.gru_pu) && al16(p.pre_out) && al16(p.bias2) && al16(p.addend2) && al16(p.y2))
         p.reserved1 |= 4;
     if (p.scale_group < 1) p.scale_group = 1;
     if (p.pre_group < 1) p.pre_group = 1;
@@ -678,6 +678,20 @@ static void conv_args_defaults(dgmr_conv_args& p) {
         p.w_cin = p.Cin;
         p.w_coff = 0;
     }
+}
+
+// DGMR_EPI_GRU_GATES2 lives in the LDS-DMA window kernel's 16-byte epilogue only
+static bool gates2_ok(const dgmr_conv_args& p) {
+    WinPlan w;
+    return p.epi_mode == DGMR_EPI_GRU_GATES2 && p.gru_split > 0 && p.gru_split % 4 == 0 && p.Cout == 2 * p.gru_split && p.gru_h && p.y2 &&
+           !p.upsample && !p.pool2 && !p.residual && !p.mask_src && !p.stats_out && (p.reserved1 & 4) && window_plan(p, &w) && w.glds;
+}
+
+extern "C" int dgmr_conv_gates2_supported(const dgmr_conv_args* a) {
+    if (!a || a->N <= 0 || a->H <= 0 || a->W <= 0 || a->Cout <= 0 || a->Cin <= 0 || !a->y) return 0;
+    dgmr_conv_args p = *a;
+    conv_args_defaults(p);
+    return gates2_ok(p) ? 1 : 0;
 }
 
 extern "C" int dgmr_conv_stats_rows(const dgmr_conv_args* a) {
@@ -710,6 +724,9 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
                    "dgmr_conv_fwd: weight slice [%d, %d) of %d channels is invalid", a->w_coff, a->w_coff + a->Cin, a->w_cin);
     dgmr_conv_args p = *a;
     conv_args_defaults(p);
+    DGMR_CHECK_ARG(p.epi_mode != DGMR_EPI_GRU_GATES2 || gates2_ok(p),
+                   "dgmr_conv_fwd: DGMR_EPI_GRU_GATES2 needs a conv the LDS-DMA window kernel takes, Cout == 2 * gru_split, gru_split %% 4 == 0, "
+                   "gru_h / y2 and 16-byte aligned tensors (ask dgmr_conv_gates2_supported)");
     const int M = (int)M64, Ktot = a->KD * a->KH * a->KW * a->Cin;
     hipStream_t s = (hipStream_t)stream;
     const int C = a->Cout;
@@ -996,7 +1013,8 @@ extern "C" int dgmr_upsample_phase_weights(const float* w, float* out, int Cout,
     return 0;
 }
 
-extern "C" int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, int w_cin, int w_coff, int planes, void* stream) {
+extern "C" int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, int Cin, int w_cin, int w_coff, int planes,
+                                  int64_t plane_stride, void* stream) {
     DGMR_CHECK_ARG(w && out && rows > 0 && Cin > 0 && Cin % 2 == 0, "dgmr_split_weights: bad args (Cin=%d must be even)", Cin);
     DGMR_CHECK_ARG(planes >= 1 && planes <= 3, "dgmr_split_weights: planes=%d (1 .. 3)", planes);
     if (w_cin == 0) {
@@ -1005,8 +1023,12 @@ extern "C" int dgmr_split_weights(const float* w, uint16_t* out, int64_t rows, i
     }
     DGMR_CHECK_ARG(w_coff >= 0 && w_coff + Cin <= w_cin, "dgmr_split_weights: bad slice");
     const int64_t total = rows * Cin;
+    if (plane_stride == 0) plane_stride = total;
+    DGMR_CHECK_ARG(plane_stride >= total && plane_stride % 2 == 0, "dgmr_split_weights: plane_stride=%lld < %lld elements", (long long)plane_stride,
+                   (long long)total);
     const int blocks = (int)std::min<int64_t>((total / 2 + 255) / 256, 2048);
-    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, total, Cin, w_cin, w_coff, planes);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, total, Cin, w_cin, w_coff, planes,
+                       plane_stride);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256, (NSTAGE == 1 && BM == 128) ? 3 : 2) void conv3
 // out[plane][i], plane k = bf16(w - plane 0 - ... - plane k-1), `planes` of them (2: bf16x3 / bf16, 3: bf16x6); i runs over
 // (co, tap, ci) of the slice [w_coff, w_coff+Cin)
 __global__ void split_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int64_t total, int Cin, int w_cin,
-                                     int w_coff, int planes) {
+                                     int w_coff, int planes, int64_t plane_stride) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total / 2; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e = i * 2;  // Cin is even: the pair never straddles a row
         const int64_t row = e / Cin;
@@ -777,7 +777,7 @@ __global__ void split_weights_kernel(const float* __restrict__ w, uint16_t* __re
         float a = w[row * w_cin + w_coff + ci], b = w[row * w_cin + w_coff + ci + 1];
         for (int k = 0; k < planes; ++k) {
             const uint32_t q = pack_bf16(a, b);
-            reinterpret_cast<uint32_t*>(out + (int64_t)k * total)[i] = q;
+            reinterpret_cast<uint32_t*>(out + (int64_t)k * plane_stride)[i] = q;
             a -= __uint_as_float(q << 16);
             b -= __uint_as_float(q & 0xffff0000u);
         }

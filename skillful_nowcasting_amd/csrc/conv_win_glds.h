@@ -418,6 +418,40 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
         for (int j = 0; j < TN; ++j) {  // one column block at a time: its per-column operands and sums stay in a few registers
             const int col4 = n0 + wn * TN * MB + j * MB + 4 * q4;
             const bool cok = col4 < p.Cout;  // (Cout % 4 == 0: the whole quad of columns is in or out)
+            if (emode == DGMR_EPI_GRU_GATES2) {
+                // read and update gate of a ConvGRU step in one launch: columns [0, C) are the read gate's (pre_out, y = sigmoid * h),
+                // [C, 2C) the update gate's (y2 = pre-activation); every tensor has C channels per pixel (C % 4 == 0: no quad straddles)
+                const int C = p.gru_split;
+                const bool is2 = col4 >= C;
+                const int c0 = cok ? (is2 ? col4 - C : col4) : 0;
+                const float* bp = is2 ? p.bias2 : p.bias;
+                const float* ap = is2 ? p.addend2 : p.addend;
+                const f32x4 b4 = bp ? *reinterpret_cast<const f32x4*>(bp + c0) : zero4;
+                const float scj = is2 ? (p.scale2 ? p.scale2[smp / p.scale_group] : 1.f) : sc;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const size_t off = (size_t)mpix[i][g] * C + c0;
+                        f32x4 v = quad_transpose(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], lane);
+                        if (ap) v += *reinterpret_cast<const f32x4*>(ap + off);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], scj, b4[c]);
+                        if (!cok) continue;
+                        if (is2) {
+                            *reinterpret_cast<f32x4*>(p.y2 + off) = v;
+                        } else {
+                            const f32x4 hv = *reinterpret_cast<const f32x4*>(p.gru_h + off);
+                            f32x4 o;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] = sigmoid_(v[c]) * hv[c];
+                            if (p.pre_out) *reinterpret_cast<f32x4*>(p.pre_out + off) = v;
+                            *reinterpret_cast<f32x4*>(p.y + off) = o;
+                        }
+                    }
+                }
+                continue;
+            }
             const int cc = cok ? col4 : 0;
             const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cc) : zero4;
             f32x4 ma4 = one4, mb4 = zero4;

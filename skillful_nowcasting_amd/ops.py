@@ -560,10 +560,36 @@ def _split_planes(w: torch.Tensor, flipped: bool, coff: int = 0, cin: Optional[i
         return hit[1]
     out = torch.empty(planes * cout * taps * cin, device=w.device, dtype=torch.int16)
     if flipped:  # the flipped slice is already dense
-        call("dgmr_split_weights", _p(_flipped_weight(w, coff, cin)), _p(out), rows_c * taps, k_c, 0, 0, planes, _stream())
+        call("dgmr_split_weights", _p(_flipped_weight(w, coff, cin)), _p(out), rows_c * taps, k_c, 0, 0, planes, 0, _stream())
     else:
-        call("dgmr_split_weights", _p(w), _p(out), rows_c * taps, k_c, cin_total, coff, planes, _stream())
+        call("dgmr_split_weights", _p(w), _p(out), rows_c * taps, k_c, cin_total, coff, planes, 0, _stream())
     _split_cache[key] = (tag, out, weakref.ref(w, lambda _r, k=key: _split_cache.pop(k, None)))
+    return out
+
+
+_GRU_FUSE_GATES = __import__("os").environ.get("DGMR_GRU_FUSE", "1") != "0"  # measurement switch
+
+
+def _split_planes_cat(ws: Sequence[torch.Tensor], coff: int, cin: int) -> Optional[torch.Tensor]:
+    """bf16 planes of the input-channel slice [coff, coff+cin) of SEVERAL 3x3 conv weights stacked along the output-channel axis
+    ([planes][sum Cout][9][cin]): the ConvGRU's read and update gate convs as ONE conv (DGMR_EPI_GRU_GATES2).  Cached until any of
+    the parameters changes."""
+    if _PRECISION_CODE == 0 or cin % 8 or any(w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) for w in ws):
+        return None
+    planes = _PLANES[_PRECISION_CODE]
+    key = (tuple(id(w) for w in ws), "cat", coff, cin, planes)
+    tag = tuple((w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape)) for w in ws)
+    hit = _split_cache.get(key)
+    if hit is not None and hit[0] == tag and all(r() is w for r, w in zip(hit[2], ws)):
+        return hit[1]
+    rows = sum(w.shape[0] for w in ws)
+    stride = rows * 9 * cin
+    out = torch.empty(planes * stride, device=ws[0].device, dtype=torch.int16)
+    r0 = 0
+    for w in ws:
+        call("dgmr_split_weights", _p(w), out.data_ptr() + 2 * r0 * 9 * cin, w.shape[0] * 9, cin, w.shape[1], coff, planes, stride, _stream())
+        r0 += w.shape[0]
+    _split_cache[key] = (tag, out, tuple(weakref.ref(w, lambda _r, k=key: _split_cache.pop(k, None)) for w in ws))
     return out
 
 
@@ -586,7 +612,7 @@ def _phase_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
     sums = torch.empty(16 * cout * cin, device=w.device, dtype=torch.float32)
     call("dgmr_upsample_phase_weights", _p(w), _p(sums), cout, cin, _stream())
     out = torch.empty(planes * 16 * cout * cin, device=w.device, dtype=torch.int16)
-    call("dgmr_split_weights", _p(sums), _p(out), 16 * cout, cin, 0, 0, planes, _stream())
+    call("dgmr_split_weights", _p(sums), _p(out), 16 * cout, cin, 0, 0, planes, 0, _stream())
     _phase_cache[key] = (tag, out, weakref.ref(w, lambda _r, k=key: _phase_cache.pop(k, None)))
     return out
 
@@ -606,7 +632,7 @@ def _pool2_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
     sums = torch.empty(16 * cout * cin, device=w.device, dtype=torch.float32)
     call("dgmr_pool2_phase_weights", _p(_flipped_weight(w)), _p(sums), cin, cout, _stream())
     out = torch.empty(planes * 16 * cout * cin, device=w.device, dtype=torch.int16)
-    call("dgmr_split_weights", _p(sums), _p(out), 16 * cin, cout, 0, 0, planes, _stream())
+    call("dgmr_split_weights", _p(sums), _p(out), 16 * cin, cout, 0, 0, planes, 0, _stream())
     _phase_cache[key] = (tag, out, weakref.ref(w, lambda _r, k=key: _phase_cache.pop(k, None)))
     return out
 
@@ -616,18 +642,22 @@ def _kdims(w: torch.Tensor):
     return tuple([1] + ks) if len(ks) == 2 else tuple(ks)
 
 
-EPI_PLAIN, EPI_GRU_GATE, EPI_GRU_BLEND = 0, 1, 2
+EPI_PLAIN, EPI_GRU_GATE, EPI_GRU_BLEND, EPI_GRU_GATES2 = 0, 1, 2, 3
 
 
 def _launch_conv(x, w_ptr, bias, scale, y, n, d, h, w_, cin, cout, kd, kh, kw, *, upsample=False, pre_relu=False, pre_a=None,
                  pre_b=None, pre_group=1, residual=None, addend=None, mask_src=None, mask_a=None, mask_b=None, mask_group=1,
                  scale_group=None, act_relu=False, w_cin=0, w_coff=0, epi_mode=EPI_PLAIN, gru_h=None, gru_pu=None, pre_out=None,
-                 device=None, w_split=None, residual_up=False, want_stats=False, w_phase=None, pool2=False):
+                 device=None, w_split=None, residual_up=False, want_stats=False, w_phase=None, pool2=False, gates2=None):
     """`want_stats`: ask for the BatchNorm partial sums of the OUTPUT (dgmr_conv_args.stats_out); returns the [rows, 2, Cout] partials
     tensor, or None when the kernel the library dispatches for these arguments has no fused statistics.
     `pool2`: y is the 2x2 sum pool of the conv (dgmr_conv_args.pool2); returns NotImplemented - nothing launched - when the library has
-    no single-pass kernel for these arguments."""
+    no single-pass kernel for these arguments.
+    `gates2` = (scale2, bias2, addend2, y2, C) with epi_mode EPI_GRU_GATES2: the fused read + update gate launch; returns NotImplemented
+    when the library cannot take it."""
     a = ConvArgs()
+    if gates2 is not None:
+        a.scale2, a.bias2, a.addend2, a.y2, a.gru_split = _p(gates2[0]), _p(gates2[1]), _p(gates2[2]), _p(gates2[3]), int(gates2[4])
     a.w_split = _p(w_split)
     a.w_phase = _p(w_phase)
     a.residual_up = int(bool(residual_up))
@@ -649,6 +679,11 @@ def _launch_conv(x, w_ptr, bias, scale, y, n, d, h, w_, cin, cout, kd, kh, kw, *
         from ._lib import load
 
         if not load().dgmr_conv_pool2_supported(ctypes.byref(a)):
+            return NotImplemented
+    if gates2 is not None:
+        from ._lib import load
+
+        if not load().dgmr_conv_gates2_supported(ctypes.byref(a)):
             return NotImplemented
     partials = None
     if want_stats:
@@ -1245,13 +1280,23 @@ class ConvGRUFn(Function):
 
         sr, su, sc = seqs
         spr, spu, spc = (_split_planes(w, False, cx, ch) for w in (wr, wu, wc))  # h halves as bf16 planes (bf16 modes, big maps)
+        # read and update gate convolve the same h (ConvGRU.py:69-76): one launch with 2 ch output columns whenever the LDS-DMA window
+        # kernel takes the step (DGMR_EPI_GRU_GATES2: the halo of h is staged once, a third fewer launches on the recurrent path)
+        sp_ru = _split_planes_cat((wr, wu), cx, ch) if (_GRU_FUSE_GATES and (kh, kw) == (3, 3) and sgroup(sr) == sgroup(su)) else None
+        fused = sp_ru is not None
         for t in range(T):
             hp, out = step_ptr(buf, t), step_ptr(buf, t + 1)
-            _launch_conv(hp, _p(wr), br, scale_ptr(sr, t), kept(rh, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
-                         addend=x_ptr(xr, t), epi_mode=EPI_GRU_GATE, gru_h=hp, pre_out=kept(pr, t), device=dev, w_split=spr,
-                         scale_group=sgroup(sr))
-            _launch_conv(hp, _p(wu), bu, scale_ptr(su, t), kept(pu, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
-                         addend=x_ptr(xu, t), device=dev, w_split=spu, scale_group=sgroup(su))
+            if fused:
+                r_ = _launch_conv(hp, _p(wr), br, scale_ptr(sr, t), kept(rh, t), b, 1, hh, ww, ch, 2 * ch, 1, kh, kw, addend=x_ptr(xr, t),
+                                  epi_mode=EPI_GRU_GATES2, gru_h=hp, pre_out=kept(pr, t), device=dev, w_split=sp_ru, scale_group=sgroup(sr),
+                                  gates2=(scale_ptr(su, t), bu, x_ptr(xu, t), kept(pu, t), ch))
+                fused = r_ is not NotImplemented  # (decided by the first step: the geometry is the same for all of them)
+            if not fused:
+                _launch_conv(hp, _p(wr), br, scale_ptr(sr, t), kept(rh, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
+                             addend=x_ptr(xr, t), epi_mode=EPI_GRU_GATE, gru_h=hp, pre_out=kept(pr, t), device=dev, w_split=spr,
+                             scale_group=sgroup(sr))
+                _launch_conv(hp, _p(wu), bu, scale_ptr(su, t), kept(pu, t), b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
+                             addend=x_ptr(xu, t), device=dev, w_split=spu, scale_group=sgroup(su))
             _launch_conv(kept(rh, t), _p(wc), bc, scale_ptr(sc, t), out, b, 1, hh, ww, ch, ch, 1, kh, kw, w_cin=ct, w_coff=cx,
                          addend=x_ptr(xc, t), epi_mode=EPI_GRU_BLEND, gru_h=hp, gru_pu=kept(pu, t), pre_out=kept(pc, t),
                          device=dev, w_split=spc, scale_group=sgroup(sc))

@@ -57,7 +57,7 @@ def test_window_conv_variants_agree(tuned, n, h, w, cin, cout, up, bn, res):
     b = torch.randn(n * cin, device=DEV) * 0.1
     r = torch.randn(n * h * w * cout, device=DEV) if res else None
     wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
-    call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, 2, ops._stream())
+    call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, 2, 0, ops._stream())
     ys = {}
     # register-staged window, LDS-DMA window, the same with private per-wave weight slices (no barrier between taps; 128- and
     # 64-column tiles), with 256-pixel tiles (where eligible), implicit GEMM
@@ -113,7 +113,7 @@ def test_upsample_phases_match_upsampled_conv(n, h, w, cin, cout, bn, res, prec)
     S.set_precision(prec)
     try:
         wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
-        call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, 2, ops._stream())
+        call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, 2, 0, ops._stream())
         sums = torch.empty(16 * cout * cin, device=DEV)
         call("dgmr_upsample_phase_weights", wt.data_ptr(), sums.data_ptr(), cout, cin, ops._stream())
         # the tap sums themselves, against torch
@@ -124,7 +124,7 @@ def test_upsample_phases_match_upsampled_conv(n, h, w, cin, cout, bn, res, prec)
                             for py in (0, 1) for px in (0, 1)], 0)  # [4][Cout][2][2][Cin]
         assert torch.allclose(sums.view(4, cout, 2, 2, cin), want, rtol=0, atol=1e-6)
         wph = torch.empty(2 * sums.numel(), device=DEV, dtype=torch.int16)
-        call("dgmr_split_weights", sums.data_ptr(), wph.data_ptr(), 16 * cout, cin, 0, 0, 2, ops._stream())
+        call("dgmr_split_weights", sums.data_ptr(), wph.data_ptr(), 16 * cout, cin, 0, 0, 2, 0, ops._stream())
         ys = []
         for ph in (None, wph):
             y = torch.full((n * h * w * cout,), float("nan"), device=DEV)
@@ -167,7 +167,7 @@ def test_window_conv3d_matches_implicit_gemm(tuned, n, d, h, w, cin, cout, relu,
     scale = torch.rand(n, device=DEV) + 0.5
     r = torch.randn(n * d * h * w * cout, device=DEV) if res else None
     wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
-    call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 27, cin, 0, 0, 2, ops._stream())
+    call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 27, cin, 0, 0, 2, 0, ops._stream())
     ys = {}
     for mode in (3, 0):
         tuned(-1, -1, mode, -1)
@@ -226,3 +226,66 @@ def test_window_wgrad_matches_im2col_wgrad(tuned, n, h, w, cin, cout, up, bn, gr
     assert not torch.isnan(g1).any()
     assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
     assert float((b0 - b1).abs().max()) <= 2e-5 * float(b0.abs().max())
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 3e-5), ("bf16x6", 3e-6)])
+@pytest.mark.parametrize("cx,ch,hw,b,draws", [(96, 48, 32, 8, 1), (192, 96, 32, 6, 2), (384, 192, 16, 12, 1), (768, 384, 8, 96, 6)])
+def test_convgru_fused_gates_match_separate_launches(prec, tol, cx, ch, hw, b, draws):
+    """DGMR_EPI_GRU_GATES2: the read and update gate convs of a ConvGRU step as ONE launch with 2 C output columns (both convolve the
+    same h, dgmr/layers/ConvGRU.py:69-76) against the three-launch step: layer outputs, input / initial-state gradients and every
+    parameter gradient.  Same products, same K order; the 96- / 128-column tile of the fused launch groups them into other MFMA
+    blocks than the separate launches' tiles, hence a rounding-level tolerance instead of bit equality."""
+    import copy
+
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import ops
+    from skillful_nowcasting_amd.layers import ConvGRU
+
+    T = 3
+    S.set_precision(prec)
+    fused_launches = []
+    orig_launch = ops._launch_conv
+
+    def spy(*a, **k):
+        r = orig_launch(*a, **k)
+        if k.get("gates2") is not None:
+            fused_launches.append(r is not NotImplemented)
+        return r
+
+    ops._launch_conv = spy
+    keep = ops._GRU_FUSE_GATES
+    try:
+        torch.manual_seed(5)
+        a = ConvGRU(cx + ch, ch, 3).to("cuda")
+        bmod = copy.deepcopy(a)
+        x = torch.randn(T * b, cx, hw, hw, device="cuda")
+        h0 = torch.randn(b, ch, hw, hw, device="cuda")
+        cot = torch.randn(T * b, ch, hw, hw, device="cuda")
+        lay = ops.CallLayout(draws, T, time_major=True) if draws > 1 else None
+        res = []
+        for mod, fuse in ((a, True), (bmod, False)):
+            ops._GRU_FUSE_GATES = fuse
+            xs, hs = x.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+            out = mod.forward_batched(xs, hs, T, draws=draws, layout=lay)
+            (out * cot).sum().backward()
+            torch.cuda.synchronize()
+            res.append((out.detach(), xs.grad, hs.grad, {k: p.grad.clone() for k, p in mod.named_parameters()},
+                        {k: v.clone() for k, v in mod.state_dict().items() if k.endswith(("_u", "_v"))}))
+    finally:
+        ops._launch_conv = orig_launch
+        ops._GRU_FUSE_GATES = keep
+        S.set_precision("f32")
+    assert fused_launches and all(fused_launches) and len(fused_launches) == T, fused_launches  # the fused path really ran, every step
+    (o1, gx1, gh1, gp1, st1), (o2, gx2, gh2, gp2, st2) = res
+
+    def close(u, v, what, t=tol):
+        err = (u.double() - v.double()).abs().max().item() / max(v.double().abs().max().item(), 1e-30)
+        assert err <= t, f"{what}: {err:.2e}"
+
+    close(o1, o2, "outputs")
+    close(gx1, gx2, "d x", 4 * tol)
+    close(gh1, gh2, "d h0", 4 * tol)
+    for k in gp2:
+        close(gp1[k], gp2[k], "grad " + k, 10 * tol)
+    for k in st2:
+        assert torch.equal(st1[k], st2[k]), k  # spectral-norm state does not depend on how the convs are launched

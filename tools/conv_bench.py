@@ -131,14 +131,14 @@ def main():
         wsp = None
         if ops.get_precision() != "f32" and ks in ((1, 3, 3), (3, 3, 3)) and cin % 8 == 0 and "--nowin" not in sys.argv:
             wsp = torch.empty(2 * wt.numel(), device=dev, dtype=torch.int16)
-            call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * kd * 9, cin, 0, 0, 2, ops._stream())
+            call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * kd * 9, cin, 0, 0, 2, 0, ops._stream())
 
         wph0 = None
         if "--phases-only" in sys.argv and up and wsp is not None and ks == (1, 3, 3):  # PMC runs: only the path the product takes
             sums0 = torch.empty(16 * cout * cin, device=dev)
             call("dgmr_upsample_phase_weights", wt.data_ptr(), sums0.data_ptr(), cout, cin, ops._stream())
             wph0 = torch.empty(2 * sums0.numel(), device=dev, dtype=torch.int16)
-            call("dgmr_split_weights", sums0.data_ptr(), wph0.data_ptr(), 16 * cout, cin, 0, 0, 2, ops._stream())
+            call("dgmr_split_weights", sums0.data_ptr(), wph0.data_ptr(), 16 * cout, cin, 0, 0, 2, 0, ops._stream())
 
         def fwd():
             ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, d, h, w, cin, cout, kd, kh, kw, upsample=up,
@@ -150,7 +150,7 @@ def main():
             sums = torch.empty(16 * cout * cin, device=dev)
             call("dgmr_upsample_phase_weights", wt.data_ptr(), sums.data_ptr(), cout, cin, ops._stream())
             wph = torch.empty(2 * sums.numel(), device=dev, dtype=torch.int16)
-            call("dgmr_split_weights", sums.data_ptr(), wph.data_ptr(), 16 * cout, cin, 0, 0, 2, ops._stream())
+            call("dgmr_split_weights", sums.data_ptr(), wph.data_ptr(), 16 * cout, cin, 0, 0, 2, 0, ops._stream())
             y_direct = y.clone()
             y.zero_()
 
@@ -211,11 +211,11 @@ def main():
                 hi = torch.empty(n * h * w * cin, device=dev)
                 wflip = torch.randn(cin * 9 * cout, device=dev) * 0.05
                 wfs = torch.empty(2 * wflip.numel(), device=dev, dtype=torch.int16)
-                call("dgmr_split_weights", wflip.data_ptr(), wfs.data_ptr(), cin * 9, cout, 0, 0, 2, ops._stream())
+                call("dgmr_split_weights", wflip.data_ptr(), wfs.data_ptr(), cin * 9, cout, 0, 0, 2, 0, ops._stream())
                 sums = torch.empty(16 * cout * cin, device=dev)
                 call("dgmr_pool2_phase_weights", wflip.data_ptr(), sums.data_ptr(), cin, cout, ops._stream())
                 wpl = torch.empty(2 * sums.numel(), device=dev, dtype=torch.int16)
-                call("dgmr_split_weights", sums.data_ptr(), wpl.data_ptr(), 16 * cin, cout, 0, 0, 2, ops._stream())
+                call("dgmr_split_weights", sums.data_ptr(), wpl.data_ptr(), 16 * cin, cout, 0, 0, 2, 0, ops._stream())
 
                 def dg_old():
                     ops._launch_conv(y, wflip.data_ptr(), None, scale, hi, n, d, h, w, cout, cin, kd, kh, kw, w_split=wfs)

@@ -52,7 +52,7 @@ def main():
         bias = torch.randn(ch, device=dev)
         scale = torch.full((1,), 0.5, device=dev)
         wsp = torch.empty(2 * ch * 9 * ch, device=dev, dtype=torch.int16)
-        call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), ch * 9, ch, ct, cx, 2, ops._stream())
+        call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), ch * 9, ch, ct, cx, 2, 0, ops._stream())
         flops = 2.0 * m * 9 * ch * ch
 
         def fwd(use_split=True):

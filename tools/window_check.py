@@ -15,7 +15,7 @@ for (n,h,w,cin,cout,up,bn) in [(4,64,64,192,96,False,True),(2,128,128,96,96,True
     a=torch.rand(n*cin,device=dev)+0.5; b=torch.randn(n*cin,device=dev)*0.1
     res=torch.randn(n*h*w*cout,device=dev)
     wsp=torch.empty(2*wt.numel(),device=dev,dtype=torch.int16)
-    call("dgmr_split_weights",wt.data_ptr(),wsp.data_ptr(),cout*9,cin,0,0,2,ops._stream())
+    call("dgmr_split_weights",wt.data_ptr(),wsp.data_ptr(),cout*9,cin,0,0,2,0,ops._stream())
     ys=[]
     for mode in (1,3,0):
         call("dgmr_conv_tune",-1,-1,mode,-1)
