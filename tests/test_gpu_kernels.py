@@ -229,7 +229,7 @@ def test_window_wgrad_matches_im2col_wgrad(tuned, n, h, w, cin, cout, up, bn, gr
 
 
 @pytest.mark.parametrize("prec,tol", [("bf16x3", 3e-5), ("bf16x6", 3e-6)])
-@pytest.mark.parametrize("cx,ch,hw,b,draws", [(96, 48, 32, 8, 1), (192, 96, 32, 6, 2), (384, 192, 16, 12, 1), (768, 384, 8, 96, 6)])
+@pytest.mark.parametrize("cx,ch,hw,b,draws", [(96, 48, 64, 6, 1), (192, 96, 32, 12, 2), (384, 192, 16, 32, 1), (768, 384, 8, 96, 6)])
 def test_convgru_fused_gates_match_separate_launches(prec, tol, cx, ch, hw, b, draws):
     """DGMR_EPI_GRU_GATES2: the read and update gate convs of a ConvGRU step as ONE launch with 2 C output columns (both convolve the
     same h, dgmr/layers/ConvGRU.py:69-76) against the three-launch step: layer outputs, input / initial-state gradients and every
