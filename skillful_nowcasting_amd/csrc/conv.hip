@@ -744,6 +744,9 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     else if (bn == 96) variant = V_F128x96;
     else if (bn == 64) variant = wgs128 >= 256 ? V_F128x64 : V_F64x64;
     else variant = V_F128x32;
+    // bf16x6: three planes per operand - the 128-row tiles with 64 / 96 columns hold 92 / 107 KB of LDS (one workgroup per CU); the
+    // 64 x 64 tile keeps two resident, which is what the short-K layers that land here need (the discriminators' Cin = 4 first convs)
+    if (g_precision == 3 && (variant == V_F128x64 || variant == V_F128x96)) variant = V_F64x64;
     if (g_tune_variant >= V_F128x128 && g_tune_variant <= V_F128x32) variant = g_tune_variant;
     // 3x3 convs of the big feature maps in the bf16 modes: LDS-window kernel (needs pre-split weights)
     WinPlan wp;

@@ -213,7 +213,10 @@ def test_hip_training_steps_adv_match_reference(precision, grad_tol):
     for o, r in zip(outs, rec["losses"].tolist()):
         _check_losses([float(o["d_loss"]), float(o["g_loss"]), float(o["grid_loss"])], r, "returned losses")
     # bf16x3: 16-bit products; measured 1.5 ... 6 x the reference's own band (f32: 0.6 ... 1.6 x), see conftest.band_check
-    _check_grads(grads, rec, grad_tol, *((3.0, 0.9) if precision in ("f32", "bf16x6") else (10.0, 0.5)))
+    # bf16x6: fp32-faithful products, but another rounding sequence than the f32 MFMA's: after three chaotic steps it sits at 2 ... 5 x
+    # the band between the reference's own runs (estimated from a handful of thread counts), e.g. 1.2e-2 on the 4-element
+    # sampler.conv_1x1.bias whose band is 2.5e-3
+    _check_grads(grads, rec, grad_tol, *{"f32": (3.0, 0.9), "bf16x6": (6.0, 0.9)}.get(precision, (10.0, 0.5)))
     _check_post(sd0, model.state_dict(), rec, keys, kw, steps)
 
 
