@@ -451,7 +451,8 @@ int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window);
 /* Kernel-phase timing switches for tools/conv_bench.py (process-wide, 0 at load and in every product launch): bit 0 = the LDS-window
  * conv kernels return before their epilogue, bit 1 = they stage only their first input halo.  Outputs are then garbage by design;
  * only the launch duration is meaningful (how much of a launch is operand staging / matrix work / epilogue).  Bit 3 (8) = the
- * window kernels use their lane-per-channel epilogue instead of the 16-byte one (A/B: results are bit-identical). */
+ * window kernels use their lane-per-channel epilogue instead of the 16-byte one (A/B: results are bit-identical); 64 / 128 = every
+ * wave sleeps ~3.4 / ~6.8 us after issuing its last store (how long does a finished wave wait for its stores anyway?). */
 int dgmr_debug_flags(int flags);
 
 #ifdef __cplusplus

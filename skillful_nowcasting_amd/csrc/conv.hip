@@ -666,7 +666,7 @@ extern "C" int dgmr_conv_pool2_supported(const dgmr_conv_args* a) {
 static inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 static void conv_args_defaults(dgmr_conv_args& p) {
     p.reserved0 = 0;
-    p.reserved1 = g_debug_flags & 3;
+    p.reserved1 = g_debug_flags & (3 | 64 | 128);
     // bit 2: the window kernels may use their 16-byte epilogue (conv_win_glds.h) - four consecutive output channels per lane
     if (!(g_debug_flags & 8) && p.Cout % 4 == 0 && al16(p.y) && al16(p.bias) && al16(p.addend) && al16(p.residual) && al16(p.mask_src) &&
         al16(p.mask_a) && al16(p.mask_b) && al16(p.gru_h) && al16(p.gru_pu) && al16(p.pre_out) && al16(p.bias2) && al16(p.addend2) && al16(p.y2))
@@ -1055,7 +1055,7 @@ extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_win
 }
 
 extern "C" int dgmr_debug_flags(int flags) {
-    DGMR_CHECK_ARG(flags >= 0 && flags <= 15 && !(flags & 4), "dgmr_debug_flags: %d", flags);
+    DGMR_CHECK_ARG(flags >= 0 && flags <= 255 && !(flags & 4), "dgmr_debug_flags: %d", flags);
     g_debug_flags = flags;
     return 0;
 }

@@ -542,6 +542,13 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
                 if (n0 + cl < p.Cout) p.stats_out[(srow * 2 + which) * p.Cout + n0 + cl] = v;
             }
         }
+        // tail probe (dgmr_debug_flags 64 / 128: sleep ~3.4 / ~6.8 us after the last store was ISSUED): a wave cannot retire before its
+        // stores are acknowledged; if a launch does not get slower with the sleep, that wait is at least as long
+        if (dbg & 64) __builtin_amdgcn_s_sleep(127);
+        if (dbg & 128) {
+            __builtin_amdgcn_s_sleep(127);
+            __builtin_amdgcn_s_sleep(127);
+        }
         return;
     }
     float bj[TN];
