@@ -1,0 +1,125 @@
+"""Second-stream scheduling of the backward pass: weight gradients beside the data-gradient chain, an optional branch stream for
+the temporal discriminator, and the joins that order the main stream behind them (no host synchronisation anywhere)."""
+from __future__ import annotations
+
+import ctypes
+import weakref
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from ._lib import ConvArgs, WgradArgs, call
+
+# Weight gradients off the critical path: the backward chain only needs each conv's DATA gradient; its weight gradient (window /
+# im2col kernel, slab reduce, spectral-norm finalize - latency-bound kernels at 20-30 % matrix-pipe occupancy) runs on a second
+# stream beside the data-gradient convs of the layers below.  The main stream joins it when the backward pass ends
+# (autograd engine callback), i.e. before anything can read a .grad.
+_SIDE_STREAMS = {}
+_SIDE_PENDING = {}
+_SIDE_KEEP = []  # (event after the side work, tensors it reads)
+
+
+_DEFER_JOIN = [0]
+
+
+class defer_side_join:
+    """Inside: the end of a backward pass does NOT make the main stream wait for the weight-gradient stream; the caller does, with
+    join_side_streams(), before it reads a .grad - after putting work that does not need the gradients in between
+    (DGMR.training_step: the generator forward of the next discriminator iteration runs beside the tail of the weight gradients)."""
+
+    def __enter__(self):
+        _DEFER_JOIN[0] += 1
+
+    def __exit__(self, *exc):
+        _DEFER_JOIN[0] -= 1
+
+
+_BRANCH_STREAMS = {}
+# opt-in: measured 1044.7 vs 1049.6 ms/step (-0.5 %) with all parity tests green; off by default - autograd warns about the
+# AccumulateGrad stream of inputs shared by the two branches, and half a percent does not pay for a second compute stream's risk
+_BRANCH_ON = __import__("os").environ.get("DGMR_BRANCH_STREAM", "0") != "0"
+
+
+def branch_stream(dev):
+    """A second compute stream for an independent branch of the forward (the temporal discriminator beside the spatial one); autograd
+    runs the branch's backward on it as well.  None: disabled."""
+    if not _BRANCH_ON:
+        return None
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _BRANCH_STREAMS.get(idx)
+    if st is None:
+        st = _BRANCH_STREAMS[idx] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def join_side_streams():
+    """The current stream waits for everything issued on the weight-gradient streams and on the branch stream (no host
+    synchronisation): parameter gradients are written by the kernels, not handed to autograd, so its own end-of-backward stream
+    synchronisation does not cover them."""
+    cur = torch.cuda.current_stream()
+    for idx, st in _BRANCH_STREAMS.items():
+        if cur.device.index == idx:
+            cur.wait_stream(st)
+    for (idx, _lane), side in _SIDE_STREAMS.items():
+        if cur.device.index == idx:
+            cur.wait_stream(side)
+    _SIDE_PENDING.clear()
+    _SIDE_KEEP.clear()
+
+
+def _join_side_streams():
+    if _DEFER_JOIN[0]:
+        return
+    for key, main in list(_SIDE_PENDING.items()):
+        main.wait_stream(_SIDE_STREAMS[key])
+    for idx, st in _BRANCH_STREAMS.items():  # (its own parameter gradients; the default stream is the one readers use)
+        torch.cuda.default_stream(torch.device("cuda", idx)).wait_stream(st)
+        for (i2, _lane), side in _SIDE_STREAMS.items():
+            if i2 == idx:
+                torch.cuda.default_stream(torch.device("cuda", idx)).wait_stream(side)
+    _SIDE_PENDING.clear()
+    _SIDE_KEEP.clear()  # everything the main stream does from here on is ordered behind the side work
+
+
+_SIDE_LANES = int(__import__("os").environ.get("DGMR_WGRAD_LANES", "1"))  # more lanes measured no gain (1051-1060 ms for 1, 2, 3)
+_side_rr = [0]
+
+
+def _on_side_stream(dev, fn, tensors, lane=None):
+    """Run fn() (kernel launches through _stream()) on one of the device's side streams, ordered after everything issued so far on
+    the current stream; `tensors`: what fn reads that the caller may free right after (kept alive for the side stream's work).
+    lane: a fixed stream for work that shares a scratch buffer (the pair-sum planes: lane 0); None: round robin."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if lane is None:
+        _side_rr[0] = (_side_rr[0] + 1) % _SIDE_LANES
+        lane = _side_rr[0]
+    idx = (idx, lane)
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(idx)
+    if side is None:
+        side = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
+    while _SIDE_KEEP and _SIDE_KEEP[0][0].query():
+        _SIDE_KEEP.pop(0)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        fn()
+    tensors = tuple(t for t in tensors if isinstance(t, torch.Tensor))
+    for t in tensors:
+        t.record_stream(side)
+    # A reference is held until the side work is done: autograd accumulates a second gradient INTO a buffered one in place when
+    # nobody else holds it (InputBuffer) - e.g. the gradient this conv hands to its residual - and would overwrite dy on the main
+    # stream under the weight-gradient kernel still reading it here.
+    _SIDE_KEEP.append((side.record_event(), tensors))
+    # a callback per call (the first to run joins, the rest find nothing pending): a backward pass that died on an exception must
+    # not leave a stale "callback already queued" state behind
+    _SIDE_PENDING[idx] = main
+    torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+
+
+def side_streams(device) -> List["torch.cuda.Stream"]:
+    """The weight-gradient / branch streams of `device` that exist so far (ddp: a collective must be ordered behind them)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return [st for (i, _lane), st in _SIDE_STREAMS.items() if i == idx] + [st for i, st in _BRANCH_STREAMS.items() if i == idx]
+

@@ -24,16 +24,16 @@ from torch.autograd import Function
 
 from ._lib import ConvArgs, WgradArgs, call
 
-_WEIGHTS_EPOCH = 0  # bumped by the optimiser after every in-place parameter update (flip cache key)
-
-
-def bump_weights_epoch():
-    global _WEIGHTS_EPOCH
-    _WEIGHTS_EPOCH += 1
-
-
-def weights_epoch() -> int:
-    return _WEIGHTS_EPOCH
+from . import _core, _streams
+from ._core import (BNState, CallLayout, SNCall, SPLITK_WS_BYTES, _copy, _dims, _p, _scratch, _splitk_ws, _stream, bn_prepare,  # noqa: F401
+                    bump_weights_epoch, call_slots, empty_cl, grad_buffer, require_hip, require_weight_layout, set_grad_touch_hook, to_cl,
+                    weights_epoch)
+from ._head_ops import (AttentionFn, AxpbyFn, BatchNorm1dFn, GridCellFn, HingeDiscFn, MeanFn, ReluSumHWFn, SNLinear1Fn, adam_update,  # noqa: F401
+                        attention, axpby, relu_sum_hw)
+from ._layout_ops import (CatChannelsFn, D2SFramesFn, FramesS2DFn, FramesToBatchFn, PoolAddFn, RepeatBatchFn, StackBatchFn,  # noqa: F401
+                          SumGroupsFn, TimeToChannelsFn, UnstackBatchFn, avg_pool_add, cat_channels, d2s_frames, frames_s2d,
+                          frames_to_batch, repeat_batch, stack_batch, sum_groups, time_to_channels, unstack_batch)
+from ._streams import _on_side_stream, branch_stream, defer_side_join, join_side_streams, side_streams  # noqa: F401
 
 
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x6": 3}
@@ -101,298 +101,13 @@ class discriminator_forward_precision:
             _set_code(self.prev)
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
-def _p(t):
-    """Device pointer of a tensor (None -> NULL); raw integer addresses pass through (slices of step buffers)."""
-    if t is None or isinstance(t, int):
-        return t
-    return t.data_ptr()
-
-
-_SPLITK_WS = {}
-SPLITK_WS_BYTES = 64 << 20
-
-
-def _splitk_ws(device) -> torch.Tensor:
-    """Per-(device, stream) scratch for split-K partial sums (launches are stream-ordered, so one buffer serves every conv of a stream)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _SPLITK_WS.get(key)
-    if ws is None:
-        ws = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
-        _SPLITK_WS[key] = ws
-    return ws
-
-
 # Weight gradients off the critical path: the backward chain only needs each conv's DATA gradient; its weight gradient (window /
 # im2col kernel, slab reduce, spectral-norm finalize - latency-bound kernels at 20-30 % matrix-pipe occupancy) runs on a second
 # stream beside the data-gradient convs of the layers below.  The main stream joins it when the backward pass ends
 # (autograd engine callback), i.e. before anything can read a .grad.
 _WGRAD_STREAM = __import__("os").environ.get("DGMR_WGRAD_STREAM", "1") != "0"
-_SIDE_STREAMS = {}
-_SIDE_PENDING = {}
-_SIDE_KEEP = []  # (event after the side work, tensors it reads)
-
-
-_DEFER_JOIN = [0]
-
-
-class defer_side_join:
-    """Inside: the end of a backward pass does NOT make the main stream wait for the weight-gradient stream; the caller does, with
-    join_side_streams(), before it reads a .grad - after putting work that does not need the gradients in between
-    (DGMR.training_step: the generator forward of the next discriminator iteration runs beside the tail of the weight gradients)."""
-
-    def __enter__(self):
-        _DEFER_JOIN[0] += 1
-
-    def __exit__(self, *exc):
-        _DEFER_JOIN[0] -= 1
-
-
-_BRANCH_STREAMS = {}
-# opt-in: measured 1044.7 vs 1049.6 ms/step (-0.5 %) with all parity tests green; off by default - autograd warns about the
-# AccumulateGrad stream of inputs shared by the two branches, and half a percent does not pay for a second compute stream's risk
-_BRANCH_ON = __import__("os").environ.get("DGMR_BRANCH_STREAM", "0") != "0"
-
-
-def branch_stream(dev):
-    """A second compute stream for an independent branch of the forward (the temporal discriminator beside the spatial one); autograd
-    runs the branch's backward on it as well.  None: disabled."""
-    if not _BRANCH_ON:
-        return None
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _BRANCH_STREAMS.get(idx)
-    if st is None:
-        st = _BRANCH_STREAMS[idx] = torch.cuda.Stream(device=dev)
-    return st
-
-
-def join_side_streams():
-    """The current stream waits for everything issued on the weight-gradient streams and on the branch stream (no host
-    synchronisation): parameter gradients are written by the kernels, not handed to autograd, so its own end-of-backward stream
-    synchronisation does not cover them."""
-    cur = torch.cuda.current_stream()
-    for idx, st in _BRANCH_STREAMS.items():
-        if cur.device.index == idx:
-            cur.wait_stream(st)
-    for (idx, _lane), side in _SIDE_STREAMS.items():
-        if cur.device.index == idx:
-            cur.wait_stream(side)
-    _SIDE_PENDING.clear()
-    _SIDE_KEEP.clear()
-
-
-def _join_side_streams():
-    if _DEFER_JOIN[0]:
-        return
-    for key, main in list(_SIDE_PENDING.items()):
-        main.wait_stream(_SIDE_STREAMS[key])
-    for idx, st in _BRANCH_STREAMS.items():  # (its own parameter gradients; the default stream is the one readers use)
-        torch.cuda.default_stream(torch.device("cuda", idx)).wait_stream(st)
-        for (i2, _lane), side in _SIDE_STREAMS.items():
-            if i2 == idx:
-                torch.cuda.default_stream(torch.device("cuda", idx)).wait_stream(side)
-    _SIDE_PENDING.clear()
-    _SIDE_KEEP.clear()  # everything the main stream does from here on is ordered behind the side work
-
-
-_SIDE_LANES = int(__import__("os").environ.get("DGMR_WGRAD_LANES", "1"))  # more lanes measured no gain (1051-1060 ms for 1, 2, 3)
-_side_rr = [0]
-
-
-def _on_side_stream(dev, fn, tensors, lane=None):
-    """Run fn() (kernel launches through _stream()) on one of the device's side streams, ordered after everything issued so far on
-    the current stream; `tensors`: what fn reads that the caller may free right after (kept alive for the side stream's work).
-    lane: a fixed stream for work that shares a scratch buffer (the pair-sum planes: lane 0); None: round robin."""
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if lane is None:
-        _side_rr[0] = (_side_rr[0] + 1) % _SIDE_LANES
-        lane = _side_rr[0]
-    idx = (idx, lane)
-    main = torch.cuda.current_stream(dev)
-    side = _SIDE_STREAMS.get(idx)
-    if side is None:
-        side = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
-    while _SIDE_KEEP and _SIDE_KEEP[0][0].query():
-        _SIDE_KEEP.pop(0)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        fn()
-    tensors = tuple(t for t in tensors if isinstance(t, torch.Tensor))
-    for t in tensors:
-        t.record_stream(side)
-    # A reference is held until the side work is done: autograd accumulates a second gradient INTO a buffered one in place when
-    # nobody else holds it (InputBuffer) - e.g. the gradient this conv hands to its residual - and would overwrite dy on the main
-    # stream under the weight-gradient kernel still reading it here.
-    _SIDE_KEEP.append((side.record_event(), tensors))
-    # a callback per call (the first to run joins, the rest find nothing pending): a backward pass that died on an exception must
-    # not leave a stale "callback already queued" state behind
-    _SIDE_PENDING[idx] = main
-    torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
-
 
 _GRU_KEEP_ALWAYS = bool(int(__import__("os").environ.get("DGMR_GRU_KEEP_ALWAYS", "0")))  # measurement switch
-_SCRATCH = {}
-
-
-def _scratch(numel: int, device, key: str) -> torch.Tensor:
-    """A persistent fp32 scratch buffer per (device, key), grown to the largest request: for multi-GB temporaries that live inside one
-    backward function (launches are stream-ordered: the next user overwrites it only after the previous kernels).  Kept out of
-    torch's caching allocator on purpose - a 22.8 GB temporary that comes and goes made the allocator split its cached block for
-    other requests and hipMalloc a second one a few steps later (0.4 s stall in the third step, tools/mem_segments.py)."""
-    k = (device, key)
-    buf = _SCRATCH.get(k)
-    if buf is None or buf.numel() < numel:
-        _SCRATCH.pop(k, None)
-        buf = torch.empty(numel, device=device, dtype=torch.float32)
-        _SCRATCH[k] = buf
-    return buf[:numel]
-
-
-def require_hip(t: torch.Tensor, what: str = "input"):
-    if not t.is_cuda:
-        raise RuntimeError(
-            f"skillful_nowcasting_amd: {what} is on '{t.device}'. The DGMR kernels are HIP-only (gfx950); "
-            "there is no CPU fallback — move the module and its inputs to a HIP device."
-        )
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"skillful_nowcasting_amd: {what} must be float32, got {t.dtype}")
-
-
-def require_weight_layout(w: torch.Tensor, what: str = "conv weight"):
-    """The kernels index conv weights as O[D]HWI storage (an OIHW parameter in channels_last memory format).  A parameter that
-    was replaced by an NCHW-contiguous tensor (load_state_dict(assign=True), `p.data = ...`) would be read with the wrong
-    strides: refuse it instead of computing garbage (nn.SNConv / nn.Conv re-layout such tensors when a state_dict is loaded)."""
-    if w.dim() in (4, 5):
-        mf = torch.channels_last if w.dim() == 4 else torch.channels_last_3d
-        if not w.is_contiguous(memory_format=mf):
-            raise RuntimeError(
-                f"skillful_nowcasting_amd: {what} of shape {tuple(w.shape)} has strides {tuple(w.stride())}; the HIP kernels need "
-                f"channels-last (O[D]HWI) storage. Use `p.data = p.data.contiguous(memory_format=torch.channels_last[_3d])` "
-                "and ops.bump_weights_epoch() after writing a parameter out of band.")
-
-
-def to_cl(x: torch.Tensor) -> torch.Tensor:
-    """Channels-last contiguous view/copy of a 4-D or 5-D activation (no-op on the hot path)."""
-    if x.dim() == 4:
-        return x.contiguous(memory_format=torch.channels_last)
-    if x.dim() == 5:
-        return x.contiguous(memory_format=torch.channels_last_3d)
-    return x.contiguous()
-
-
-def empty_cl(shape: Sequence[int], like: torch.Tensor) -> torch.Tensor:
-    mf = torch.channels_last if len(shape) == 4 else torch.channels_last_3d
-    return torch.empty(tuple(shape), device=like.device, dtype=torch.float32, memory_format=mf)
-
-
-def _dims(x: torch.Tensor):
-    """(N, C, D, H, W) of a 4-D / 5-D logical NC[D]HW tensor."""
-    if x.dim() == 4:
-        n, c, h, w = x.shape
-        return n, c, 1, h, w
-    n, c, d, h, w = x.shape
-    return n, c, d, h, w
-
-
-_GRAD_TOUCH_HOOK = [None]
-
-
-def set_grad_touch_hook(fn):
-    """fn(p) is called whenever a kernel is about to accumulate into p.grad (None: off).  ddp.GradSync uses the sequence of these
-    "touches" to launch each gradient bucket's all-reduce as soon as the backward pass is done with it."""
-    _GRAD_TOUCH_HOOK[0] = fn
-
-
-def side_streams(device) -> List["torch.cuda.Stream"]:
-    """The weight-gradient / branch streams of `device` that exist so far (ddp: a collective must be ordered behind them)."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    return [st for (i, _lane), st in _SIDE_STREAMS.items() if i == idx] + [st for i, st in _BRANCH_STREAMS.items() if i == idx]
-
-
-def grad_buffer(p: torch.Tensor) -> torch.Tensor:
-    """``p.grad`` with p's physical layout, zero-initialised on first touch.  THE way a kernel launch obtains the destination of a
-    parameter gradient (see set_grad_touch_hook)."""
-    if p.grad is None:
-        p.grad = torch.zeros_like(p)  # preserve_format: same strides as the parameter
-    if _GRAD_TOUCH_HOOK[0] is not None:
-        _GRAD_TOUCH_HOOK[0](p)
-    return p.grad
-
-
-# ---------------------------------------------------------------------------------------------------
-# call groups: which reference CALL of a module each group of a batched launch stands for
-# ---------------------------------------------------------------------------------------------------
-@dataclass(frozen=True)
-class CallLayout:
-    """`outer * inner` consecutive calls of one module, run as the groups of ONE batched launch.
-
-    The reference calls a sampler / discriminator module once per forecast step (or frame) inside every generator draw (or
-    discriminator call): call number  c = d' * inner + i  for draw position d' and step i.  State that moves per call - the
-    spectral-norm power iteration (u, v, sigma) and BatchNorm's running statistics - must follow THAT order, while the batch that
-    carries all calls at once is laid out for the kernels:
-
-      time_major   groups [inner][outer]  (the ConvGRU needs every draw's samples of one step contiguous), or
-      draw-major   groups [outer][inner]  (context stack: the four context frames of one draw together);
-      reverse      the reference visits the draws last-to-first: activation checkpointing recomputes the generator forwards of a
-                   step in reverse order during the backward pass (dgmr/dgmr.py:176, torch.utils.checkpoint), and that recompute
-                   is what the gradients (and the second advance of u / v / running statistics) come from.
-    """
-
-    outer: int = 1
-    inner: int = 1
-    time_major: bool = True
-    reverse: bool = False
-
-    @property
-    def calls(self) -> int:
-        return self.outer * self.inner
-
-    def slots(self) -> List[int]:
-        """slots()[c] = group of the batch that call c of the reference's sequence belongs to."""
-        out = []
-        for c in range(self.calls):
-            dpos, i = divmod(c, self.inner)
-            d = self.outer - 1 - dpos if self.reverse else dpos
-            out.append(i * self.outer + d if self.time_major else d * self.inner + i)
-        return out
-
-    def is_identity(self) -> bool:
-        return self.slots() == list(range(self.calls))
-
-
-_SLOT_CACHE = {}
-
-
-def call_slots(layout: Optional[CallLayout], device) -> Optional[torch.Tensor]:
-    """Device int32 array of `layout.slots()` (None for the identity order), cached per (layout, device)."""
-    if layout is None or layout.is_identity():
-        return None
-    key = (layout, str(device))
-    t = _SLOT_CACHE.get(key)
-    if t is None:
-        t = torch.tensor(layout.slots(), dtype=torch.int32).to(device)
-        _SLOT_CACHE[key] = t
-    return t
-
-
-# ---------------------------------------------------------------------------------------------------
-# spectral norm (torch/nn/utils/parametrizations.py:454-521)
-# ---------------------------------------------------------------------------------------------------
-@dataclass
-class SNCall:
-    """Record of `groups` consecutive calls of one spectral-norm module (1 for an ordinary call)."""
-
-    inv_sigma: torch.Tensor  # [groups]
-    u: torch.Tensor  # [groups, Cout]  copies of the u, v that sigma was computed with (the module buffers move on)
-    v: torch.Tensor  # [groups, K]
-    groups: int = 1
-
-    def at(self, t: int) -> "SNCall":
-        """The t-th call of a sequence as a single-call record (views, no copies)."""
-        return SNCall(self.inv_sigma[t:t + 1], self.u[t:t + 1], self.v[t:t + 1], 1)
 
 
 def spectral_sigma(w: torch.Tensor, u: torch.Tensor, v: torch.Tensor, scratch: torch.Tensor, eps: float, train: bool) -> SNCall:
@@ -440,59 +155,6 @@ def spectral_sigma_seq(w: torch.Tensor, gram: torch.Tensor, u: torch.Tensor, v: 
 
 
 # ---------------------------------------------------------------------------------------------------
-# batch norm statistics -> per-channel affine consumed by the next conv's operand load
-# ---------------------------------------------------------------------------------------------------
-@dataclass
-class BNState:
-    a: torch.Tensor  # [G, C]   y = relu(a*x + b)
-    b: torch.Tensor
-    mean: torch.Tensor
-    rstd: torch.Tensor
-    gamma: Optional[torch.Tensor]
-    beta: Optional[torch.Tensor]
-    train: bool
-    groups: int
-    group_size: int  # samples per group
-
-
-def bn_prepare(x: torch.Tensor, gamma, beta, running_mean, running_var, num_batches_tracked, eps: float, momentum: float,
-               train: bool, groups: int = 1, layout: Optional[CallLayout] = None, partials: Optional[torch.Tensor] = None) -> BNState:
-    """BatchNorm statistics of x (train) or running statistics (eval) folded to y = a*x + b.
-
-    torch.nn.BatchNorm2d semantics (dgmr/common.py:38-39,108-109; generators.py:113): biased batch variance
-    for normalisation, unbiased for the running estimate, momentum 0.1, one running update per group, applied in the
-    reference's call order (`layout`, see CallLayout; default: group order).
-    """
-    require_hip(x)
-    x = to_cl(x)
-    n, c, d, h, w = _dims(x)
-    if not train:
-        groups = 1
-    assert n % groups == 0
-    r = (n // groups) * d * h * w
-    dev = x.device
-    a = torch.empty(groups, c, device=dev)
-    b = torch.empty(groups, c, device=dev)
-    mean = torch.empty(groups, c, device=dev)
-    rstd = torch.empty(groups, c, device=dev)
-    if train:
-        sums = torch.zeros(groups * 2 * c, device=dev, dtype=torch.float64)
-        if partials is not None and partials.shape[0] % groups == 0 and partials.shape[2] == c:
-            # the conv that produced x already summed y and y^2 per pixel tile in its epilogue (`want_stats`): x is not read again
-            call("dgmr_bn_partial_reduce", _p(partials), _p(sums), groups, partials.shape[0] // groups, c, _stream())
-        else:
-            call("dgmr_bn_stats", _p(x), _p(sums), groups, r, c, _stream())
-        if layout is not None and layout.calls != groups:
-            raise RuntimeError(f"batch norm: {groups} call groups but the call layout describes {layout.calls}")
-        call("dgmr_bn_finalize", _p(sums), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(num_batches_tracked),
-             _p(a), _p(b), _p(mean), _p(rstd), groups, r, c, float(eps), float(momentum), _p(call_slots(layout, dev)), _stream())
-    else:
-        call("dgmr_bn_finalize", None, _p(gamma), _p(beta), _p(running_mean), _p(running_var), None, _p(a), _p(b), _p(mean),
-             _p(rstd), 1, r, c, float(eps), float(momentum), None, _stream())
-    return BNState(a, b, mean, rstd, gamma, beta, train, groups, n // groups)
-
-
-# ---------------------------------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------------------------------
 @dataclass
@@ -523,7 +185,7 @@ def _flipped_weight(w: torch.Tensor, coff: int = 0, cin: Optional[int] = None) -
     if cin is None:
         cin = cin_total
     key = (id(w), coff, cin)
-    tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    tag = (w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
     hit = _flip_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:  # the weakref guards against id() reuse after a parameter is freed
         return hit[1]
@@ -554,7 +216,7 @@ def _split_planes(w: torch.Tensor, flipped: bool, coff: int = 0, cin: Optional[i
         return None
     planes = _PLANES[_PRECISION_CODE]
     key = (id(w), flipped, coff, cin, planes)
-    tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    tag = (w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
     hit = _split_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
@@ -578,7 +240,7 @@ def _split_planes_cat(ws: Sequence[torch.Tensor], coff: int, cin: int) -> Option
         return None
     planes = _PLANES[_PRECISION_CODE]
     key = (tuple(id(w) for w in ws), "cat", coff, cin, planes)
-    tag = tuple((w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape)) for w in ws)
+    tag = tuple((w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape)) for w in ws)
     hit = _split_cache.get(key)
     if hit is not None and hit[0] == tag and all(r() is w for r, w in zip(hit[2], ws)):
         return hit[1]
@@ -605,7 +267,7 @@ def _phase_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
     cout, cin = w.shape[0], w.shape[1]
     planes = _PLANES[_PRECISION_CODE]
     key = (id(w), "phase", planes)
-    tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    tag = (w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
     hit = _phase_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
@@ -625,7 +287,7 @@ def _pool2_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
     cout, cin = w.shape[0], w.shape[1]
     planes = _PLANES[_PRECISION_CODE]
     key = (id(w), "pool2", planes)
-    tag = (w._version, _WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    tag = (w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
     hit = _phase_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
@@ -971,185 +633,6 @@ def conv(x, w, bias=None, scale=None, residual=None, spec: Optional[ConvSpec] = 
 
 
 # ---------------------------------------------------------------------------------------------------
-# pooling / layout
-# ---------------------------------------------------------------------------------------------------
-class PoolAddFn(Function):
-    """AvgPool2d(2) / AvgPool3d(2) (+ addend): dgmr/common.py:189-191,225,236-237."""
-
-    @staticmethod
-    def forward(ctx, x, addend, pd: int):
-        require_hip(x)
-        x = to_cl(x)
-        n, c, d, h, w = _dims(x)
-        oshape = (n, c, h // 2, w // 2) if x.dim() == 4 else (n, c, d // pd, h // 2, w // 2)
-        y = empty_cl(oshape, x)
-        if addend is not None:
-            addend = to_cl(addend)
-        call("dgmr_pool_fwd", _p(x), _p(addend), _p(y), n, d, h, w, c, pd, 0.0, None, None, None, 1, _stream())
-        ctx.geom = (n, c, d, h, w, pd, x.dim())
-        ctx.has_addend = addend is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        n, c, d, h, w, pd, nd = ctx.geom
-        dy = to_cl(dy)
-        dx = empty_cl((n, c, h, w) if nd == 4 else (n, c, d, h, w), dy)
-        call("dgmr_pool_bwd", _p(dy), _p(dx), n, d, h, w, c, pd, 0.0, _stream())
-        return dx, (dy if ctx.has_addend else None), None
-
-
-def avg_pool_add(x, addend=None, pd: int = 1):
-    return PoolAddFn.apply(x, addend, pd)
-
-
-class FramesS2DFn(Function):
-    """[B,T,C,H,W] frames -> (optional AvgPool2d(2)) -> PixelUnshuffle(2) -> channels-last batch of frames.
-
-    discriminators.py:106-108,202-203 ; common.py:393,400.
-    """
-
-    @staticmethod
-    def forward(ctx, frames, idx, pool: bool, frame_major: bool, as_3d: bool, idx_group: int = 0):
-        require_hip(frames)
-        frames = frames.contiguous()
-        b, t, c, h, w = frames.shape
-        if idx is not None and idx.dim() == 2:  # [calls][F]: one row of frame indices per group of idx_group samples
-            if idx_group < 1 or b % idx_group or idx.shape[0] != b // idx_group:
-                raise RuntimeError(f"frames_s2d: {tuple(idx.shape)} index rows do not fit {b} samples in groups of {idx_group}")
-            f = idx.shape[1]
-        else:
-            idx_group = 0
-            f = t if idx is None else idx.numel()
-        p = 2 if pool else 1
-        ho, wo = h // (2 * p), w // (2 * p)
-        if as_3d:
-            out = empty_cl((b, 4 * c, f, ho, wo), frames)
-        else:
-            out = empty_cl((b * f, 4 * c, ho, wo), frames)
-        call("dgmr_frames_s2d", _p(frames), _p(idx), _p(out), b, t, c, h, w, f, int(pool), int(frame_major), idx_group, _stream())
-        ctx.geom = (b, t, c, h, w, f, int(pool), int(frame_major), idx_group)
-        ctx.idx = idx
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        b, t, c, h, w, f, pool, fm, idx_group = ctx.geom
-        dout = to_cl(dout)
-        dfr = torch.zeros(b, t, c, h, w, device=dout.device, dtype=torch.float32)
-        call("dgmr_frames_s2d_bwd", _p(dout), _p(ctx.idx), _p(dfr), b, t, c, h, w, f, pool, fm, idx_group, _stream())
-        return dfr, None, None, None, None, None
-
-
-def frames_s2d(frames, idx=None, pool=False, frame_major=False, as_3d=False, idx_group: int = 0):
-    return FramesS2DFn.apply(frames, idx, pool, frame_major, as_3d, idx_group)
-
-
-class D2SFramesFn(Function):
-    """T channels-last maps [B,4C,h,w] -> PixelShuffle(2) -> stacked frames [B,T,C,2h,2w] (generators.py:178-181)."""
-
-    @staticmethod
-    def forward(ctx, x, t: int):
-        x = to_cl(x)
-        require_hip(x)
-        tb, c4, h, w = x.shape
-        c, b = c4 // 4, tb // t
-        frames = torch.empty(b, t, c, 2 * h, 2 * w, device=x.device, dtype=torch.float32)
-        n = b * c4 * h * w
-        for i in range(t):
-            call("dgmr_d2s_frames", x.data_ptr() + 4 * n * i, _p(frames), b, t, i, c, h, w, _stream())
-        ctx.geom = (b, t, c, h, w)
-        return frames
-
-    @staticmethod
-    def backward(ctx, dfr):
-        b, t, c, h, w = ctx.geom
-        dfr = dfr.contiguous()
-        dx = empty_cl((t * b, 4 * c, h, w), dfr)
-        n = b * 4 * c * h * w
-        for i in range(t):
-            call("dgmr_d2s_frames_bwd", _p(dfr), dx.data_ptr() + 4 * n * i, b, t, i, c, h, w, _stream())
-        return dx, None
-
-
-def d2s_frames(x: torch.Tensor, t: int):
-    """Time-major batch [T*B, 4C, h, w] -> PixelShuffle(2) -> frames [B, T, C, 2h, 2w]."""
-    return D2SFramesFn.apply(x, t)
-
-
-class CatChannelsFn(Function):
-    """torch.cat(dim=1) on channels-last tensors; `interleave`: 'b t c h w -> b (c t) h w' (common.py:423)."""
-
-    @staticmethod
-    def forward(ctx, interleave: bool, *xs):
-        xs = [to_cl(x) for x in xs]
-        require_hip(xs[0])
-        cs = [x.shape[1] for x in xs]
-        ctot = sum(cs)
-        shape = list(xs[0].shape)
-        shape[1] = ctot
-        out = empty_cl(shape, xs[0])
-        r = xs[0].numel() // cs[0]
-        off = 0
-        for i, x in enumerate(xs):
-            if interleave:
-                call("dgmr_copy_channels", _p(x), _p(out), r, cs[i], cs[i], 0, 1, ctot, i, len(xs), 0, _stream())
-            else:
-                call("dgmr_copy_channels", _p(x), _p(out), r, cs[i], cs[i], 0, 1, ctot, off, 1, 0, _stream())
-            off += cs[i]
-        ctx.cs, ctx.interleave, ctx.r = cs, interleave, r
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        dout = to_cl(dout)
-        cs, ctot = ctx.cs, sum(ctx.cs)
-        outs = []
-        off = 0
-        for i, c in enumerate(cs):
-            shape = list(dout.shape)
-            shape[1] = c
-            dx = empty_cl(shape, dout)
-            if ctx.interleave:
-                call("dgmr_copy_channels", _p(dout), _p(dx), ctx.r, c, ctot, i, len(cs), c, 0, 1, 0, _stream())
-            else:
-                call("dgmr_copy_channels", _p(dout), _p(dx), ctx.r, c, ctot, off, 1, c, 0, 1, 0, _stream())
-            outs.append(dx)
-            off += c
-        return (None, *outs)
-
-
-def cat_channels(xs: Sequence[torch.Tensor], interleave: bool = False):
-    return CatChannelsFn.apply(interleave, *xs)
-
-
-class RepeatBatchFn(Function):
-    """einops 'b c h w -> (repeat b) c h w' (generators.py:146-148 at b == 1): the whole batch tiled `repeat` times."""
-
-    @staticmethod
-    def forward(ctx, x, repeat: int):
-        require_hip(x)
-        x = to_cl(x)
-        out = empty_cl((repeat * x.shape[0],) + tuple(x.shape[1:]), x)
-        call("dgmr_repeat_rows", _p(x), _p(out), x.numel(), repeat, _stream())
-        ctx.repeat = repeat
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        dout = to_cl(dout)
-        n = dout.numel() // ctx.repeat
-        dx = empty_cl((dout.shape[0] // ctx.repeat,) + tuple(dout.shape[1:]), dout)
-        tmp = torch.empty(2 * n, device=dout.device, dtype=torch.float64)
-        call("dgmr_colsum", _p(dout), _p(dx), _p(tmp), ctx.repeat, n, 0, _stream())
-        return dx, None
-
-
-def repeat_batch(x, repeat: int):
-    return RepeatBatchFn.apply(x, repeat)
-
-
-# ---------------------------------------------------------------------------------------------------
 # ConvGRU gating (dgmr/layers/ConvGRU.py:69-85)
 # ---------------------------------------------------------------------------------------------------
 class GruGateFn(Function):
@@ -1443,421 +926,3 @@ class ConvGRUFn(Function):
 
 def conv_gru(x_all, h0, params, seqs, steps: int, x_shared: bool = False, draws: int = 1):
     return ConvGRUFn.apply(x_all, h0, params, seqs, steps, x_shared, draws, params[0])
-
-
-# ---------------------------------------------------------------------------------------------------
-# latent attention (dgmr/layers/Attention.py:9-20,78-82)
-# ---------------------------------------------------------------------------------------------------
-class AttentionFn(Function):
-    @staticmethod
-    def forward(ctx, q, k, v):
-        q, k, v = to_cl(q), to_cl(k), to_cl(v)
-        require_hip(q)
-        b, cq, h, w = q.shape
-        if v.shape[1] != cq:
-            raise RuntimeError("attention: ratio_kq must equal ratio_v (the reference's einsum requires it)")
-        L = cq * h
-        out = torch.empty_like(v)
-        beta = torch.empty(b, L, L, device=q.device, dtype=torch.float32)
-        n = cq * h * w
-        for i in range(b):
-            o = 4 * n * i
-            call("dgmr_attention_fwd", q.data_ptr() + o, k.data_ptr() + o, v.data_ptr() + o, beta.data_ptr() + 4 * L * L * i,
-                 out.data_ptr() + o, cq, h, w, _stream())
-        ctx.save_for_backward(q, k, v, beta)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        q, k, v, beta = ctx.saved_tensors
-        dout = to_cl(dout)
-        b, cq, h, w = q.shape
-        L = cq * h
-        n = cq * h * w
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        tmp = torch.empty(L * L, device=q.device, dtype=torch.float32)
-        for i in range(b):
-            o = 4 * n * i
-            call("dgmr_attention_bwd", dout.data_ptr() + o, q.data_ptr() + o, k.data_ptr() + o, v.data_ptr() + o,
-                 beta.data_ptr() + 4 * L * L * i, dq.data_ptr() + o, dk.data_ptr() + o, dv.data_ptr() + o, _p(tmp), cq, h, w,
-                 _stream())
-        return dq, dk, dv
-
-
-attention = AttentionFn.apply
-
-
-# ---------------------------------------------------------------------------------------------------
-# discriminator heads (discriminators.py:127-131,217-219)
-# ---------------------------------------------------------------------------------------------------
-class ReluSumHWFn(Function):
-    @staticmethod
-    def forward(ctx, x):
-        require_hip(x)
-        x = to_cl(x)
-        n, c, h, w = x.shape
-        y = torch.empty(n, c, device=x.device, dtype=torch.float32)
-        call("dgmr_relu_sum_hw_fwd", _p(x), _p(y), n, h * w, c, _stream())
-        ctx.save_for_backward(x)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        n, c, h, w = x.shape
-        dx = torch.empty_like(x)
-        call("dgmr_relu_sum_hw_bwd", _p(dy.contiguous()), _p(x), _p(dx), n, h * w, c, _stream())
-        return dx
-
-
-relu_sum_hw = ReluSumHWFn.apply
-
-
-class BatchNorm1dFn(Function):
-    """torch.nn.BatchNorm1d on [N, C] (discriminators.py:102,129,194,218), batch statistics in train mode."""
-
-    @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, eps, momentum, train, groups=1, layout=None):
-        require_hip(x)
-        x = x.contiguous()
-        n, c = x.shape
-        st = bn_prepare(x.view(n, c, 1, 1), gamma, beta, running_mean, running_var, nbt, eps, momentum, train, groups, layout)
-        y = torch.empty_like(x)
-        if st.groups > 1:
-            call("dgmr_affine", _p(x), _p(st.a), _p(st.b), _p(y), st.groups, n // st.groups, c, 0, _stream())
-        else:
-            call("dgmr_affine", _p(x), _p(st.a), _p(st.b), _p(y), 1, n, c, 0, _stream())
-        ctx.st = st
-        ctx.save_for_backward(x, st.mean, st.rstd)  # see ConvFn.forward: nothing tensor-valued may be read from ctx.st
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, mean, rstd = ctx.saved_tensors
-        st: BNState = ctx.st
-        n, c = x.shape
-        dy = dy.contiguous()
-        gq = st.groups
-        sums = torch.zeros(gq * 2 * c, device=x.device, dtype=torch.float64)
-        call("dgmr_bn_bwd_reduce", _p(dy), _p(x), _p(mean), _p(rstd), _p(sums), gq, n // gq, c, _stream())
-        dx = torch.empty_like(x)
-        dgam = grad_buffer(st.gamma) if st.gamma.requires_grad else None
-        dbet = grad_buffer(st.beta) if st.beta.requires_grad else None
-        call("dgmr_bn_bwd_apply", _p(dy), _p(x), _p(mean), _p(rstd), _p(st.gamma), _p(sums), None, _p(dx), _p(dgam), _p(dbet),
-             gq, n // gq, c, int(st.train), _stream())
-        return dx, None, None, None, None, None, None, None, None, None, None
-
-
-class SNLinear1Fn(Function):
-    """spectral_norm(Linear(C, 1)) (discriminators.py:100,192); `sn.groups` calls (frames) per launch."""
-
-    @staticmethod
-    def forward(ctx, x, w, bias, sn: SNCall):
-        require_hip(x)
-        x = x.contiguous()
-        n, c = x.shape
-        if n % sn.groups:
-            raise RuntimeError(f"linear: {n} rows are not divisible into {sn.groups} spectral-norm call groups")
-        y = torch.empty(n, 1, device=x.device, dtype=torch.float32)
-        call("dgmr_linear1_fwd", _p(x), _p(w), _p(bias), _p(sn.inv_sigma), _p(y), n, c, n // sn.groups, _stream())
-        ctx.groups = sn.groups
-        ctx.params = (w, bias)
-        ctx.save_for_backward(x, sn.inv_sigma, sn.u, sn.v)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, inv_sigma, sn_u, sn_v = ctx.saved_tensors
-        w, bias = ctx.params
-        n, c = x.shape
-        gq = ctx.groups
-        dy = dy.contiguous()
-        dev = x.device
-        dx = torch.empty_like(x)
-        g = torch.empty(gq * c, device=dev, dtype=torch.float32)
-        gb = torch.empty(1, device=dev, dtype=torch.float32)
-        st = _stream()
-        call("dgmr_linear1_bwd", _p(dy), _p(x), _p(w), _p(inv_sigma), _p(dx), _p(g), _p(gb), n, c, n // gq, st)
-        if bias is not None and bias.requires_grad:
-            b = grad_buffer(bias)
-            call("dgmr_axpby", _p(b), _p(gb), _p(b), 1.0, 1.0, 1, st)
-        if w.requires_grad:
-            dot = torch.zeros(gq, device=dev, dtype=torch.float32)
-            g2 = torch.empty(c, device=dev, dtype=torch.float32)
-            call("dgmr_wgrad_reduce", _p(g), gq, gq, c, _p(w), _p(inv_sigma), _p(g2), _p(dot), st)
-            call("dgmr_sn_wgrad_finalize", _p(g2), _p(grad_buffer(w)), _p(dot), _p(inv_sigma), _p(sn_u), _p(sn_v), 1, c, 1, gq, 1, st)
-        return dx, None, None, None
-
-
-# ---------------------------------------------------------------------------------------------------
-# batch <-> list / time <-> channel layout moves for the T-batched modules
-# ---------------------------------------------------------------------------------------------------
-def _copy(src_ptr, dst_ptr, n):
-    call("dgmr_axpby", src_ptr, None, dst_ptr, 1.0, 0.0, n, _stream())
-
-
-class StackBatchFn(Function):
-    """T tensors [B, ...] -> one [T*B, ...] (time-major): the per-step outputs of a ConvGRU become ONE batch, so that the
-    1x1 / G-block / upsample-G-block convs of all forecast steps run as one launch (generators.py:153-171)."""
-
-    @staticmethod
-    def forward(ctx, *xs):
-        xs = [to_cl(x) for x in xs]
-        require_hip(xs[0])
-        b = xs[0].shape[0]
-        out = empty_cl((b * len(xs),) + tuple(xs[0].shape[1:]), xs[0])
-        n = xs[0].numel()
-        for i, x in enumerate(xs):
-            _copy(_p(x), out.data_ptr() + 4 * n * i, n)
-        ctx.t, ctx.b = len(xs), b
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        dout = to_cl(dout)
-        n = dout.numel() // ctx.t
-        outs = []
-        for i in range(ctx.t):
-            g = empty_cl((ctx.b,) + tuple(dout.shape[1:]), dout)
-            _copy(dout.data_ptr() + 4 * n * i, _p(g), n)
-            outs.append(g)
-        return tuple(outs)
-
-
-def stack_batch(xs):
-    return StackBatchFn.apply(*xs)
-
-
-class UnstackBatchFn(Function):
-    """[T*B, ...] -> T tensors [B, ...]; the backward writes each gradient into its slot of one buffer."""
-
-    @staticmethod
-    def forward(ctx, x, t: int):
-        require_hip(x)
-        x = to_cl(x)
-        b = x.shape[0] // t
-        n = x.numel() // t
-        outs = []
-        for i in range(t):
-            o = empty_cl((b,) + tuple(x.shape[1:]), x)
-            _copy(x.data_ptr() + 4 * n * i, _p(o), n)
-            outs.append(o)
-        ctx.t, ctx.shape = t, tuple(x.shape)
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, *douts):
-        ref = next(d for d in douts if d is not None)
-        dx = empty_cl(ctx.shape, ref)
-        n = dx.numel() // ctx.t
-        for i, d in enumerate(douts):
-            if d is None:
-                call("dgmr_fill", dx.data_ptr() + 4 * n * i, 0.0, n, _stream())
-            else:
-                _copy(_p(to_cl(d)), dx.data_ptr() + 4 * n * i, n)
-        return dx, None
-
-
-def unstack_batch(x, t: int):
-    return list(UnstackBatchFn.apply(x, t))
-
-
-class TimeToChannelsFn(Function):
-    """[T*B, C, h, w] (time-major batch) -> [B, C*T, h, w] with channel index c*T + t: einops 'b t c h w -> b (c t) h w'
-    (common.py:423) read straight from the batched D-block output."""
-
-    @staticmethod
-    def forward(ctx, x, t: int, outer: int = 1):
-        """outer > 1: x is [outer][T][B] (several generator draws, draw-major) -> [outer * B, C*T, h, w]."""
-        require_hip(x)
-        x = to_cl(x)
-        otb, c, h, w = x.shape
-        b = otb // (t * outer)
-        out = empty_cl((outer * b, c * t, h, w), x)
-        r = b * h * w
-        for o in range(outer):
-            for i in range(t):
-                call("dgmr_copy_channels", x.data_ptr() + 4 * r * c * (o * t + i), out.data_ptr() + 4 * r * c * t * o, r, c, c, 0, 1,
-                     c * t, i, t, 0, _stream())
-        ctx.geom = (t, b, c, h, w, outer)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        t, b, c, h, w, outer = ctx.geom
-        dout = to_cl(dout)
-        dx = empty_cl((outer * t * b, c, h, w), dout)
-        r = b * h * w
-        for o in range(outer):
-            for i in range(t):
-                call("dgmr_copy_channels", dout.data_ptr() + 4 * r * c * t * o, dx.data_ptr() + 4 * r * c * (o * t + i), r, c, c * t, i,
-                     t, c, 0, 1, 0, _stream())
-        return dx, None, None
-
-
-def time_to_channels(x, t: int, outer: int = 1):
-    return TimeToChannelsFn.apply(x, t, outer)
-
-
-class FramesToBatchFn(Function):
-    """[N, C, T, h, w] (channels_last_3d, i.e. N T h w C) -> frame-major batch [T*N, C, h, w]: every `x[:, :, idx]` of the
-    temporal discriminator's loop at once (discriminators.py:119-120)."""
-
-    @staticmethod
-    def forward(ctx, x):
-        require_hip(x)
-        x = to_cl(x)
-        n, c, t, h, w = x.shape
-        out = empty_cl((t * n, c, h, w), x)
-        call("dgmr_permute_nt", _p(x), _p(out), n, t, h * w * c, _stream())
-        ctx.geom = (n, c, t, h, w)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        n, c, t, h, w = ctx.geom
-        dout = to_cl(dout)
-        dx = empty_cl((n, c, t, h, w), dout)
-        call("dgmr_permute_nt", _p(dout), _p(dx), t, n, h * w * c, _stream())
-        return dx
-
-
-frames_to_batch = FramesToBatchFn.apply
-
-
-class SumGroupsFn(Function):
-    """[G*N, 1] -> [N, 1]: sum over the G frame groups (torch.sum(torch.stack(reps, dim=1), dim=1), discriminators.py:134-137)."""
-
-    @staticmethod
-    def forward(ctx, x, groups: int):
-        require_hip(x)
-        x = x.contiguous()
-        n = x.shape[0] // groups
-        out = torch.empty(n, 1, device=x.device, dtype=torch.float32)
-        tmp = torch.empty(2 * n, device=x.device, dtype=torch.float64)
-        call("dgmr_colsum", _p(x), _p(out), _p(tmp), groups, n, 0, _stream())
-        ctx.groups, ctx.n = groups, n
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        dout = dout.contiguous()
-        dx = torch.empty(ctx.groups * ctx.n, 1, device=dout.device, dtype=torch.float32)
-        for i in range(ctx.groups):
-            _copy(_p(dout), dx.data_ptr() + 4 * ctx.n * i, ctx.n)
-        return dx, None
-
-
-sum_groups = SumGroupsFn.apply
-
-
-# ---------------------------------------------------------------------------------------------------
-# losses (dgmr/losses.py:172-192,307-319 ; dgmr/dgmr.py:20-33)
-# ---------------------------------------------------------------------------------------------------
-class HingeDiscFn(Function):
-    @staticmethod
-    def forward(ctx, score_generated, score_real):
-        require_hip(score_real)
-        sg, sr = score_generated.contiguous(), score_real.contiguous()
-        loss = torch.empty((), device=sr.device, dtype=torch.float32)
-        dg, dr = torch.empty_like(sg), torch.empty_like(sr)
-        call("dgmr_hinge_disc", _p(sr), _p(sg), _p(loss), _p(dr), _p(dg), sr.numel(), sg.numel(), _stream())
-        ctx.save_for_backward(dg, dr)
-        return loss
-
-    @staticmethod
-    def backward(ctx, gl):
-        dg, dr = ctx.saved_tensors
-        gl = gl.contiguous()
-        og, orr = torch.empty_like(dg), torch.empty_like(dr)
-        call("dgmr_scale_by_dev", _p(dg), _p(gl), 1.0, _p(og), dg.numel(), _stream())
-        call("dgmr_scale_by_dev", _p(dr), _p(gl), 1.0, _p(orr), dr.numel(), _stream())
-        return og, orr
-
-
-class MeanFn(Function):
-    """sign * mean(x) (loss_hinge_gen = -mean)."""
-
-    @staticmethod
-    def forward(ctx, x, sign: float):
-        require_hip(x)
-        x = x.contiguous()
-        n = x.numel()
-        out = torch.empty((), device=x.device, dtype=torch.float32)
-        tmp = torch.empty(2, device=x.device, dtype=torch.float64)
-        call("dgmr_colsum", _p(x), _p(out), _p(tmp), n, 1, 0, _stream())
-        call("dgmr_axpby", _p(out), None, _p(out), sign / n, 0.0, 1, _stream())
-        ctx.n, ctx.sign, ctx.shape = n, sign, x.shape
-        return out
-
-    @staticmethod
-    def backward(ctx, gl):
-        g = torch.empty(ctx.shape, device=gl.device, dtype=torch.float32)
-        ones = torch.ones(ctx.shape, device=gl.device, dtype=torch.float32)
-        call("dgmr_scale_by_dev", _p(ones), _p(gl.contiguous()), ctx.sign / ctx.n, _p(g), ctx.n, _stream())
-        return g, None
-
-
-class GridCellFn(Function):
-    """GridCellLoss on the mean of K stacked predictions: || (mean_k g_k - y) * max(y+1, cap) ||_1 / T * H * W."""
-
-    @staticmethod
-    def forward(ctx, preds, targets, cap: float, weights=None):
-        """`weights`: explicit per-element weights (a caller-supplied weight_fn evaluated on the targets); None = the reference's
-        default max(y + 1, cap), evaluated inside the kernel."""
-        require_hip(preds)
-        preds, targets = preds.contiguous(), targets.contiguous()
-        if weights is not None:
-            weights = weights.expand_as(targets).contiguous().float()
-        k = preds.shape[0]
-        n = targets.numel()
-        mult = float(targets.size(3) * targets.size(4)) / float(targets.size(1))
-        loss = torch.empty((), device=preds.device, dtype=torch.float32)
-        acc = torch.zeros(1, device=preds.device, dtype=torch.float64)
-        dweight = torch.empty_like(targets)
-        call("dgmr_grid_cell_loss", _p(preds), k, n, _p(targets), _p(weights), float(cap), _p(acc), _p(loss), mult, _p(dweight), n,
-             _stream())
-        ctx.save_for_backward(dweight)
-        ctx.k, ctx.mult = k, mult
-        return loss
-
-    @staticmethod
-    def backward(ctx, gl):
-        (dweight,) = ctx.saved_tensors
-        n = dweight.numel()
-        g1 = torch.empty_like(dweight)
-        call("dgmr_scale_by_dev", _p(dweight), _p(gl.contiguous()), ctx.mult, _p(g1), n, _stream())
-        return g1.unsqueeze(0).expand(ctx.k, *dweight.shape), None, None, None
-
-
-class AxpbyFn(Function):
-    """alpha*a + beta*b on device (loss bookkeeping without torch arithmetic kernels)."""
-
-    @staticmethod
-    def forward(ctx, a, b, alpha: float, beta: float):
-        require_hip(a)
-        a, b = a.contiguous(), b.contiguous()
-        out = torch.empty_like(a)
-        call("dgmr_axpby", _p(a), _p(b), _p(out), alpha, beta, a.numel(), _stream())
-        ctx.ab = (alpha, beta)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        alpha, beta = ctx.ab
-        g = g.contiguous()
-        ga, gb = torch.empty_like(g), torch.empty_like(g)
-        call("dgmr_axpby", _p(g), None, _p(ga), alpha, 0.0, g.numel(), _stream())
-        call("dgmr_axpby", _p(g), None, _p(gb), beta, 0.0, g.numel(), _stream())
-        return ga, gb, None, None
-
-
-def axpby(a, b, alpha=1.0, beta=1.0):
-    return AxpbyFn.apply(a, b, float(alpha), float(beta))
-
-
-# ---------------------------------------------------------------------------------------------------
-# Adam (dgmr/dgmr.py:292-300)
-# ---------------------------------------------------------------------------------------------------
-def adam_update(p, g, m, v, step, lr, beta1, beta2, eps=1e-8):
-    call("dgmr_adam", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step), _stream())
