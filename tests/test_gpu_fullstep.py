@@ -22,11 +22,14 @@ What is compared (float32 oracle = the reference's arithmetic, float64 oracle = 
     tests/test_gpu_fullsize.py::test_discriminator_fwd_bwd_paper_config);
   * the discriminator gradients of the second pass (after one Adam update, whose +-lr steps on noise elements differ between any two
     fp32 implementations): cosine >= 0.9999 and 2e-2 of max;
-  * every buffer after the step (u, v, BatchNorm running mean / var / num_batches_tracked): within max(1e-3, factor x the distance
-    between the float32 and the float64 oracle) of the float64 oracle, relative to the tensor's max (the BatchNorm1d running variance
-    of the heads over 4 near-identical rows and the u / v of weights that took an Adam step of +-lr per element are the
-    ill-conditioned ones: the two oracles themselves differ by up to 2e-3 there) - this is what pins the call-group ORDER at the
-    benchmarked size: a swapped pair of calls moves u / v and the running statistics by 1e-1 ... 1;
+  * every buffer after the step (u, v, BatchNorm running mean / var / num_batches_tracked): within max(floor, factor x the distance
+    between the float32 and the float64 oracle) of the float64 oracle, relative to the tensor's max; floor = 3e-3 in exact f32, 5e-3
+    in "mixed".  Why not 1e-3: with beta1 = 0 Adam moves EVERY weight by +-lr per step whatever its gradient's size, so an element
+    whose gradient is rounding noise goes the other way in any second fp32 implementation (2 lr = 4e-4 apart on weights of size
+    ~3e-2); the u / v of a weight that took two such steps before its last power iteration then differ by 1e-3 ... 3e-3 (measured:
+    1.2e-3 worst in f32, 3.2e-3 in mixed; the test prints how many buffers stay within 1e-3), and the heads' BatchNorm1d running variance over 4
+    near-identical rows by up to 6e-3 with the two oracles themselves 2e-3 apart.  What this check is for - the call-group ORDER at
+    the benchmarked size - moves u / v and the running statistics by 1e-1 ... 1 when a pair of calls is swapped;
   * the 12 parameters the reference never gives a gradient are untouched.
 """
 import pytest
@@ -160,9 +163,9 @@ def test_training_step_paper_config_vs_oracle(initial, oracle_step, precision, t
     dead = [k for k, p in model.named_parameters() if p.grad is None]
     assert len(dead) == 12, dead
     # ---- every buffer after the step ----
-    factor = 10.0 if precision == "mixed" else 3.0
+    factor, floor = (10.0, 5e-3) if precision == "mixed" else (3.0, 3e-3)
     sd1 = model.state_dict()
-    bad, worst = [], (0.0, "")
+    bad, worst, n_buf, n_tight = [], (0.0, ""), 0, 0
     for k, ref in r64["buffers"].items():
         got = sd1[k].detach().cpu()
         if not ref.is_floating_point():
@@ -173,7 +176,9 @@ def test_training_step_paper_config_vs_oracle(initial, oracle_step, precision, t
         band = (r32["buffers"][k].double() - ref).abs().max().item() / scale
         if err > worst[0]:
             worst = (err, k)
-        if err > max(1e-3, factor * band) + 1e-9:
+        if err > max(floor, factor * band) + 1e-9:
             bad.append((k, err, band))
-    print(f"buffers after the step [{precision}]: worst {worst[1]} at {worst[0]:.2e} of its max")
-    assert not bad, f"{len(bad)} buffers beyond max(1e-3, {factor:g} x fp32 band) after the step: {sorted(bad, key=lambda t: -t[1])[:8]}"
+        n_buf += 1
+        n_tight += err <= 1e-3
+    print(f"buffers after the step [{precision}]: worst {worst[1]} at {worst[0]:.2e} of its max; {n_tight} of {n_buf} within 1e-3")
+    assert not bad, f"{len(bad)} buffers beyond max({floor:g}, {factor:g} x fp32 band) after the step: {sorted(bad, key=lambda t: -t[1])[:8]}"
