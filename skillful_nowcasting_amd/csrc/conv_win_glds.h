@@ -148,11 +148,15 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
     const int cq = tid & 7;
     uint32_t a_goff[APASS];
     unsigned a_valid = 0;
+    // (pix / HP and prem / HTw by reciprocal multiplication: an integer division by a run-time divisor is ~35 VALU instructions, and
+    //  the 2 x APASS of them were a third of a tile's set-up.  Exact: pix + 0.5 is at least 0.5 / HP = 1.5e-3 away from every multiple
+    //  of HP in relative terms, the float error is 1e-6.)
+    const float inv_hp = 1.f / (float)HP, inv_htw = 1.f / (float)HTw;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
         const int pix = (tid >> 3) + i * 32;
-        const int sub = pix / HP, prem = pix - sub * HP;
-        const int lr = prem / HTw, lc = prem - lr * HTw;
+        const int sub = (int)(((float)pix + 0.5f) * inv_hp), prem = pix - sub * HP;
+        const int lr = (int)(((float)prem + 0.5f) * inv_htw), lc = prem - lr * HTw;
         const int ih = oh + lr, iw = ow + lc;
         const bool ok = pix < npix && (unsigned)ih < (unsigned)Hs && (unsigned)iw < (unsigned)Ws;
         a_goff[i] = !ok ? 0u
