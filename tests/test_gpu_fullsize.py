@@ -264,8 +264,12 @@ def test_discriminator_fwd_bwd_paper_config(setup, precision, tol, data):
         S.set_precision("f32")
     ref = _oracle_d(setup, data, aligner)
     kinks = aligner.report()
-    print(f"\nrelu masks that differ from the oracle's own sign [{precision}, {data}]: "
-          + (", ".join(f"{t} ({d.replace('torch.', '')}): {n} elements, |x| <= {r:.1e} of max" for t, d, n, r in kinks) or "none"))
+    from conftest import _log_band
+
+    msg = (f"relu masks that differ from the oracle's own sign [{precision}, {data}]: "
+           + (", ".join(f"{t} ({d.replace('torch.', '')}): {n} elements, |x| <= {r:.1e} of max" for t, d, n, r in kinks) or "none"))
+    print("\n" + msg)
+    _log_band(msg)
     # a mask may differ from the oracle's sign only where the pre-activation is rounding noise
     lim = {"f32": 2e-5, "bf16x6": 2e-5, "mixed": 2e-5, "bf16x3": 2e-3}[precision]
     assert all(r <= lim for _, d, _, r in kinks if d == "torch.float64"), kinks
