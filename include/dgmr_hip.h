@@ -446,13 +446,15 @@ int dgmr_profile_collect2(double* total_ms, double* total_flops, double* execute
  * also the state at load): variant = index of a conv_fwd_dgrad<..> tile as listed by dgmr_profile_variant_name, ksplit = number
  * of K slabs (needs a workspace in the args), window = 0 never / 1 the register-staged LDS-window 3x3 kernel whenever the geometry allows / 2 likewise, with the experimental
  * 256-pixel tiles / 3 the LDS-DMA window kernel where eligible (what -1 picks, but also below the automatic size threshold);
- * wgrad_window = 0 never / 1 (= automatic) the LDS-window weight-gradient kernel wherever the geometry allows. */
+ * wgrad_window = 0 never an LDS-window weight-gradient kernel / 1 the one-role kernel of round 2 (wgrad_win.h) wherever the geometry
+ * allows / 2 (= automatic) the wave-specialised one (wgrad_ws.h: loader waves + matrix waves, ds_read_b64_tr_b16 fragments). */
 int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window);
 /* Kernel-phase timing switches for tools/conv_bench.py (process-wide, 0 at load and in every product launch): bit 0 = the LDS-window
  * conv kernels return before their epilogue, bit 1 = they stage only their first input halo.  Outputs are then garbage by design;
  * only the launch duration is meaningful (how much of a launch is operand staging / matrix work / epilogue).  Bit 3 (8) = the
  * window kernels use their lane-per-channel epilogue instead of the 16-byte one (A/B: results are bit-identical); 64 / 128 = every
- * wave sleeps ~3.4 / ~6.8 us after issuing its last store (how long does a finished wave wait for its stores anyway?). */
+ * wave sleeps ~3.4 / ~6.8 us after issuing its last store (how long does a finished wave wait for its stores anyway?); 16 = the
+ * wave-specialised weight-gradient kernel without its matrix work (the loaders' time alone). */
 int dgmr_debug_flags(int flags);
 
 #ifdef __cplusplus

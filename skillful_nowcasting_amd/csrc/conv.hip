@@ -832,6 +832,9 @@ static bool wgrad_uses_window(const dgmr_wgrad_args* a) {
     return g_precision != 0 && g_tune_wgrad_window != 0 && a->KD == 1 && a->KH == 3 && a->KW == 3 && a->D == 1 &&
            ((a->W % 32 == 0 && a->H % 2 == 0) || (a->W == 16 && a->H % 4 == 0));
 }
+// which of the two window kernels: the wave-specialised one (wgrad_ws.h; dgmr_conv_tune wgrad_window 2 = automatic) or the one-role
+// kernel of round 2 (wgrad_win.h; 1)
+static bool wgrad_ws() { return g_tune_wgrad_window != 1; }
 // tiles of 64 pixels: 2 x 32, or 4 x 16 on 16-pixel-wide maps
 static int wgrad_window_tw_shift(const dgmr_wgrad_args* a) { return a->W % 32 == 0 ? 5 : 4; }
 
@@ -848,7 +851,8 @@ extern "C" int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a) {
     // measures better than 1.5 rounds (tail) and than many small slabs (partial-sum traffic); >= 2 tiles of 64 pixels per slab
     const int per_slab = ((a->Cin + 31) / 32) * (a->Cout % 96 == 0 ? a->Cout / 96 : (a->Cout + 63) / 64);
     const int64_t tiles_per_group = (int64_t)(a->N / groups) * ((int64_t)a->H * a->W / 64);
-    int64_t per = 512 / ((int64_t)per_slab * groups);  // slabs per group
+    // (the wave-specialised kernel, wgrad_ws.h, has ONE workgroup per CU: one round of <= 256)
+    int64_t per = (wgrad_ws() ? 256 : 512) / ((int64_t)per_slab * groups);  // slabs per group
     per = std::min<int64_t>(per, tiles_per_group / 2);
     per = std::max<int64_t>(per, 1);
     a->nsplit = (int)std::min<int64_t>(per * groups, 4096);
@@ -885,7 +889,8 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
         const int tiles_per_split = (tiles_per_group + spg - 1) / spg;
         const bool b96 = a->Cout % 96 == 0;
         const dim3 grid((a->Cin + 31) / 32, b96 ? a->Cout / 96 : (a->Cout + 63) / 64, a->nsplit);
-        DGMR_BY_NS(launch_wgrad_window, p, grid, tw_shift, tiles_w, tiles_hw, tiles_per_split, spg, tiles_per_group, s);
+        DGMR_BY_NS(launch_wgrad_window, p, grid, tw_shift, tiles_w, tiles_hw, tiles_per_split, spg, tiles_per_group,
+                   wgrad_ws() ? (1 | ((g_debug_flags & 16) >> 3)) : 0, s);
         DGMR_CHECK_LAUNCH();
         return 0;
     }
@@ -1045,7 +1050,7 @@ extern "C" int dgmr_get_precision(void) { return g_precision; }
 
 extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window) {
     DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 5 && wgrad_window >= -1 &&
-                       wgrad_window <= 1,
+                       wgrad_window <= 2,
                    "dgmr_conv_tune: variant %d ksplit %d window %d wgrad_window %d", variant, ksplit, window, wgrad_window);
     g_tune_variant = variant;
     g_tune_ksplit = ksplit;

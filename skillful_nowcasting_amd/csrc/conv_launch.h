@@ -26,7 +26,8 @@ inline int ns_of_precision(int prec) { return prec == 1 ? 3 : (prec == 2 ? 1 : 6
     DGMR_HIDDEN int launch_gemm_ns##NS(int variant, const dgmr_conv_args& p, int M, int Ktot, int kt_per_split, dim3 grid,           \
                                        hipStream_t s);                                                                               \
     DGMR_HIDDEN int launch_wgrad_window_ns##NS(const dgmr_wgrad_args& p, dim3 grid, int tw_shift, int tiles_w, int tiles_hw,         \
-                                               int tiles_per_split, int splits_per_group, int tiles_per_group, hipStream_t s);      \
+                                               int tiles_per_split, int splits_per_group, int tiles_per_group, int ws,         \
+                                               hipStream_t s);                                                                        \
     DGMR_HIDDEN int launch_wgrad_gemm_ns##NS(const dgmr_wgrad_args& p, int bi, dim3 grid, int M, int Ktot, int rows_per_split,       \
                                              int splits_per_group, int rows_per_group, hipStream_t s);
 DGMR_TU_DECLARE(1)

@@ -2,6 +2,7 @@
 // compile with -DDGMR_NS=1 | 3 | 6.  Called from dgmr_conv_wgrad (conv.hip).
 #include "conv_launch.h"
 #include "wgrad_win.h"
+#include "wgrad_ws.h"
 
 #ifndef DGMR_NS
 #error "compile with -DDGMR_NS=1|3|6"
@@ -10,9 +11,23 @@
 namespace dgmr_tu {
 
 int DGMR_TU_CAT(launch_wgrad_window_ns, DGMR_NS)(const dgmr_wgrad_args& p, dim3 grid, int tw_shift, int tiles_w, int tiles_hw,
-                                                 int tiles_per_split, int splits_per_group, int tiles_per_group, hipStream_t s) {
+                                                 int tiles_per_split, int splits_per_group, int tiles_per_group, int ws, hipStream_t s) {
     constexpr int NS = DGMR_NS;
     const bool b96 = p.Cout % 96 == 0;
+    if (ws) {  // wave-specialised kernel (wgrad_ws.h): 3 matrix + 4 loader waves
+#define DGMR_WGS(BI_, TWS_)                                                                                                      \
+    hipLaunchKernelGGL((conv_wgrad_ws_kernel<BI_, NS, TWS_>), dim3(grid.x * grid.y * grid.z), dim3(448), 0, s, p, tiles_w, tiles_hw, tiles_per_split, \
+                       splits_per_group, tiles_per_group, ws)
+        if (b96) {
+            if (tw_shift == 5) DGMR_WGS(96, 5);
+            else DGMR_WGS(96, 4);
+        } else {
+            if (tw_shift == 5) DGMR_WGS(64, 5);
+            else DGMR_WGS(64, 4);
+        }
+#undef DGMR_WGS
+        return 0;
+    }
 #define DGMR_WGW(BI_, TWS_)                                                                                                       \
     hipLaunchKernelGGL((conv_wgrad_win_kernel<BI_, NS, TWS_>), grid, dim3(192), 0, s, p, tiles_w, tiles_hw, tiles_per_split, \
                        splits_per_group, tiles_per_group)

@@ -1,0 +1,347 @@
+// Weight gradient of a 3x3 convolution, WAVE-SPECIALISED (round 3): four loader waves keep a double-buffered LDS image of the next
+// tile coming while three matrix waves multiply the current one.
+//
+//   G[co][tap][ci] = sum over pixels  dY[n,h,w,co] * pre(x)[n, h+dy, w+dx, ci]     (autograd of F.conv2d at every `spectral_norm(conv)`
+//                                                                                   call of the reference)
+//
+// conv_wgrad_win_kernel (wgrad_win.h) does the same arithmetic with ONE set of waves: fetch the tile, transpose it 4 px x 4 ch in
+// registers, store it [channel][pixel] through conflicted 8-byte LDS writes, barrier, 108 MFMAs per wave, barrier - nothing overlaps
+// inside a workgroup and two of them share a CU: a CU finishes a 64-pixel tile every ~12 000 cycles where the matrix work is 3 456
+// (profiles/r03_probe_wgrad_full_batch.log: 181 - 303 TF against 314 - 354 for the forward of the same layers).  Here
+//   * the tiles stay PIXEL-MAJOR in LDS exactly as they arrive from HBM ([pixel][32 ci], [pixel][BI co], bf16 planes): the loaders only
+//     apply the fused BatchNorm / ReLU prologue, split into planes and issue lane-linear ds_write_b64 - no register transposes;
+//   * the matrix waves read their MFMA fragments with ds_read_b64_tr_b16, gfx950's transposing LDS read: within a 16-lane group lane i
+//     supplies the address of 4 consecutive 16-bit elements of row i / 4 (segment i % 4) and receives column i of that 4 x 16 block
+//     (decoded on the hardware: tools/probes/tr_read_probe.hip, profiles/r03_probe_ds_read_tr16_b64.log) - the reduction index (pixels)
+//     becomes the fragment's k without any data movement, and the +-1 shifts of the taps are plain row offsets;
+//   * LDS holds TWO tile images: while the matrix waves are on tile t the loaders store tile t + 1 (fetched two iterations earlier
+//     into one of two register sets: the HBM latency has two whole matrix phases to pass) - ONE barrier per tile;
+//   * wave w < 3 owns filter row w (3 taps x BI / 32 output-channel blocks = up to 9 accumulators [32 co x 32 ci], as before);
+//     one workgroup of 7 waves per CU (84 KB of LDS at BI = 96 in bf16x3);
+//   * the two roles are two DISJOINT programs (`if (loader) {...} else {...}`, each with its own loop) that meet at the same
+//     barriers - the hardware counts arriving waves, not code addresses.  In one shared loop with per-role bodies the compiler keeps
+//     the loaders' 104 staging registers and the 144 accumulators live together (1 KB of scratch per lane) and merges the two paths'
+//     s_waitcnt bookkeeping at every barrier, so that each store waits for nearly all loads in flight.
+// Output: partial[slab][co][tap*Cin + ci], the layout dgmr_wgrad_reduce* consume; bias gradient as in wgrad_win.h.
+#pragma once
+#include "conv_bf16.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// 8 bytes per lane, transposed across each 16-lane group; `p` points into LDS
+__device__ __forceinline__ s16x4 lds_read_tr(const uint32_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+#else
+    (void)p;
+    return (s16x4){0, 0, 0, 0};
+#endif
+}
+// MFMA fragment (8 consecutive k of this lane's row / column): k 0..3 from `p`, k 4..7 from four rows further
+__device__ __forceinline__ bf16x8_t tr_fragment(const uint32_t* p, int row4_dwords) {
+    const s16x4 lo = lds_read_tr(p), hi = lds_read_tr(p + row4_dwords);
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+constexpr int ws_gcd(int a, int b) { return b == 0 ? a : ws_gcd(b, a % b); }
+
+template <int BI, int NS, int TWS>
+__global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_args p, const int tiles_w, const int tiles_hw,
+                                                           const int tiles_per_split, const int splits_per_group,
+                                                           const int tiles_per_group, const int dbg) {
+    constexpr int NP = planes_of<NS>::value;
+    constexpr int CK = 32, CB = BI / 32;
+    constexpr int TW = 1 << TWS, TH = 64 >> TWS;      // 32 x 2 or 16 x 4 pixels
+    constexpr int HTW = TW + 2, HTH = TH + 2;          // halo: columns w0-1 .. w0+TW, rows h0-1 .. h0+TH
+    constexpr int HPIX = HTH * HTW;                    // 136 / 108 pixels
+    constexpr int XROW = CK / 2;                       // dwords per halo pixel: 32 bf16
+    constexpr int YROW = BI == 64 ? 36 : BI / 2;       // dwords per dY pixel: BI bf16 (64: padded to 144 B - 128-byte rows put rows p and p + 2 of a transposing read on the same banks)
+    constexpr int XPL = HPIX * XROW, YPL = 64 * YROW;  // dwords per plane
+    constexpr int BUF = NP * (XPL + YPL);              // dwords per tile image
+    constexpr int NL = 256;                            // loader threads (4 waves)
+    constexpr int XITEMS = HPIX * 8, YQ = BI / 4, YITEMS = 64 * YQ;  // 16-byte fp32 items of a tile: [pixel][4-channel quad]
+    constexpr int XP = (XITEMS + NL - 1) / NL, YP = YITEMS / NL;
+    // a loader thread's dY items i, i + BSN, ... have the same channel quad (items advance by NL % YQ quads): 3 (BI 96) / 1 (BI 64)
+    constexpr int BSN = NL % YQ == 0 ? 1 : YQ / ws_gcd(NL % YQ, YQ);
+    static_assert(BI == 64 || BI == 96, "BI");
+    static_assert(TWS == 5 || TWS == 4, "tile width");
+    static_assert(YITEMS % NL == 0 && YP % BSN == 0, "dY items per loader thread");
+
+    __shared__ __attribute__((aligned(16))) uint32_t smem[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the role branch and the loops below are uniform control flow)
+    // workgroups go to the 8 XCDs round-robin by linear index, each XCD with its own L2: give every XCD a CONTIGUOUS range of logical
+    // workgroups, so that the input-channel chunks (which all read the slab's dY) and the output-channel tiles (which all read its x)
+    // of one slab run side by side under one L2 instead of fetching the slab from HBM once per XCD
+    const int n_chunks = (p.Cin + CK - 1) / CK, n_cot = (p.Cout + BI - 1) / BI;
+    const int total = gridDim.x, xcd = blockIdx.x & 7, per_xcd = total >> 3, rem = total & 7;
+    const int wg = xcd * per_xcd + min(xcd, rem) + (blockIdx.x >> 3);
+    const int chunk = wg % n_chunks, wg2 = wg / n_chunks;
+    const int slab = wg2 / n_cot, co0 = (wg2 - slab * n_cot) * BI;
+    const int grp = slab / splits_per_group;
+    const int t_begin = grp * tiles_per_group + (slab - grp * splits_per_group) * tiles_per_split;
+    const int t_end = min((grp + 1) * tiles_per_group, t_begin + tiles_per_split);
+    const int nt = max(t_end - t_begin, 0);  // (0: a slab plan with more slabs than tiles - that slab's partial sums are zeros)
+    const bool want_bias = p.bias_grad && chunk == 0;  // (uniform per workgroup)
+    float* red = reinterpret_cast<float*>(smem);       // bias sums of the workgroup, after the last tile
+
+    if (wid >= 3) {
+        // ================================================ loaders ================================================
+        const int lt = tid - 192;  // 0 .. 255
+        const int xq = lt & 7;     // this thread's 4-channel quad of the 32-channel chunk: the same for all its X items
+        const int xci = chunk * CK + xq * 4;
+        const bool xc_ok = xci < p.Cin;
+        const int us = p.upsample ? 1 : 0;
+        const int Hs = p.H >> us, Ws = p.W >> us;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        // per-thread constants: every item's element offset from its tile's origin (the tile origin is a multiple of the tile size, so
+        // floor((origin - 1 + r) / 2) of the fused x2 upsampling splits into origin / 2 + ((r - 1) >> 1)) and its edge membership
+        // (bit i = item i is valid at all / lies in the halo's top / bottom / left / right edge; y_ok: co < Cout)
+        int xrel[XP];
+        uint32_t yrel[YP];
+        unsigned m_all = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0, y_ok = 0;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int idx = lt + i * NL;
+            const int pix = idx >> 3;
+            const int pr = pix / HTW, pc = pix - pr * HTW;  // (compile-time divisor)
+            xrel[i] = (((pr - 1) >> us) * Ws + ((pc - 1) >> us)) * p.Cin + xci;
+            const unsigned bit = 1u << i;
+            m_all |= (idx < XITEMS && xc_ok) ? bit : 0u;
+            m_top |= pr == 0 ? bit : 0u;
+            m_bot |= pr == HTH - 1 ? bit : 0u;
+            m_left |= pc == 0 ? bit : 0u;
+            m_right |= pc == HTW - 1 ? bit : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < YP; ++i) {
+            const int idx = lt + i * NL;
+            const int pix = idx / YQ, q = idx - pix * YQ;  // (compile-time divisor)
+            const int co = co0 + q * 4;
+            yrel[i] = (uint32_t)((pix >> TWS) * p.W + (pix & (TW - 1))) * p.Cout + min(co, p.Cout - 4);
+            y_ok |= co < p.Cout ? 1u << i : 0u;
+        }
+        // position of the next tile to fetch (tiles are fetched in order: stepped, not divided) and how many lie beyond it
+        int cn = t_begin / tiles_hw, ch0, cw0, left = nt - 1;
+        {
+            const int trem = t_begin - cn * tiles_hw;
+            const int th = trem / tiles_w;
+            ch0 = th * TH;
+            cw0 = (trem - th * tiles_w) << TWS;
+        }
+        // prologue as one expression, max(a x + b, floor): a = 1, b = 0 where there is no BatchNorm, floor = -inf where there is no ReLU
+        const float relu_floor = (p.pre_a || p.pre_relu) ? 0.f : -__builtin_inff();
+        // two staging sets (tile parity): the tile's X and dY items, its BatchNorm scale / shift, the validity bits of its X items
+        f32x4 sx[2][XP], sy[2][YP], sa[2], sb[2], bsum[BSN];
+        unsigned xm[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) sa[e] = (f32x4){1.f, 1.f, 1.f, 1.f}, sb[e] = zero4;
+#pragma unroll
+        for (int i = 0; i < BSN; ++i) bsum[i] = zero4;
+
+        // issue the global loads of the next tile into staging set E; every load unconditional on a clamped address - and every CALL
+        // unconditional: the compiler counts the loads in flight per control-flow path and waits for the minimum over all paths, so
+        // one `if (more tiles) issue()` makes every store wait for vmcnt(0), i.e. for the set issued last as well (the prefetch depth
+        // of 2 then behaves as 1).  Past the slab's last tile the position stays and that tile is fetched again, into a set that is
+        // never stored
+        auto issue = [&](auto set_c) {
+            constexpr int E = decltype(set_c)::value;
+            const uint32_t xb = (((uint32_t)cn * Hs + (ch0 >> us)) * Ws + (cw0 >> us)) * p.Cin;
+            const unsigned kill = (ch0 == 0 ? m_top : 0u) | (ch0 + TH >= p.H ? m_bot : 0u) | (cw0 == 0 ? m_left : 0u) | (cw0 + TW >= p.W ? m_right : 0u);
+            const unsigned m = m_all & ~kill;
+            xm[E] = m;
+#pragma unroll
+            for (int i = 0; i < XP; ++i) sx[E][i] = *reinterpret_cast<const f32x4*>(p.x + (((m >> i) & 1u) ? xb + (uint32_t)xrel[i] : 0u));
+            if (p.pre_a) {
+                const uint32_t g = xc_ok ? (uint32_t)(cn / p.pre_group) * p.Cin + xci : 0u;
+                sa[E] = *reinterpret_cast<const f32x4*>(p.pre_a + g);
+                sb[E] = *reinterpret_cast<const f32x4*>(p.pre_b + g);
+            }
+            const float* yb = p.dy + (((size_t)cn * p.H + ch0) * p.W + cw0) * p.Cout;
+#pragma unroll
+            for (int i = 0; i < YP; ++i) sy[E][i] = *reinterpret_cast<const f32x4*>(yb + yrel[i]);
+            if (left > 0) {
+                --left;
+                cw0 += TW;
+                if (cw0 >= p.W) {
+                    cw0 = 0;
+                    ch0 += TH;
+                    if (ch0 >= p.H) {
+                        ch0 = 0;
+                        ++cn;
+                    }
+                }
+            }
+        };
+        // prologue, split into planes, lane-linear 8-byte LDS stores: X[plane][halo pixel][32 ci], dY[plane][pixel][BI co]
+        // (tile parity = staging set = LDS image; !live: past the slab's end, nobody reads what is stored)
+        auto store = [&](auto set_c, bool live) {
+            constexpr int E = decltype(set_c)::value;
+            uint32_t* Xs = smem + E * BUF + lt * 2;
+            uint32_t* Ys = smem + E * BUF + NP * XPL;
+            const unsigned m = xm[E];
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                if (i == XP - 1 && XITEMS % NL != 0 && lt + i * NL >= XITEMS) continue;
+                f32x4 v = sx[E][i];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(fmaf(v[c], sa[E][c], sb[E][c]), relu_floor);
+                v = ((m >> i) & 1u) ? v : zero4;
+                u32x2 pl[NP];
+                split_planes4<NP>(v, pl);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(Xs + q * XPL + i * NL * 2) = pl[q];  // (pixel * 16 + quad * 2 dwords = item * 2)
+            }
+#pragma unroll
+            for (int i = 0; i < YP; ++i) {
+                const int idx = lt + i * NL;
+                const int pix = idx / YQ, q = idx - pix * YQ;
+                const f32x4 v = ((y_ok >> i) & 1u) ? sy[E][i] : zero4;
+                if (want_bias && live) bsum[i % BSN] += v;  // (item i + BSN of this thread has the same channel quad)
+                u32x2 pl[NP];
+                split_planes4<NP>(v, pl);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) *reinterpret_cast<u32x2*>(Ys + k * YPL + pix * YROW + q * 2) = pl[k];
+            }
+        };
+        // iteration t: the matrix waves multiply image t & 1 while the loaders store tile t + 1 (its loads were issued TWO matrix
+        // phases earlier, into staging set (t + 1) & 1) into the other image and issue the loads of tile t + 3 into the set just freed
+        using set0 = std::integral_constant<int, 0>;
+        using set1 = std::integral_constant<int, 1>;
+        if (nt > 0) {  // (the loop INSIDE the condition: a path that reaches it with no loads in flight would make its waits conservative)
+            issue(set0{});
+            issue(set1{});
+            store(set0{}, true);
+            issue(set0{});
+            __syncthreads();
+            // (tiles in pairs with ONE loop exit: a `break` between the halves becomes a second edge into the loop header in the
+            //  structurised control flow, with the staging sets in the opposite order - and the waits turn conservative again; with an
+            //  odd tile count the last half-iteration stores and fetches for nobody)
+            for (int t = 0; t < nt; t += 2) {
+                store(set1{}, t + 1 < nt);
+                issue(set1{});
+                __syncthreads();
+                store(set0{}, t + 2 < nt);
+                issue(set0{});
+                __syncthreads();
+            }
+        } else {
+            __syncthreads();
+        }
+        // ---- bias gradient (first input-channel chunk only): column sums of dY, folded in LDS (the tile images are free now) ----
+        if (want_bias) {
+            __syncthreads();  // (the matrix waves have zeroed `red`)
+#pragma unroll
+            for (int i = 0; i < BSN; ++i) {
+                const int q = (lt + i * NL) % YQ;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) atomicAdd(&red[q * 4 + c], bsum[i][c]);
+            }
+            __syncthreads();
+        }
+    } else {
+        // ============================================= matrix waves =============================================
+        f32x16 acc[CB * 3];
+#pragma unroll
+        for (int a = 0; a < CB * 3; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        // transposing-read geometry of this lane: 16-lane group g, lane i of it supplies row (i >> 2) of the 4 x 16 block, segment (i & 3)
+        const int tg = lane >> 4, ti = lane & 15;
+        const int k_lane = 8 * (tg >> 1) + (ti >> 2);      // pixel (inside a 16-pixel step) whose row this lane addresses for k 0..3
+        const int col_lane = 16 * (tg & 1) + 4 * (ti & 3);  // first of the 4 channels (inside a 32-channel block) it addresses
+        auto compute = [&](int buf) {
+            const uint32_t* Xs = smem + buf * BUF;
+            const uint32_t* Ys = Xs + NP * XPL;
+            // 16-pixel step kk = tile pixels [16 kk, 16 kk + 16): tile row (16 kk) >> TWS, first column (16 kk) & (TW - 1); filter row
+            // wid reads halo row (tile row + wid), tap d halo column (column + d)
+            auto fetch_x = [&](int kk, int pl, bf16x8_t (&dst)[3]) {
+                const int hp0 = (((kk * 16) >> TWS) + wid) * HTW + ((kk * 16) & (TW - 1));
+                const uint32_t* xb = Xs + pl * XPL + (hp0 + k_lane) * XROW + (col_lane >> 1);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) dst[d] = tr_fragment(xb + d * XROW, 4 * XROW);
+            };
+            auto fetch_y = [&](int kk, int pl, bf16x8_t (&dst)[CB]) {
+                const uint32_t* yb = Ys + pl * YPL + (kk * 16 + k_lane) * YROW + (col_lane >> 1);
+#pragma unroll
+                for (int c = 0; c < CB; ++c) dst[c] = tr_fragment(yb + c * 16, 4 * YROW);
+            };
+            auto mm = [&](const bf16x8_t (&y)[CB], const bf16x8_t (&x)[3]) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int c = 0; c < CB; ++c)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) acc[c * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[c], x[d], acc[c * 3 + d], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            if constexpr (NP == 2) {
+                // bf16x3 = three products hi.hi + hi.lo + lo.hi.  The fragments of step kk + 1 are read while the MFMAs of step kk run,
+                // with 1.5 fragment sets instead of 2 (144 accumulator registers leave no room for two): the products are ordered so
+                // that a low plane is dead after its single use and is refilled at once; only the high planes are double-buffered
+                bf16x8_t x0[2][3], y0[2][CB], x1[3], y1[CB];
+                fetch_x(0, 0, x0[0]), fetch_y(0, 0, y0[0]), fetch_x(0, 1, x1), fetch_y(0, 1, y1);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int e = kk & 1;
+                    if (kk < 3) fetch_x(kk + 1, 0, x0[e ^ 1]), fetch_y(kk + 1, 0, y0[e ^ 1]);
+                    mm(y0[e], x1);  // hi(dY) . lo(x)
+                    if (kk < 3) fetch_x(kk + 1, 1, x1);
+                    mm(y1, x0[e]);  // lo(dY) . hi(x)
+                    if (kk < 3) fetch_y(kk + 1, 1, y1);
+                    mm(y0[e], x0[e]);  // hi . hi
+                }
+            } else if constexpr (NP == 1) {
+                bf16x8_t xf[2][3], yf[2][CB];
+                fetch_x(0, 0, xf[0]), fetch_y(0, 0, yf[0]);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kk < 3) fetch_x(kk + 1, 0, xf[(kk + 1) & 1]), fetch_y(kk + 1, 0, yf[(kk + 1) & 1]);
+                    mm(yf[kk & 1], xf[kk & 1]);
+                }
+            } else {  // bf16x6: six products per step (54 MFMAs) behind one fragment set of 72 registers
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    bf16x8_t xf[NP][3], yf[NP][CB];
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) fetch_x(kk, pl, xf[pl]), fetch_y(kk, pl, yf[pl]);
+                    for_each_product<NP>([&](auto qa, auto qb) { mm(yf[qa], xf[qb]); });
+                }
+            }
+        };
+        __syncthreads();
+        for (int t = 0; t < nt; t += 2) {
+            if (!(dbg & 2)) compute(0);  // (dgmr_debug_flags 16 -> dbg 2: timing probe without the matrix work)
+            __syncthreads();
+            if (t + 1 < nt && !(dbg & 2)) compute(1);
+            __syncthreads();
+        }
+        // ---- partial[slab][co][tap*Cin + ci]: lane = input channel, 16 output channels per MFMA block ----
+        float* out = p.partial + (size_t)slab * p.Cout * (9 * p.Cin);
+        const int ci = chunk * CK + (lane & 31), Ktot = 9 * p.Cin;
+        if (ci < p.Cin) {
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (co >= p.Cout) continue;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) out[(size_t)co * Ktot + (wid * 3 + d) * p.Cin + ci] = acc[c * 3 + d][r];
+                }
+        }
+        if (want_bias) {  // (the loaders add their column sums of dY between the two barriers)
+            if (tid < BI) red[tid] = 0.f;
+            __syncthreads();
+            __syncthreads();
+            if (tid < BI && co0 + tid < p.Cout) atomicAdd(p.bias_grad + co0 + tid, red[tid]);
+        }
+    }
+}
+
+}  // namespace

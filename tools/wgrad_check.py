@@ -56,6 +56,8 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--prec="):
             prec = a.split("=")[1]
+        if a.startswith("--dbg="):  # dgmr_debug_flags timing probes (16: wgrad_ws.h without its matrix work)
+            call("dgmr_debug_flags", int(a.split("=")[1]))
         if a.startswith("--modes="):  # two dgmr_conv_tune wgrad_window values to compare
             MODES = tuple(int(v) for v in a.split("=")[1].split(","))
     ops.set_precision(prec)
