@@ -851,10 +851,14 @@ extern "C" int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a) {
     // measures better than 1.5 rounds (tail) and than many small slabs (partial-sum traffic); >= 2 tiles of 64 pixels per slab
     const int per_slab = ((a->Cin + 31) / 32) * (a->Cout % 96 == 0 ? a->Cout / 96 : (a->Cout + 63) / 64);
     const int64_t tiles_per_group = (int64_t)(a->N / groups) * ((int64_t)a->H * a->W / 64);
-    // (the wave-specialised kernel, wgrad_ws.h, has ONE workgroup per CU: one round of <= 256)
-    int64_t per = (wgrad_ws() ? 256 : 512) / ((int64_t)per_slab * groups);  // slabs per group
+    int64_t per = 512 / ((int64_t)per_slab * groups);  // slabs per group
     per = std::min<int64_t>(per, tiles_per_group / 2);
     per = std::max<int64_t>(per, 1);
+    // the wave-specialised kernel (wgrad_ws.h) has ONE workgroup per CU: one round of <= 256.  (Several rounds of smaller slabs fill
+    // the chip better when the launch runs alone - 3 chunks x 18 groups: 216 of 256 CUs with 4 slabs per group, 756 of 768 with 14,
+    // +8 % in isolation - but in the training step the weight gradients share the chip with the other streams' kernels and the
+    // larger partial sums cost what the fill gains: 999 vs 1000 - 1004 ms per step)
+    if (wgrad_ws()) per = std::max<int64_t>(1, std::min<int64_t>(256 / ((int64_t)per_slab * groups), tiles_per_group / 2));
     a->nsplit = (int)std::min<int64_t>(per * groups, 4096);
     return 0;
 }
