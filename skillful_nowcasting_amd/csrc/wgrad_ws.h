@@ -340,7 +340,7 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
                 }
             }
         };
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);  // (in the step, beside the other streams' kernels: no difference with or without, 990.5 / 987.5 vs 990.3 / 992.8 ms)
         __syncthreads();
         for (int t = 0; t < nt; t += 2) {
             if (!(dbg & 2)) compute(0);  // (dgmr_debug_flags 16 -> dbg 2: timing probe without the matrix work)

@@ -257,6 +257,7 @@ def _split_planes_cat(ws: Sequence[torch.Tensor], coff: int, cin: int) -> Option
 
 _phase_cache = {}
 _NO_PHASES = bool(int(__import__("os").environ.get("DGMR_NO_PHASES", "0")))  # measurement switch (tools/conv_bench.py)
+_UP_WGRAD_SUMS = bool(int(__import__("os").environ.get("DGMR_UP_WGRAD_SUMS", "0")))  # A/B switch: pair-sum weight gradient of upsampling convs everywhere
 
 
 def _phase_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
@@ -439,7 +440,12 @@ class ConvFn(Function):
                 wa.pre_a, wa.pre_b = (_p(bn_a), _p(bn_b)) if bn else (None, None)
                 wa.pre_relu, wa.pre_group = int(spec.pre_relu), (bn.group_size if bn else 1)
                 wa.groups = groups
-                if spec.upsample and _PRECISION_CODE != 0 and not _NO_PHASES and (kd, kh, kw) == (1, 3, 3) and d == 1:
+                # (where the wave-specialised LDS-window weight gradient applies - whole rows of 32 output pixels, or 16-pixel-wide maps -
+                #  it takes the upsampling conv as it is, nearest-2x fused into its loads, at 330 - 350 TF: 2.3 ms for up_g4.first
+                #  against ~20 ms for the sums kernel, which writes a 9-plane map of 4 GB, plus the GEMM over it)
+                window_wgrad = (wd % 32 == 0 and h % 2 == 0) or (wd == 16 and h % 4 == 0)
+                if (spec.upsample and _PRECISION_CODE != 0 and not _NO_PHASES and (kd, kh, kw) == (1, 3, 3) and d == 1
+                        and (_UP_WGRAD_SUMS or not window_wgrad)):
                     # upsampling conv, bf16 modes: sum the 2x2 pixels of dy that meet each INPUT pixel under each tap (9 planes), then the
                     # gradient is a 1x1 problem on the low-resolution map - a quarter of the multiply steps (dgmr_upsample_wgrad_sums)
                     z9 = _scratch(n * (h // 2) * (wd // 2) * 9 * cout, dev, "z9")

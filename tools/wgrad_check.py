@@ -1,6 +1,9 @@
-"""Window weight-gradient kernel vs the im2col one through the C ABI (GPU only): same partial sums, timing of both.
+"""Two weight-gradient kernels against each other through the C ABI (GPU only): same partial sums, timing of both.
 
-    python tools/wgrad_check.py [--prec=bf16x3]
+    python tools/wgrad_check.py [--prec=bf16x3] [--modes=1,2] [--dbg=16] [shape substrings]
+
+--modes: two dgmr_conv_tune wgrad_window values - 0 im2col, 1 one-role LDS-window kernel (wgrad_win.h), 2 wave-specialised one
+(wgrad_ws.h, the library's choice); default 1,2.
 """
 import ctypes
 import os
@@ -46,7 +49,7 @@ def bench(fn, iters=5):
     return e0.elapsed_time(e1) / iters
 
 
-MODES = (0, 1)
+MODES = (1, 2)
 
 
 def main():
