@@ -299,3 +299,48 @@ def test_convgru_fused_gates_match_separate_launches(prec, tol, cx, ch, hw, b, d
         close(gp1[k], gp2[k], "grad " + k, 10 * tol)
     for k in st2:
         assert torch.equal(st1[k], st2[k]), k  # spectral-norm state does not depend on how the convs are launched
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,groups", [(4, 16, 16, 64, 96, 2), (6, 8, 8, 96, 192, 3), (2, 32, 32, 40, 48, 1)])
+def test_upsampling_conv_weight_gradient_paths_agree(n, h, w, cin, cout, groups):
+    """Weight / bias / scale gradient of an upsampling 3x3 conv (nearest-2x fused into the operand load, GBlock's first conv): the
+    wave-specialised window kernel on the full-resolution map (the default where the output rows are 16 or 32 k pixels wide) against
+    the pair-sum path (dgmr_upsample_wgrad_sums + a 1x1 weight gradient on the low-resolution map, kept for the other geometries;
+    `ops._UP_WGRAD_SUMS` forces it) and against exact f32."""
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import ops
+
+    torch.manual_seed(3)
+    mf = torch.channels_last
+    x = (torch.randn(n, cin, h, w) + 0.3).to(DEV).contiguous(memory_format=mf)
+    w0 = (torch.randn(cout, cin, 3, 3) * (cin * 9) ** -0.5).to(DEV).contiguous(memory_format=mf)
+    b0 = torch.randn(cout).to(DEV)
+    inv_sigma = (torch.rand(groups) + 0.5).to(DEV)
+    u = torch.nn.functional.normalize(torch.randn(groups, cout, device=DEV), dim=1)
+    v = torch.nn.functional.normalize(torch.randn(groups, cin * 9, device=DEV), dim=1)
+    gy = torch.randn(n, cout, 2 * h, 2 * w).to(DEV).contiguous(memory_format=mf)
+
+    def grads(prec, sums):
+        S.set_precision(prec)
+        old = ops._UP_WGRAD_SUMS
+        ops._UP_WGRAD_SUMS = sums
+        try:
+            wt, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
+            xr = x.clone().requires_grad_(True)
+            sn = ops.SNCall(inv_sigma, u, v, groups)
+            y = ops.conv(xr, wt, b, inv_sigma, None, ops.ConvSpec(pre_relu=True, sn=sn, upsample=True))
+            y.backward(gy)
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            return [t.detach().clone() for t in (ops.grad_buffer(wt), ops.grad_buffer(b), xr.grad)]
+        finally:
+            ops._UP_WGRAD_SUMS = old
+            S.set_precision("f32")
+
+    ref = grads("f32", False)
+    direct = grads("bf16x3", False)
+    summed = grads("bf16x3", True)
+    for got, what in ((direct, "window"), (summed, "pair sums")):
+        for g, r, name in zip(got, ref, ("weight", "bias", "input")):
+            err = float((g.double() - r.double()).abs().max()) / float(r.double().abs().max())
+            assert err <= 1e-4, f"{what}: {name} gradient rel err {err:.2e}"
