@@ -101,7 +101,7 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
     const int t_end = min((grp + 1) * tiles_per_group, t_begin + tiles_per_split);
     const int nt = max(t_end - t_begin, 0);  // (0: a slab plan with more slabs than tiles - that slab's partial sums are zeros)
     const bool want_bias = p.bias_grad && chunk == 0;  // (uniform per workgroup)
-    float* red = reinterpret_cast<float*>(smem);       // bias sums of the workgroup, after the last tile
+    float* red = reinterpret_cast<float*>(smem);       // [slot][loader thread][4]: the loaders' bias sums, after the last tile
 
     if (wid >= 3) {
         // ================================================ loaders ================================================
@@ -246,15 +246,11 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
         } else {
             __syncthreads();
         }
-        // ---- bias gradient (first input-channel chunk only): column sums of dY, folded in LDS (the tile images are free now) ----
+        // ---- bias gradient (first input-channel chunk only): every loader thread's column sums of dY go to LDS (the tile images are
+        //      free now); the matrix waves add them up in a fixed order ----
         if (want_bias) {
-            __syncthreads();  // (the matrix waves have zeroed `red`)
 #pragma unroll
-            for (int i = 0; i < BSN; ++i) {
-                const int q = (lt + i * NL) % YQ;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) atomicAdd(&red[q * 4 + c], bsum[i][c]);
-            }
+            for (int i = 0; i < BSN; ++i) *reinterpret_cast<f32x4*>(red + (i * NL + lt) * 4) = bsum[i];
             __syncthreads();
         }
     } else {
@@ -362,11 +358,16 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
                     for (int d = 0; d < 3; ++d) out[(size_t)co * Ktot + (wid * 3 + d) * p.Cin + ci] = acc[c * 3 + d][r];
                 }
         }
-        if (want_bias) {  // (the loaders add their column sums of dY between the two barriers)
-            if (tid < BI) red[tid] = 0.f;
-            __syncthreads();
-            __syncthreads();
-            if (tid < BI && co0 + tid < p.Cout) atomicAdd(p.bias_grad + co0 + tid, red[tid]);
+        if (want_bias) {  // (deterministic within the workgroup; across workgroups one float atomic per channel, as in wgrad_win.h)
+            __syncthreads();  // the loaders have written their sums: slot i of thread lt covers channel quad (lt + i NL) mod YQ
+            if (tid < BI && co0 + tid < p.Cout) {
+                const int q = tid >> 2, comp = tid & 3;
+                float total = 0.f;
+#pragma unroll
+                for (int i = 0; i < BSN; ++i)
+                    for (int l = ((q - i * NL) % YQ + YQ) % YQ; l < NL; l += YQ) total += red[(i * NL + l) * 4 + comp];
+                atomicAdd(p.bias_grad + co0 + tid, total);
+            }
         }
     }
 }

@@ -11,7 +11,8 @@ Two training steps per rank on DIFFERENT batches, from different initialisations
   * after the steps all replicas hold bit-identical parameters and buffers (`replicas_in_sync`), and they differ from the initial
     ones (the optimiser really stepped);
   * the overlapped exchange changes nothing: a second pair of ranks that reduces after the backward (overlap off) ends with
-    parameters equal to the first pair's to 1e-6 (bias gradients use float atomics, so not bit for bit).
+    parameters that differ from the first pair's as two such late-exchange runs differ from each other (bias gradients are summed
+    with float atomics, so no two runs are bit-identical).
 What is NOT claimed: equality with a single-process run on the concatenated batch - BatchNorm (2-D in the generator, 1-D in the
 discriminator heads) normalises with per-rank batch statistics, as under stock DDP without SyncBatchNorm, so the two are different
 computations.
@@ -109,19 +110,29 @@ def _run(overlap):
     return flat, stats
 
 
-@pytest.mark.timeout(900)
+def _compare(a, b, init):
+    err = (a - b).abs().max().item()
+    cos = torch.nn.functional.cosine_similarity((a - init).double(), (b - init).double(), dim=0).item()
+    frac = ((a - b).abs() > 1e-6 * b.abs().max().item()).float().mean().item()
+    return err, cos, frac
+
+
+@pytest.mark.timeout(1200)
 def test_two_ranks_on_one_gpu_real_steps():
     (overlapped, init), stats = _run(True)
     (late, init2), _ = _run(False)
+    (late_b, init3), _ = _run(False)
     print(f"\nddp overlap stats (rank 0): {stats}")
-    assert torch.equal(init, init2)
-    err = (overlapped - late).abs().max().item()
-    # Adam with beta1 = 0 moves every element by ~lr, including those whose gradient is rounding noise (bias gradients and slab sums
-    # use float atomics: their order, hence the sign of a noise element, differs run to run - measured 2 % of the elements between
-    # any two runs).  So: no element further apart than two steps of 2 lr, and the UPDATES agree in direction.
+    assert torch.equal(init, init2) and torch.equal(init, init3)
+    # Adam with beta1 = 0 moves every element by ~lr, including those whose gradient is rounding noise, and the bias gradients are
+    # summed across workgroups with float atomics: their order, hence the sign of a noise element, differs from run to run, and what
+    # differs after the first step feeds the second.  The yardstick is therefore a SECOND late-exchange run: the overlapped exchange
+    # may differ from a late one as two late ones differ from each other (x 3, the runs being single samples), no element further
+    # apart than two steps of 2 lr, and the updates agree in direction.
+    err0, cos0, frac0 = _compare(late_b, late, init)
+    err, cos, frac = _compare(overlapped, late, init)
+    print(f"late vs late exchange:       update cosine {cos0:.5f}, {frac0:.2%} of the elements differ, max {err0:.2e}")
+    print(f"overlapped vs late exchange: update cosine {cos:.5f}, {frac:.2%} of the elements differ, max {err:.2e}")
     assert err <= 2.1 * 2 * 2e-4, f"overlapped vs late exchange: parameters differ by {err:.3e}"
-    ua, ub = (overlapped - init).double(), (late - init).double()
-    cos = torch.nn.functional.cosine_similarity(ua, ub, dim=0).item()
-    frac = ((overlapped - late).abs() > 1e-6 * late.abs().max().item()).float().mean().item()
-    print(f"overlapped vs late exchange: update cosine {cos:.5f}, {frac:.2%} of the elements differ")
-    assert cos >= 0.98 and frac < 0.06, (cos, frac)
+    assert cos >= 0.98 and 1.0 - cos <= 3.0 * (1.0 - cos0) + 1e-4, (cos, cos0)
+    assert frac <= 3.0 * max(frac0, 0.02), (frac, frac0)
