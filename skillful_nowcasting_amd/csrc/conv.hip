@@ -828,13 +828,15 @@ extern "C" int dgmr_conv_wgrad_nsplit(int M, int Cout, int K, int groups) {
 }
 
 // the LDS-window weight gradient (wgrad_win.h) applies to 3x3 convs on 2-D maps made of whole rows of 32 (or 16) pixels, bf16 modes
-static bool wgrad_uses_window(const dgmr_wgrad_args* a) {
-    return g_precision != 0 && g_tune_wgrad_window != 0 && a->KD == 1 && a->KH == 3 && a->KW == 3 && a->D == 1 &&
-           ((a->W % 32 == 0 && a->H % 2 == 0) || (a->W == 16 && a->H % 4 == 0));
-}
 // which of the two window kernels: the wave-specialised one (wgrad_ws.h; dgmr_conv_tune wgrad_window 2 = automatic) or the one-role
 // kernel of round 2 (wgrad_win.h; 1)
 static bool wgrad_ws() { return g_tune_wgrad_window != 1; }
+// (3 x 3 x 3 convs, without upsampling: the wave-specialised kernel only, one launch per depth tap)
+static bool wgrad_uses_window(const dgmr_wgrad_args* a) {
+    const bool k2d = a->KD == 1 && a->D == 1, k3d = a->KD == 3 && a->D >= 1 && !a->upsample && wgrad_ws();
+    return g_precision != 0 && g_tune_wgrad_window != 0 && (k2d || k3d) && a->KH == 3 && a->KW == 3 &&
+           ((a->W % 32 == 0 && a->H % 2 == 0) || (a->W == 16 && a->H % 4 == 0));
+}
 // tiles of 64 pixels: 2 x 32, or 4 x 16 on 16-pixel-wide maps
 static int wgrad_window_tw_shift(const dgmr_wgrad_args* a) { return a->W % 32 == 0 ? 5 : 4; }
 
@@ -850,7 +852,7 @@ extern "C" int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a) {
     // workgroups = 32-channel input chunks x output tiles x slabs.  Two are resident per CU: one full round (<= 512 workgroups)
     // measures better than 1.5 rounds (tail) and than many small slabs (partial-sum traffic); >= 2 tiles of 64 pixels per slab
     const int per_slab = ((a->Cin + 31) / 32) * (a->Cout % 96 == 0 ? a->Cout / 96 : (a->Cout + 63) / 64);
-    const int64_t tiles_per_group = (int64_t)(a->N / groups) * ((int64_t)a->H * a->W / 64);
+    const int64_t tiles_per_group = (int64_t)(a->N / groups) * a->D * ((int64_t)a->H * a->W / 64);
     int64_t per = 512 / ((int64_t)per_slab * groups);  // slabs per group
     per = std::min<int64_t>(per, tiles_per_group / 2);
     per = std::max<int64_t>(per, 1);
@@ -889,13 +891,17 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
     if (wgrad_uses_window(a)) {
         const int tw_shift = wgrad_window_tw_shift(a);
         const int tiles_w = a->W >> tw_shift, tiles_hw = (a->H / (64 >> tw_shift)) * tiles_w;
-        const int tiles_per_group = (a->N / groups) * tiles_hw;
+        const int tiles_per_group = (a->N / groups) * a->D * tiles_hw;
         const int tiles_per_split = (tiles_per_group + spg - 1) / spg;
         const bool b96 = a->Cout % 96 == 0;
         const dim3 grid((a->Cin + 31) / 32, b96 ? a->Cout / 96 : (a->Cout + 63) / 64, a->nsplit);
-        DGMR_BY_NS(launch_wgrad_window, p, grid, tw_shift, tiles_w, tiles_hw, tiles_per_split, spg, tiles_per_group,
-                   wgrad_ws() ? (1 | ((g_debug_flags & 16) >> 3)) : 0, s);
-        DGMR_CHECK_LAUNCH();
+        for (int kd = 0; kd < a->KD; ++kd) {  // (3-D: one launch per depth tap; the bias gradient rides in the centre one, which skips no plane)
+            dgmr_wgrad_args q = p;
+            if (a->KD == 3 && kd != 1) q.bias_grad = nullptr;
+            DGMR_BY_NS(launch_wgrad_window, q, grid, tw_shift, tiles_w, tiles_hw, tiles_per_split, spg, tiles_per_group,
+                       wgrad_ws() ? (1 | ((g_debug_flags & 16) >> 3) | (kd << 8)) : 0, s);
+            DGMR_CHECK_LAUNCH();
+        }
         return 0;
     }
     if (g_precision != 0) {

@@ -17,7 +17,7 @@ int DGMR_TU_CAT(launch_wgrad_window_ns, DGMR_NS)(const dgmr_wgrad_args& p, dim3 
     if (ws) {  // wave-specialised kernel (wgrad_ws.h): 3 matrix + 4 loader waves
 #define DGMR_WGS(BI_, TWS_)                                                                                                      \
     hipLaunchKernelGGL((conv_wgrad_ws_kernel<BI_, NS, TWS_>), dim3(grid.x * grid.y * grid.z), dim3(448), 0, s, p, tiles_w, tiles_hw, tiles_per_split, \
-                       splits_per_group, tiles_per_group, ws)
+                       splits_per_group, tiles_per_group, ws & 0xff, ws >> 8)
         if (b96) {
             if (tw_shift == 5) DGMR_WGS(96, 5);
             else DGMR_WGS(96, 4);

@@ -23,6 +23,7 @@
 //     the loaders' 104 staging registers and the 144 accumulators live together (1 KB of scratch per lane) and merges the two paths'
 //     s_waitcnt bookkeeping at every barrier, so that each store waits for nearly all loads in flight.
 // Output: partial[slab][co][tap*Cin + ci], the layout dgmr_wgrad_reduce* consume; bias gradient as in wgrad_win.h.
+// 3 x 3 x 3 convs: one launch per depth tap (kernel argument kd) over the N x D planes, each writing its 9 taps of the 27.
 #pragma once
 #include "conv_bf16.h"
 
@@ -64,7 +65,7 @@ __device__ __forceinline__ void ws_interleave() {
 template <int BI, int NS, int TWS>
 __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_args p, const int tiles_w, const int tiles_hw,
                                                            const int tiles_per_split, const int splits_per_group,
-                                                           const int tiles_per_group, const int dbg) {
+                                                           const int tiles_per_group, const int dbg, const int kd) {
     constexpr int NP = planes_of<NS>::value;
     constexpr int CK = 32, CB = BI / 32;
     constexpr int TW = 1 << TWS, TH = 64 >> TWS;      // 32 x 2 or 16 x 4 pixels
@@ -140,13 +141,17 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
             y_ok |= co < p.Cout ? 1u << i : 0u;
         }
         // position of the next tile to fetch (tiles are fetched in order: stepped, not divided) and how many lie beyond it
-        int cn = t_begin / tiles_hw, ch0, cw0, left = nt - 1;
+        int cn = t_begin / tiles_hw, ch0, cw0, left = nt - 1;  // (cn: image = sample x depth plane of a 3-D conv)
         {
             const int trem = t_begin - cn * tiles_hw;
             const int th = trem / tiles_w;
             ch0 = th * TH;
             cw0 = (trem - th * tiles_w) << TWS;
         }
+        // 3 x 3 x 3 convs (the temporal discriminator's first blocks): one launch per depth tap kd.  dY plane d meets x plane d + kd - 1
+        // of the same sample - a constant shift of the image index - and contributes nothing where that plane lies outside the volume
+        const int Dp = p.D, dshift = p.KD == 3 ? kd - 1 : 0;
+        int cd = cn % Dp;  // depth plane of image cn
         // prologue as one expression, max(a x + b, floor): a = 1, b = 0 where there is no BatchNorm, floor = -inf where there is no ReLU
         const float relu_floor = (p.pre_a || p.pre_relu) ? 0.f : -__builtin_inff();
         // two staging sets (tile parity): the tile's X and dY items, its BatchNorm scale / shift, the validity bits of its X items
@@ -164,14 +169,15 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
         // never stored
         auto issue = [&](auto set_c) {
             constexpr int E = decltype(set_c)::value;
-            const uint32_t xb = (((uint32_t)cn * Hs + (ch0 >> us)) * Ws + (cw0 >> us)) * p.Cin;
+            const uint32_t xb = (((uint32_t)(cn + dshift) * Hs + (ch0 >> us)) * Ws + (cw0 >> us)) * p.Cin;  // (wraps for image -1: masked)
+            const bool plane_ok = (unsigned)(cd + dshift) < (unsigned)Dp;
             const unsigned kill = (ch0 == 0 ? m_top : 0u) | (ch0 + TH >= p.H ? m_bot : 0u) | (cw0 == 0 ? m_left : 0u) | (cw0 + TW >= p.W ? m_right : 0u);
-            const unsigned m = m_all & ~kill;
+            const unsigned m = plane_ok ? m_all & ~kill : 0u;
             xm[E] = m;
 #pragma unroll
             for (int i = 0; i < XP; ++i) sx[E][i] = *reinterpret_cast<const f32x4*>(p.x + (((m >> i) & 1u) ? xb + (uint32_t)xrel[i] : 0u));
             if (p.pre_a) {
-                const uint32_t g = xc_ok ? (uint32_t)(cn / p.pre_group) * p.Cin + xci : 0u;
+                const uint32_t g = xc_ok ? (uint32_t)(cn / Dp / p.pre_group) * p.Cin + xci : 0u;
                 sa[E] = *reinterpret_cast<const f32x4*>(p.pre_a + g);
                 sb[E] = *reinterpret_cast<const f32x4*>(p.pre_b + g);
             }
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
                     if (ch0 >= p.H) {
                         ch0 = 0;
                         ++cn;
+                        cd = cd + 1 == Dp ? 0 : cd + 1;
                     }
                 }
             }
@@ -345,8 +352,9 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
             __syncthreads();
         }
         // ---- partial[slab][co][tap*Cin + ci]: lane = input channel, 16 output channels per MFMA block ----
-        float* out = p.partial + (size_t)slab * p.Cout * (9 * p.Cin);
-        const int ci = chunk * CK + (lane & 31), Ktot = 9 * p.Cin;
+        const int Ktot = 9 * p.KD * p.Cin, tap0 = (p.KD == 3 ? kd : 0) * 9;  // K order (kd, kh, kw, ci)
+        float* out = p.partial + (size_t)slab * p.Cout * Ktot;
+        const int ci = chunk * CK + (lane & 31);
         if (ci < p.Cin) {
 #pragma unroll
             for (int c = 0; c < CB; ++c)
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
                     const int co = co0 + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (co >= p.Cout) continue;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) out[(size_t)co * Ktot + (wid * 3 + d) * p.Cin + ci] = acc[c * 3 + d][r];
+                    for (int d = 0; d < 3; ++d) out[(size_t)co * Ktot + (tap0 + wid * 3 + d) * p.Cin + ci] = acc[c * 3 + d][r];
                 }
         }
         if (want_bias) {  // (deterministic within the workgroup; across workgroups one float atomic per channel, as in wgrad_win.h)

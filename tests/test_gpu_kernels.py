@@ -194,11 +194,19 @@ WGRAD_CASES = [
     (1, 64, 32, 24, 200, True, False, 1),    # ragged input chunk (24 of 32 channels), 200 = 3 x 64 + 8 output channels
     (3, 16, 32, 96, 288, False, True, 3),    # 288 = 3 x 96 output-channel tiles
 ]
+# 3 x 3 x 3 convs (n, depth, h, w, cin, cout, call groups): the temporal discriminator's first blocks - one window launch per depth tap
+WGRAD_CASES_3D = [(2, 6, 32, 32, 48, 96, 2), (1, 5, 16, 32, 8, 48, 1), (3, 2, 32, 64, 96, 96, 3)]
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16x6", 2e-6), ("bf16", 6e-3)])
+@pytest.mark.parametrize("n,d,h,w,cin,cout,groups", WGRAD_CASES_3D)
+def test_window_wgrad_3d_matches_im2col_wgrad(tuned, n, d, h, w, cin, cout, groups, prec, tol):
+    test_window_wgrad_matches_im2col_wgrad(tuned, n, h, w, cin, cout, False, False, groups, prec, tol, depth=d)
 
 
 @pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16x6", 2e-6), ("bf16", 6e-3)])
 @pytest.mark.parametrize("n,h,w,cin,cout,up,bn,groups", WGRAD_CASES)
-def test_window_wgrad_matches_im2col_wgrad(tuned, n, h, w, cin, cout, up, bn, groups, prec, tol):
+def test_window_wgrad_matches_im2col_wgrad(tuned, n, h, w, cin, cout, up, bn, groups, prec, tol, depth=1):
     import skillful_nowcasting_amd as S
     from skillful_nowcasting_amd import ops
     from skillful_nowcasting_amd._lib import WgradArgs, call
@@ -206,20 +214,21 @@ def test_window_wgrad_matches_im2col_wgrad(tuned, n, h, w, cin, cout, up, bn, gr
     S.set_precision(prec)
     torch.manual_seed(2)
     hin, win = (h // 2, w // 2) if up else (h, w)
-    x = torch.randn(n * hin * win * cin, device=DEV)
-    dy = torch.randn(n * h * w * cout, device=DEV)
+    kd = 3 if depth > 1 else 1
+    x = torch.randn(n * depth * hin * win * cin, device=DEV)
+    dy = torch.randn(n * depth * h * w * cout, device=DEV)
     a = torch.rand(groups * cin, device=DEV) + 0.5
     b = torch.randn(groups * cin, device=DEV) * 0.3
-    k = 9 * cin
+    k = 9 * kd * cin
     res = {}
-    for mode in (0, 1, 2):  # im2col, one-role window kernel, wave-specialised window kernel
+    for mode in (0, 1, 2):  # im2col, one-role window kernel (2-D only: im2col again for 3-D), wave-specialised window kernel
         tuned(-1, -1, -1, mode)
         bias = torch.zeros(cout, device=DEV)
         wa = WgradArgs()
         wa.x, wa.dy = x.data_ptr(), dy.data_ptr()
         wa.pre_a, wa.pre_b = (a.data_ptr(), b.data_ptr()) if bn else (None, None)
-        wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, 1, h, w, cin, cout
-        wa.KD, wa.KH, wa.KW = 1, 3, 3
+        wa.N, wa.D, wa.H, wa.W, wa.Cin, wa.Cout = n, depth, h, w, cin, cout
+        wa.KD, wa.KH, wa.KW = kd, 3, 3
         wa.upsample, wa.pre_relu, wa.pre_group, wa.groups = int(up), int(not bn), n // groups, groups
         wa.bias_grad = bias.data_ptr()
         call("dgmr_conv_wgrad_plan", ctypes.byref(wa))
