@@ -447,7 +447,8 @@ int dgmr_profile_collect2(double* total_ms, double* total_flops, double* execute
  * of K slabs (needs a workspace in the args), window = 0 never / 1 the register-staged LDS-window 3x3 kernel whenever the geometry allows / 2 likewise, with the experimental
  * 256-pixel tiles / 3 the LDS-DMA window kernel where eligible (what -1 picks, but also below the automatic size threshold);
  * wgrad_window = 0 never an LDS-window weight-gradient kernel / 1 the one-role kernel of round 2 (wgrad_win.h) wherever the geometry
- * allows / 2 (= automatic) the wave-specialised one (wgrad_ws.h: loader waves + matrix waves, ds_read_b64_tr_b16 fragments). */
+ * allows / 2 the wave-specialised one (wgrad_ws.h: loader waves + matrix waves, ds_read_b64_tr_b16 fragments) with three matrix
+ * waves (32x32x16 MFMAs, one filter row each) / 3 (= automatic) with four (16x16x32 MFMAs, one per SIMD; bf16x6: three). */
 int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window);
 /* Kernel-phase timing switches for tools/conv_bench.py (process-wide, 0 at load and in every product launch): bit 0 = the LDS-window
  * conv kernels return before their epilogue, bit 1 = they stage only their first input halo.  Outputs are then garbage by design;

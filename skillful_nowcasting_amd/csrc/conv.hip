@@ -828,8 +828,8 @@ extern "C" int dgmr_conv_wgrad_nsplit(int M, int Cout, int K, int groups) {
 }
 
 // the LDS-window weight gradient (wgrad_win.h) applies to 3x3 convs on 2-D maps made of whole rows of 32 (or 16) pixels, bf16 modes
-// which of the two window kernels: the wave-specialised one (wgrad_ws.h; dgmr_conv_tune wgrad_window 2 = automatic) or the one-role
-// kernel of round 2 (wgrad_win.h; 1)
+// which of the two window kernels: the wave-specialised one (wgrad_ws.h; dgmr_conv_tune wgrad_window 2: three matrix waves, 3 = automatic:
+// four matrix waves in bf16 / bf16x3, three in bf16x6) or the one-role kernel of round 2 (wgrad_win.h; 1)
 static bool wgrad_ws() { return g_tune_wgrad_window != 1; }
 // (3 x 3 x 3 convs, without upsampling: the wave-specialised kernel only, one launch per depth tap)
 static bool wgrad_uses_window(const dgmr_wgrad_args* a) {
@@ -899,7 +899,7 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
             dgmr_wgrad_args q = p;
             if (a->KD == 3 && kd != 1) q.bias_grad = nullptr;
             DGMR_BY_NS(launch_wgrad_window, q, grid, tw_shift, tiles_w, tiles_hw, tiles_per_split, spg, tiles_per_group,
-                       wgrad_ws() ? (1 | ((g_debug_flags & 16) >> 3) | (kd << 8)) : 0, s);
+                       wgrad_ws() ? (1 | ((g_debug_flags & 16) >> 3) | (g_tune_wgrad_window != 2 && g_precision != 3 ? 4 : 0) | (kd << 8)) : 0, s);
             DGMR_CHECK_LAUNCH();
         }
         return 0;
@@ -1060,7 +1060,7 @@ extern "C" int dgmr_get_precision(void) { return g_precision; }
 
 extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window) {
     DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 5 && wgrad_window >= -1 &&
-                       wgrad_window <= 2,
+                       wgrad_window <= 3,
                    "dgmr_conv_tune: variant %d ksplit %d window %d wgrad_window %d", variant, ksplit, window, wgrad_window);
     g_tune_variant = variant;
     g_tune_ksplit = ksplit;

@@ -15,9 +15,19 @@ int DGMR_TU_CAT(launch_wgrad_window_ns, DGMR_NS)(const dgmr_wgrad_args& p, dim3 
     constexpr int NS = DGMR_NS;
     const bool b96 = p.Cout % 96 == 0;
     if (ws) {  // wave-specialised kernel (wgrad_ws.h): 3 matrix + 4 loader waves
+        // ws bit 2: four matrix waves (16 x 16 x 32 MFMAs; bf16 / bf16x3 only)
 #define DGMR_WGS(BI_, TWS_)                                                                                                      \
-    hipLaunchKernelGGL((conv_wgrad_ws_kernel<BI_, NS, TWS_>), dim3(grid.x * grid.y * grid.z), dim3(448), 0, s, p, tiles_w, tiles_hw, tiles_per_split, \
-                       splits_per_group, tiles_per_group, ws & 0xff, ws >> 8)
+    do {                                                                                                                         \
+        if constexpr (NS != 6) {                                                                                                 \
+            if (ws & 4) {                                                                                                        \
+                hipLaunchKernelGGL((conv_wgrad_ws_kernel<BI_, NS, TWS_, 4>), dim3(grid.x * grid.y * grid.z), dim3(512), 0, s, p, tiles_w, \
+                                   tiles_hw, tiles_per_split, splits_per_group, tiles_per_group, ws & 0xff, ws >> 8);            \
+                break;                                                                                                           \
+            }                                                                                                                    \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((conv_wgrad_ws_kernel<BI_, NS, TWS_, 3>), dim3(grid.x * grid.y * grid.z), dim3(448), 0, s, p, tiles_w,    \
+                           tiles_hw, tiles_per_split, splits_per_group, tiles_per_group, ws & 0xff, ws >> 8);                    \
+    } while (0)
         if (b96) {
             if (tw_shift == 5) DGMR_WGS(96, 5);
             else DGMR_WGS(96, 4);

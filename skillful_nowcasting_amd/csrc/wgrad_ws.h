@@ -62,8 +62,12 @@ __device__ __forceinline__ void ws_interleave() {
     }
 }
 
-template <int BI, int NS, int TWS>
-__global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_args p, const int tiles_w, const int tiles_hw,
+// MW = 3: three matrix waves, one filter row each, 32 x 32 x 16 MFMAs (9 accumulators [32 co x 32 ci]).
+// MW = 4: FOUR matrix waves, one per SIMD, 16 x 16 x 32 MFMAs: wave (ci half, co half) owns 16 input channels x BI / 2 output channels
+//         x all 9 taps = 9 x BI / 32 accumulators [16 co x 16 ci]; the LDS images are [16-channel block][pixel][16] (32-byte rows), so
+//         that the 8 pixel rows a 32-lane group of a transposing read touches are 256 contiguous bytes at any tap shift.
+template <int BI, int NS, int TWS, int MW = 3>
+__global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr_wgrad_args p, const int tiles_w, const int tiles_hw,
                                                            const int tiles_per_split, const int splits_per_group,
                                                            const int tiles_per_group, const int dbg, const int kd) {
     constexpr int NP = planes_of<NS>::value;
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
     constexpr int XROW = CK / 2;                       // dwords per halo pixel: 32 bf16
     constexpr int YROW = 48;                           // dwords per dY pixel: BI bf16 (64: padded to 192 B): the 4 rows of a transposing
                                                        // read's 32-lane group then start at banks 0 / 48 / 32 / 16 (x 16 banks each)
-    constexpr int XPL = HPIX * XROW, YPL = 64 * YROW;  // dwords per plane
+    constexpr int XPL = HPIX * XROW, YPL = MW == 4 ? 64 * (BI / 2) : 64 * YROW;  // dwords per plane
     constexpr int BUF = NP * (XPL + YPL);              // dwords per tile image
     constexpr int NL = 256;                            // loader threads (4 waves)
     constexpr int XITEMS = HPIX * 8, YQ = BI / 4, YITEMS = 64 * YQ;  // 16-byte fp32 items of a tile: [pixel][4-channel quad]
@@ -104,9 +108,9 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
     const bool want_bias = p.bias_grad && chunk == 0;  // (uniform per workgroup)
     float* red = reinterpret_cast<float*>(smem);       // [slot][loader thread][4]: the loaders' bias sums, after the last tile
 
-    if (wid >= 3) {
+    if (wid >= MW) {
         // ================================================ loaders ================================================
-        const int lt = tid - 192;  // 0 .. 255
+        const int lt = tid - MW * 64;  // 0 .. 255
         const int xq = lt & 7;     // this thread's 4-channel quad of the 32-channel chunk: the same for all its X items
         const int xci = chunk * CK + xq * 4;
         const bool xc_ok = xci < p.Cin;
@@ -202,7 +206,8 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
         // (tile parity = staging set = LDS image; !live: past the slab's end, nobody reads what is stored)
         auto store = [&](auto set_c, bool live) {
             constexpr int E = decltype(set_c)::value;
-            uint32_t* Xs = smem + E * BUF + lt * 2;
+            // MW = 3: X[pixel][32 ci] = item * 2 dwords;  MW = 4: X[ci half][pixel][16 ci], dY[co block of 16][pixel][16 co]
+            uint32_t* Xs = smem + E * BUF + (MW == 4 ? (xq >> 2) * (HPIX * 8) + (lt >> 3) * 8 + (xq & 3) * 2 : lt * 2);
             uint32_t* Ys = smem + E * BUF + NP * XPL;
             const unsigned m = xm[E];
 #pragma unroll
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
                 u32x2 pl[NP];
                 split_planes4<NP>(v, pl);
 #pragma unroll
-                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(Xs + q * XPL + i * NL * 2) = pl[q];  // (pixel * 16 + quad * 2 dwords = item * 2)
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(Xs + q * XPL + i * (MW == 4 ? NL : NL * 2)) = pl[q];  // (NL items = 32 pixels further)
             }
 #pragma unroll
             for (int i = 0; i < YP; ++i) {
@@ -226,7 +231,8 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
                 u32x2 pl[NP];
                 split_planes4<NP>(v, pl);
 #pragma unroll
-                for (int k = 0; k < NP; ++k) *reinterpret_cast<u32x2*>(Ys + k * YPL + pix * YROW + q * 2) = pl[k];
+                for (int k = 0; k < NP; ++k)
+                    *reinterpret_cast<u32x2*>(Ys + k * YPL + (MW == 4 ? (q >> 2) * (64 * 8) + pix * 8 + (q & 3) * 2 : pix * YROW + q * 2)) = pl[k];
             }
         };
         // iteration t: the matrix waves multiply image t & 1 while the loaders store tile t + 1 (its loads were issued TWO matrix
@@ -262,109 +268,197 @@ __global__ __launch_bounds__(448) void conv_wgrad_ws_kernel(const dgmr_wgrad_arg
         }
     } else {
         // ============================================= matrix waves =============================================
-        f32x16 acc[CB * 3];
+        if constexpr (MW == 4) {
+            constexpr int CBH = BI / 32;  // 16-channel output blocks of this wave's half
+            const int cih = wid & 1, coh = wid >> 1;
+            f32x4 acc[9][CBH];
 #pragma unroll
-        for (int a = 0; a < CB * 3; ++a)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-        // transposing-read geometry of this lane: 16-lane group g, lane i of it supplies row (i >> 2) of the 4 x 16 block, segment (i & 3)
-        const int tg = lane >> 4, ti = lane & 15;
-        const int k_lane = 8 * (tg >> 1) + (ti >> 2);      // pixel (inside a 16-pixel step) whose row this lane addresses for k 0..3
-        const int col_lane = 16 * (tg & 1) + 4 * (ti & 3);  // first of the 4 channels (inside a 32-channel block) it addresses
-        auto compute = [&](int buf) {
-            const uint32_t* Xs = smem + buf * BUF;
-            const uint32_t* Ys = Xs + NP * XPL;
-            // 16-pixel step kk = tile pixels [16 kk, 16 kk + 16): tile row (16 kk) >> TWS, first column (16 kk) & (TW - 1); filter row
-            // wid reads halo row (tile row + wid), tap d halo column (column + d)
-            auto fetch_x = [&](int kk, int pl, bf16x8_t (&dst)[3]) {
-                const int hp0 = (((kk * 16) >> TWS) + wid) * HTW + ((kk * 16) & (TW - 1));
-                const uint32_t* xb = Xs + pl * XPL + (hp0 + k_lane) * XROW + (col_lane >> 1);
+                for (int c = 0; c < CBH; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // a 32-pixel step of the reduction: operand lane l holds k = 8 (l >> 4) ... + 7 for row / column l & 15; the two transposing
+            // reads of a fragment deliver k 0..3 and 4..7 of each 16-lane group g.  Which PIXEL a k stands for is free as long as both
+            // operands agree: pixel = 16 (g >> 1) + 8 rd + 4 (g & 1) + j, so that the lanes 0 - 31 of one read touch 8 consecutive pixels
+            const int tg = lane >> 4, ti = lane & 15;
+            const int py_lane = 16 * (tg >> 1) + 4 * (tg & 1) + (ti >> 2);
+            const int px_lane = (TWS == 5 ? 16 * (tg >> 1) : (tg >> 1) * HTW) + 4 * (tg & 1) + (ti >> 2);  // (16-wide tiles: 2 rows per step)
+            const int seg = (ti & 3) * 2;
+            auto compute = [&](int buf) {
+                const uint32_t* Xs = smem + buf * BUF + cih * (HPIX * 8) + px_lane * 8 + seg;
+                const uint32_t* Ys = smem + buf * BUF + NP * XPL + coh * CBH * (64 * 8) + py_lane * 8 + seg;
+                auto fetch_x = [&](int ks, int pl, bf16x8_t (&dst)[9]) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) dst[d] = tr_fragment(xb + d * XROW, 4 * XROW);
-            };
-            auto fetch_y = [&](int kk, int pl, bf16x8_t (&dst)[CB]) {
-                const uint32_t* yb = Ys + pl * YPL + (kk * 16 + k_lane) * YROW + (col_lane >> 1);
+                    for (int t = 0; t < 9; ++t) {
+                        const int hp = ((TWS == 5 ? ks : 2 * ks) + t / 3) * HTW + t % 3;
+                        dst[t] = tr_fragment(Xs + pl * XPL + hp * 8, 8 * 8);
+                    }
+                };
+                auto fetch_y = [&](int ks, int pl, bf16x8_t (&dst)[CBH]) {
 #pragma unroll
-                for (int c = 0; c < CB; ++c) dst[c] = tr_fragment(yb + c * 16, 4 * YROW);
-            };
-            auto mm = [&](const bf16x8_t (&y)[CB], const bf16x8_t (&x)[3]) {
+                    for (int c = 0; c < CBH; ++c) dst[c] = tr_fragment(Ys + pl * YPL + c * (64 * 8) + ks * 32 * 8, 8 * 8);
+                };
+                auto mm = [&](const bf16x8_t (&y)[CBH], const bf16x8_t (&x)[9]) {
 #pragma unroll
-                for (int c = 0; c < CB; ++c)
+                    for (int t = 0; t < 9; ++t)
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) acc[c * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[c], x[d], acc[c * 3 + d], 0, 0, 0);
-            };
-            // instruction order asked of the scheduler for one product with `reads` transposing LDS reads to hide: the reads spread
-            // over the product's MFMAs instead of clustered before them.  A wave issues in order and an MFMA occupies the matrix pipe
-            // for 32 cycles, so a read placed between two MFMAs issues in the first one's shadow; a cluster of reads ahead of the
-            // MFMAs is paid in full - and ONE wave per SIMD gets 8-byte LDS reads out at a fraction of the LDS rate (~10 cycles
-            // each, MI355X_MICROARCH.md, LDS), which is what the matrix waves have
-            auto interleave = [&](auto reads_c) { ws_interleave<decltype(reads_c)::value, CB * 3, 0>(); };
-            if constexpr (NP == 2) {
-                // bf16x3 = three products hi.lo + lo.hi + hi.hi per step.  Every fragment group is read ONE product before the product
-                // that needs it, into registers whose last reader has just finished - 5 fragment groups (60 registers) live at the
-                // peak instead of the 8 of two whole sets, beside the 144 accumulator registers:
-                //   product      operands            reads in its shadow
-                //   hi.lo        y0[e], x1           y1, x0       (this step's other two products)
-                //   lo.hi        y1,    x0           x1', y0[e^1] (the next step's first product; x1 is free since hi.lo)
-                //   hi.hi        y0[e], x0           -
-                constexpr int RX = 3 * 2, RY = CB * 2;  // LDS reads per X / dY fragment group
-                using R = std::integral_constant<int, RX + RY>;
-                bf16x8_t y0[2][CB], x0[3], x1[3], y1[CB];
-                fetch_y(0, 0, y0[0]), fetch_x(0, 1, x1);
-                __builtin_amdgcn_sched_group_barrier(0x100, RX + RY, 0);
+                        for (int c = 0; c < CBH; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[c], x[t], acc[t][c], 0, 0, 0);
+                };
+                constexpr int M = 9 * CBH, RX = 18, RY = CBH * 2;
+                if constexpr (NP == 2) {  // (product order and fragment rotation as in the three-wave variant below)
+                    bf16x8_t y0[2][CBH], x0[9], x1[9], y1[CBH];
+                    fetch_y(0, 0, y0[0]), fetch_x(0, 1, x1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, RY + 6, 0);  // dY and the first filter row of x: the first MFMAs can start
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int e = kk & 1;
-                    fetch_y(kk, 1, y1), fetch_x(kk, 0, x0);
-                    mm(y0[e], x1);  // hi(dY) . lo(x)
-                    interleave(R{});
-                    if (kk < 3) fetch_x(kk + 1, 1, x1), fetch_y(kk + 1, 0, y0[e ^ 1]);
-                    mm(y1, x0);  // lo(dY) . hi(x)
-                    if (kk < 3) interleave(R{});
-                    else __builtin_amdgcn_sched_group_barrier(0x008, CB * 3, 0);
-                    mm(y0[e], x0);  // hi . hi
-                    __builtin_amdgcn_sched_group_barrier(0x008, CB * 3, 0);
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int e = ks & 1;
+                        fetch_y(ks, 1, y1), fetch_x(ks, 0, x0);
+                        mm(y0[e], x1);  // hi(dY) . lo(x)
+                        if (ks == 0) ws_interleave<RX - 6 + RX + RY, M, 0>();
+                        else ws_interleave<RX + RY, M, 0>();
+                        if (ks < 1) fetch_x(ks + 1, 1, x1), fetch_y(ks + 1, 0, y0[e ^ 1]);
+                        mm(y1, x0);  // lo(dY) . hi(x)
+                        if (ks < 1) ws_interleave<RX + RY, M, 0>();
+                        else __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
+                        mm(y0[e], x0);  // hi . hi
+                        __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
+                    }
+                } else {
+                    static_assert(NP == 1, "four matrix waves: bf16 and bf16x3 only (bf16x6 needs 144 fragment registers)");
+                    bf16x8_t xf[2][9], yf[2][CBH];
+                    fetch_y(0, 0, yf[0]), fetch_x(0, 0, xf[0]);
+                    fetch_y(1, 0, yf[1]), fetch_x(1, 0, xf[1]);
+                    mm(yf[0], xf[0]);
+                    mm(yf[1], xf[1]);
                 }
-            } else if constexpr (NP == 1) {
-                bf16x8_t xf[2][3], yf[2][CB];
-                fetch_x(0, 0, xf[0]), fetch_y(0, 0, yf[0]);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    if (kk < 3) fetch_x(kk + 1, 0, xf[(kk + 1) & 1]), fetch_y(kk + 1, 0, yf[(kk + 1) & 1]);
-                    mm(yf[kk & 1], xf[kk & 1]);
-                }
-            } else {  // bf16x6: six products per step (54 MFMAs) behind one fragment set of 72 registers
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    bf16x8_t xf[NP][3], yf[NP][CB];
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) fetch_x(kk, pl, xf[pl]), fetch_y(kk, pl, yf[pl]);
-                    for_each_product<NP>([&](auto qa, auto qb) { mm(yf[qa], xf[qb]); });
-                }
+            };
+            __builtin_amdgcn_s_setprio(1);
+            __syncthreads();
+            for (int t = 0; t < nt; t += 2) {
+                if (!(dbg & 2)) compute(0);
+                __syncthreads();
+                if (t + 1 < nt && !(dbg & 2)) compute(1);
+                __syncthreads();
             }
-        };
-        __builtin_amdgcn_s_setprio(1);  // (in the step, beside the other streams' kernels: no difference with or without, 990.5 / 987.5 vs 990.3 / 992.8 ms)
-        __syncthreads();
-        for (int t = 0; t < nt; t += 2) {
-            if (!(dbg & 2)) compute(0);  // (dgmr_debug_flags 16 -> dbg 2: timing probe without the matrix work)
-            __syncthreads();
-            if (t + 1 < nt && !(dbg & 2)) compute(1);
-            __syncthreads();
-        }
-        // ---- partial[slab][co][tap*Cin + ci]: lane = input channel, 16 output channels per MFMA block ----
-        const int Ktot = 9 * p.KD * p.Cin, tap0 = (p.KD == 3 ? kd : 0) * 9;  // K order (kd, kh, kw, ci)
-        float* out = p.partial + (size_t)slab * p.Cout * Ktot;
-        const int ci = chunk * CK + (lane & 31);
-        if (ci < p.Cin) {
+            // ---- partial[slab][co][tap*Cin + ci]: lane = input channel (16 per wave), 4 output channels per lane and block ----
+            const int Ktot = 9 * p.KD * p.Cin, tap0 = (p.KD == 3 ? kd : 0) * 9;
+            float* out = p.partial + (size_t)slab * p.Cout * Ktot;
+            const int ci = chunk * CK + cih * 16 + (lane & 15);
+            if (ci < p.Cin) {
 #pragma unroll
-            for (int c = 0; c < CB; ++c)
+                for (int c = 0; c < CBH; ++c)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (co >= p.Cout) continue;
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + (coh * CBH + c) * 16 + 4 * (lane >> 4) + r;
+                        if (co >= p.Cout) continue;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) out[(size_t)co * Ktot + (tap0 + wid * 3 + d) * p.Cin + ci] = acc[c * 3 + d][r];
+                        for (int t = 0; t < 9; ++t) out[(size_t)co * Ktot + (tap0 + t) * p.Cin + ci] = acc[t][c][r];
+                    }
+            }
+        } else {
+            f32x16 acc[CB * 3];
+    #pragma unroll
+            for (int a = 0; a < CB * 3; ++a)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+            // transposing-read geometry of this lane: 16-lane group g, lane i of it supplies row (i >> 2) of the 4 x 16 block, segment (i & 3)
+            const int tg = lane >> 4, ti = lane & 15;
+            const int k_lane = 8 * (tg >> 1) + (ti >> 2);      // pixel (inside a 16-pixel step) whose row this lane addresses for k 0..3
+            const int col_lane = 16 * (tg & 1) + 4 * (ti & 3);  // first of the 4 channels (inside a 32-channel block) it addresses
+            auto compute = [&](int buf) {
+                const uint32_t* Xs = smem + buf * BUF;
+                const uint32_t* Ys = Xs + NP * XPL;
+                // 16-pixel step kk = tile pixels [16 kk, 16 kk + 16): tile row (16 kk) >> TWS, first column (16 kk) & (TW - 1); filter row
+                // wid reads halo row (tile row + wid), tap d halo column (column + d)
+                auto fetch_x = [&](int kk, int pl, bf16x8_t (&dst)[3]) {
+                    const int hp0 = (((kk * 16) >> TWS) + wid) * HTW + ((kk * 16) & (TW - 1));
+                    const uint32_t* xb = Xs + pl * XPL + (hp0 + k_lane) * XROW + (col_lane >> 1);
+    #pragma unroll
+                    for (int d = 0; d < 3; ++d) dst[d] = tr_fragment(xb + d * XROW, 4 * XROW);
+                };
+                auto fetch_y = [&](int kk, int pl, bf16x8_t (&dst)[CB]) {
+                    const uint32_t* yb = Ys + pl * YPL + (kk * 16 + k_lane) * YROW + (col_lane >> 1);
+    #pragma unroll
+                    for (int c = 0; c < CB; ++c) dst[c] = tr_fragment(yb + c * 16, 4 * YROW);
+                };
+                auto mm = [&](const bf16x8_t (&y)[CB], const bf16x8_t (&x)[3]) {
+    #pragma unroll
+                    for (int c = 0; c < CB; ++c)
+    #pragma unroll
+                        for (int d = 0; d < 3; ++d) acc[c * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[c], x[d], acc[c * 3 + d], 0, 0, 0);
+                };
+                // instruction order asked of the scheduler for one product with `reads` transposing LDS reads to hide: the reads spread
+                // over the product's MFMAs instead of clustered before them.  A wave issues in order and an MFMA occupies the matrix pipe
+                // for 32 cycles, so a read placed between two MFMAs issues in the first one's shadow; a cluster of reads ahead of the
+                // MFMAs is paid in full - and ONE wave per SIMD gets 8-byte LDS reads out at a fraction of the LDS rate (~10 cycles
+                // each, MI355X_MICROARCH.md, LDS), which is what the matrix waves have
+                auto interleave = [&](auto reads_c) { ws_interleave<decltype(reads_c)::value, CB * 3, 0>(); };
+                if constexpr (NP == 2) {
+                    // bf16x3 = three products hi.lo + lo.hi + hi.hi per step.  Every fragment group is read ONE product before the product
+                    // that needs it, into registers whose last reader has just finished - 5 fragment groups (60 registers) live at the
+                    // peak instead of the 8 of two whole sets, beside the 144 accumulator registers:
+                    //   product      operands            reads in its shadow
+                    //   hi.lo        y0[e], x1           y1, x0       (this step's other two products)
+                    //   lo.hi        y1,    x0           x1', y0[e^1] (the next step's first product; x1 is free since hi.lo)
+                    //   hi.hi        y0[e], x0           -
+                    constexpr int RX = 3 * 2, RY = CB * 2;  // LDS reads per X / dY fragment group
+                    using R = std::integral_constant<int, RX + RY>;
+                    bf16x8_t y0[2][CB], x0[3], x1[3], y1[CB];
+                    fetch_y(0, 0, y0[0]), fetch_x(0, 1, x1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, RX + RY, 0);
+    #pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int e = kk & 1;
+                        fetch_y(kk, 1, y1), fetch_x(kk, 0, x0);
+                        mm(y0[e], x1);  // hi(dY) . lo(x)
+                        interleave(R{});
+                        if (kk < 3) fetch_x(kk + 1, 1, x1), fetch_y(kk + 1, 0, y0[e ^ 1]);
+                        mm(y1, x0);  // lo(dY) . hi(x)
+                        if (kk < 3) interleave(R{});
+                        else __builtin_amdgcn_sched_group_barrier(0x008, CB * 3, 0);
+                        mm(y0[e], x0);  // hi . hi
+                        __builtin_amdgcn_sched_group_barrier(0x008, CB * 3, 0);
+                    }
+                } else if constexpr (NP == 1) {
+                    bf16x8_t xf[2][3], yf[2][CB];
+                    fetch_x(0, 0, xf[0]), fetch_y(0, 0, yf[0]);
+    #pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        if (kk < 3) fetch_x(kk + 1, 0, xf[(kk + 1) & 1]), fetch_y(kk + 1, 0, yf[(kk + 1) & 1]);
+                        mm(yf[kk & 1], xf[kk & 1]);
+                    }
+                } else {  // bf16x6: six products per step (54 MFMAs) behind one fragment set of 72 registers
+    #pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        bf16x8_t xf[NP][3], yf[NP][CB];
+    #pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) fetch_x(kk, pl, xf[pl]), fetch_y(kk, pl, yf[pl]);
+                        for_each_product<NP>([&](auto qa, auto qb) { mm(yf[qa], xf[qb]); });
+                    }
                 }
+            };
+            __builtin_amdgcn_s_setprio(1);  // (in the step, beside the other streams' kernels: no difference with or without, 990.5 / 987.5 vs 990.3 / 992.8 ms)
+            __syncthreads();
+            for (int t = 0; t < nt; t += 2) {
+                if (!(dbg & 2)) compute(0);  // (dgmr_debug_flags 16 -> dbg 2: timing probe without the matrix work)
+                __syncthreads();
+                if (t + 1 < nt && !(dbg & 2)) compute(1);
+                __syncthreads();
+            }
+            // ---- partial[slab][co][tap*Cin + ci]: lane = input channel, 16 output channels per MFMA block ----
+            const int Ktot = 9 * p.KD * p.Cin, tap0 = (p.KD == 3 ? kd : 0) * 9;  // K order (kd, kh, kw, ci)
+            float* out = p.partial + (size_t)slab * p.Cout * Ktot;
+            const int ci = chunk * CK + (lane & 31);
+            if (ci < p.Cin) {
+    #pragma unroll
+                for (int c = 0; c < CB; ++c)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (co >= p.Cout) continue;
+    #pragma unroll
+                        for (int d = 0; d < 3; ++d) out[(size_t)co * Ktot + (tap0 + wid * 3 + d) * p.Cin + ci] = acc[c * 3 + d][r];
+                    }
+            }
         }
         if (want_bias) {  // (deterministic within the workgroup; across workgroups one float atomic per channel, as in wgrad_win.h)
             __syncthreads();  // the loaders have written their sums: slot i of thread lt covers channel quad (lt + i NL) mod YQ

@@ -105,7 +105,7 @@ def test_wgrad_plan_is_host_arithmetic(lib):
                 ns = plan(prec, n, h, w, cin, cout, k, groups)
                 assert ns >= groups and ns % groups == 0 and ns <= 4096, (prec, n, h, w, cin, cout, k, groups, ns)
         # window path (bf16x3, 3x3, W % 32 == 0), workgroups = chunks x output tiles x slabs: one round of <= 256 for the wave-specialised
-        # kernel (one workgroup per CU), of <= 512 for the one-role kernel (dgmr_conv_tune wgrad_window = 1)
+        # kernels (one workgroup per CU), of <= 512 for the one-role kernel (dgmr_conv_tune wgrad_window = 1)
         ns = plan(1, 288, 128, 128, 96, 96, 3, 18)
         assert 3 * 1 * ns <= 256 and ns == 72
         assert lib.dgmr_conv_tune(-1, -1, -1, 1) == 0

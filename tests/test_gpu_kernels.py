@@ -221,7 +221,7 @@ def test_window_wgrad_matches_im2col_wgrad(tuned, n, h, w, cin, cout, up, bn, gr
     b = torch.randn(groups * cin, device=DEV) * 0.3
     k = 9 * kd * cin
     res = {}
-    for mode in (0, 1, 2):  # im2col, one-role window kernel (2-D only: im2col again for 3-D), wave-specialised window kernel
+    for mode in (0, 1, 2, 3):  # im2col, one-role window kernel (2-D only: im2col again for 3-D), wave-specialised kernel with 3 / 4 matrix waves
         tuned(-1, -1, -1, mode)
         bias = torch.zeros(cout, device=DEV)
         wa = WgradArgs()
@@ -240,7 +240,7 @@ def test_window_wgrad_matches_im2col_wgrad(tuned, n, h, w, cin, cout, up, bn, gr
         torch.cuda.synchronize()
         res[mode] = (partial.view(groups, ns // groups, cout, k).double().sum(1), bias.double())
     g0, b0 = res[0]
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         g1, b1 = res[mode]
         assert not torch.isnan(g1).any(), mode
         assert float((g0 - g1).abs().max()) <= tol * float(g0.abs().max()), mode

@@ -2,8 +2,8 @@
 
     python tools/wgrad_check.py [--prec=bf16x3] [--modes=1,2] [--dbg=16] [shape substrings]
 
---modes: two dgmr_conv_tune wgrad_window values - 0 im2col, 1 one-role LDS-window kernel (wgrad_win.h), 2 wave-specialised one
-(wgrad_ws.h, the library's choice); default 1,2.
+--modes: two dgmr_conv_tune wgrad_window values - 0 im2col, 1 one-role LDS-window kernel (wgrad_win.h), 2 / 3 wave-specialised one
+(wgrad_ws.h) with three / four matrix waves (3 = the library's choice); default 1,3.
 """
 import ctypes
 import os
@@ -49,7 +49,7 @@ def bench(fn, iters=5):
     return e0.elapsed_time(e1) / iters
 
 
-MODES = (1, 2)
+MODES = (1, 3)
 
 
 def main():
