@@ -1,5 +1,5 @@
 // Weight gradient of a 3x3 convolution, WAVE-SPECIALISED (round 3): four loader waves keep a double-buffered LDS image of the next
-// tile coming while three matrix waves multiply the current one.
+// tile coming while three or four matrix waves multiply the current one.
 //
 //   G[co][tap][ci] = sum over pixels  dY[n,h,w,co] * pre(x)[n, h+dy, w+dx, ci]     (autograd of F.conv2d at every `spectral_norm(conv)`
 //                                                                                   call of the reference)
@@ -16,8 +16,9 @@
 //     becomes the fragment's k without any data movement, and the +-1 shifts of the taps are plain row offsets;
 //   * LDS holds TWO tile images: while the matrix waves are on tile t the loaders store tile t + 1 (fetched two iterations earlier
 //     into one of two register sets: the HBM latency has two whole matrix phases to pass) - ONE barrier per tile;
-//   * wave w < 3 owns filter row w (3 taps x BI / 32 output-channel blocks = up to 9 accumulators [32 co x 32 ci], as before);
-//     one workgroup of 7 waves per CU (84 KB of LDS at BI = 96 in bf16x3);
+//   * matrix waves: MW = 3 - wave w owns filter row w (3 taps x BI / 32 output-channel blocks = up to 9 accumulators [32 co x 32 ci],
+//     as before) - or MW = 4, one per SIMD, on 16 x 16 x 32 MFMAs (see the template); one workgroup of 7 / 8 waves per CU (84 KB of
+//     LDS at BI = 96 in bf16x3);
 //   * the two roles are two DISJOINT programs (`if (loader) {...} else {...}`, each with its own loop) that meet at the same
 //     barriers - the hardware counts arriving waves, not code addresses.  In one shared loop with per-role bodies the compiler keeps
 //     the loaders' 104 staging registers and the 144 accumulators live together (1 KB of scratch per lane) and merges the two paths'
