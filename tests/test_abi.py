@@ -186,6 +186,47 @@ def test_lds_dma_stages_are_drained_before_their_barrier(lib, tmp_path):
     assert checked >= 30, checked  # three instantiations x (1 + 9 + 1) barriers
 
 
+def test_wave_specialised_wgrad_keeps_its_prefetch_in_flight(lib, tmp_path):
+    """wgrad_ws.h: the loader waves fetch tile t + 3 into one of two register sets while tile t + 1 is being stored, so at every wait
+    of the loader program a whole set (XP + YP sixteen-byte loads) must be allowed to stay in flight.  hipcc computes s_waitcnt vmcnt
+    as the minimum over all control-flow paths: one conditional prefetch, a break inside the loop, or a scratch reload between two
+    global loads turns the waits into vmcnt(0 ... 9) and the prefetch depth of two into one - silently, with correct results and
+    20 - 60 % longer launches.  Checked in the BINARY, for every instantiation: between the first and the last
+    global load, no wait below XP + YP; transposing LDS reads present; no scratch instruction in the bf16 / bf16x3 variants."""
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    from skillful_nowcasting_amd import _lib
+
+    so = tmp_path / "libdgmr_hip.so"
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], check=True, cwd=tmp_path, capture_output=True)
+    checked = set()
+    for bname in [f for f in os.listdir(tmp_path) if "gfx950" in f]:
+        asm = subprocess.run([objdump, "-d", str(tmp_path / bname)], check=True, capture_output=True, text=True).stdout.split("\n")
+        heads = [i for i, l in enumerate(asm) if l.endswith(">:")]
+        for hi, start in enumerate(heads):
+            m = re.search(r"conv_wgrad_ws_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", asm[start])
+            if not m:
+                continue
+            bi, ns, tws, mw = (int(v) for v in m.groups())
+            body = asm[start:heads[hi + 1] if hi + 1 < len(heads) else len(asm)]
+            loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l]
+            assert loads, asm[start]
+            hpix = (32 + 2) * (2 + 2) if tws == 5 else (16 + 2) * (4 + 2)
+            per_set = -(-hpix * 8 // 256) + bi // 16  # XP + YP
+            waits = [int(w.group(1)) for l in body[loads[0]:loads[-1] + 1] for w in [re.search(r"s_waitcnt.*vmcnt\((\d+)\)", l)] if w]
+            assert waits and min(waits) >= per_set, f"{asm[start]}: vmcnt waits {sorted(set(waits))} in the loader program, a set is {per_set} loads"
+            assert any("ds_read_b64_tr_b16" in l for l in body), asm[start]
+            if ns != 6:
+                assert not any("scratch_" in l for l in body), f"{asm[start]}: scratch traffic in the weight-gradient kernel"
+            checked.add((bi, ns, tws, mw))
+    assert len(checked) == 20, sorted(checked)  # BI {64, 96} x tile {32x2, 16x4} x (bf16, bf16x3: 3 and 4 matrix waves; bf16x6: 3)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from skillful_nowcasting_amd import _lib
 
