@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DGMR_BENCH_BATCH", "16")), help="per-GPU batch")
     ap.add_argument("--workload", default="paper", choices=["paper", "cfg2", "cfg5", "smoke"])
     ap.add_argument("--fast", action="store_true", help="strict_reference_semantics=False (skip discarded work)")
-    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "off"])
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "off", "only"])
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tune", default="", help="A/B switch for kernel development: variant,ksplit,window,wgrad_window for "
                                                "dgmr_conv_tune (-1 = the library's own choice, the default)")
@@ -80,21 +80,73 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(kw, hw, T):
-    """Oracle (CPU restatement of the reference, `kind: port`) timed on this host on a bounded sample: ONE whole
-    `training_step` (oracle.training_step = dgmr/dgmr.py:137-218 as written: 17 generator forwards, 8 generator backwards, 16
-    discriminator sequence forwards and backwards, both Adam updates) at the bench's model configuration and batch 1.
-    frames/s = (4 + T) / t_step.  The generator forward is timed twice beside it as a spread indicator."""
+def _cpu_threads():
     import torch
-
-    import skillful_nowcasting_amd as S
-    from oracle import dgmr_oracle as O
 
     # torch's CPU convolutions scale badly past a few tens of threads on these shapes: on the 2x EPYC 9575F GPU box one paper-config
     # generator forward takes 0.88 / 0.75 / 2.13 / 3.80 / 8.70 s at 8 / 16 / 32 / 64 / 128 threads (tools/cpu_threads_probe.py), so
     # the baseline runs at the best setting rather than at torch's default (all cores)
     threads = int(os.environ.get("DGMR_CPU_BASELINE_THREADS", "16"))
     torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
+    return torch.get_num_threads()
+
+
+def cpu_baseline_reference(kw, hw, T):
+    """The UNMODIFIED reference (`oracle/_ref/dgmr`, staged byte for byte from /root/reference/dgmr by oracle/make_ref.py) timed on
+    THIS host: whole `DGMR.training_step` calls (dgmr/dgmr.py:137-218) at the bench's model configuration and batch 1, through the
+    stand-ins of oracle/_stubs.py for the three packages the image lacks (pytorch_lightning's LightningModule -> nn.Module with
+    manual_backward / optimizers / log_dict, torchvision, pytorch_msssim: none of them does arithmetic on this path).  One step AS
+    WRITTEN (torch.autograd.set_detect_anomaly(True), dgmr.py:130) is `value`; a second with anomaly detection off rides along.
+    Returns None when oracle/_ref is absent."""
+    ref_root = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.isdir(os.path.join(ref_root, "dgmr")):
+        return None
+    import torch
+
+    from oracle import _stubs
+
+    _stubs.install(ref_root)
+    import dgmr as ref  # the reference's own package
+
+    assert os.path.realpath(ref.__file__).startswith(os.path.realpath(ref_root)), ref.__file__
+    cores = _cpu_threads()
+    torch.manual_seed(0)
+    model = ref.DGMR(**kw)  # (sets anomaly detection on, globally, as the reference does)
+    model.train()
+    x = torch.rand(1, 4, 1, hw, hw)
+    y = torch.rand(1, T, 1, hw, hw)
+    with torch.no_grad():
+        model(x)  # warm-up: thread pool, oneDNN primitive caches (advances u / v like any forward)
+    times = {}
+    for label, anomaly in (("anomaly_off", False), ("as_written_anomaly_on", True)):  # (the first step also pays the one-off warm-up costs)
+        torch.autograd.set_detect_anomaly(anomaly)
+        t0 = time.perf_counter()
+        model.training_step((x, y), 0)
+        times[label] = time.perf_counter() - t0
+    torch.autograd.set_detect_anomaly(False)
+    t_step = times["as_written_anomaly_on"]
+    return {
+        "value": (4 + T) / t_step, "unit": "radar frames/s", "cores": cores, "kind": "reference", "host_cpus": os.cpu_count(),
+        "seconds_per_step": {k: round(v, 2) for k, v in times.items()},
+        "value_anomaly_off": (4 + T) / times["anomaly_off"],
+        "sample": f"the unmodified reference's DGMR.training_step (dgmr/dgmr.py:137-218; package staged by oracle/make_ref.py, "
+                  f"LightningModule stand-in from oracle/_stubs.py), torch-CPU fp32, batch 1, {cores} threads of {os.cpu_count()} host "
+                  f"CPUs: one step with anomaly detection off first ({times['anomaly_off']:.1f} s, absorbs "
+                  f"the one-off warm-up), then ONE step as written (anomaly detection on, dgmr.py:130) = {t_step:.1f} s = `value`; no extrapolation",
+    }
+
+
+def cpu_baseline(kw, hw, T):
+    """Oracle (CPU restatement of the reference, `kind: port`) timed on this host on a bounded sample: ONE whole
+    `training_step` (oracle.training_step = dgmr/dgmr.py:137-218 as written: 17 generator forwards, 8 generator backwards, 16
+    discriminator sequence forwards and backwards, both Adam updates) at the bench's model configuration and batch 1.
+    frames/s = (4 + T) / t_step.  Used only when the staged reference (cpu_baseline_reference) is absent."""
+    import torch
+
+    import skillful_nowcasting_amd as S
+    from oracle import dgmr_oracle as O
+
+    cores = _cpu_threads()
     torch.manual_seed(0)
     model = S.DGMR(**kw)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items() if k.startswith(("generator.", "discriminator."))}
@@ -102,24 +154,19 @@ def cpu_baseline(kw, hw, T):
     x = torch.rand(1, 4, 1, hw, hw)
     y = torch.rand(1, T, 1, hw, hw)
     z = O.draw_latent((8, hw // 32, hw // 32))
-    t_gf = []
     with torch.no_grad():
         O.generator(sd, "generator.", x, z, T, True)  # warm-up (thread pool, oneDNN primitive caches)
-        for _ in range(2):
-            t0 = time.perf_counter()
-            O.generator(sd, "generator.", x, z, T, True)
-            t_gf.append(time.perf_counter() - t0)
     hp = dict(forecast_steps=T, generation_steps=kw.get("generation_steps", 6), grid_lambda=20.0, gen_lr=5e-5, disc_lr=2e-4, beta1=0.0,
               beta2=0.999, precip_weight_cap=24.0, latent_shape=(8, hw // 32, hw // 32), num_spatial_frames=8)
     t0 = time.perf_counter()
     O.training_step(sd, x, y, hp, {"step": {}, "m": {}, "v": {}})
     t_step = time.perf_counter() - t0
     return {
-        "value": (4 + T) / t_step, "unit": "radar frames/s", "cores": torch.get_num_threads(), "kind": "port",
+        "value": (4 + T) / t_step, "unit": "radar frames/s", "cores": cores, "kind": "port",
         "host_cpus": os.cpu_count(),
         "sample": f"oracle.training_step (torch-CPU fp32 restatement of the reference's step, as written: 17 G fwd, 8 G bwd, 16 D "
                   f"seq fwd+bwd, 2 Adam) at its best thread count on this host, batch 1, ONE measured step of {t_step:.1f} s (no "
-                  f"extrapolation); generator forward alone {t_gf[0]:.2f} / {t_gf[1]:.2f} s in two repeats",
+                  f"extrapolation); oracle/_ref (the staged reference package) was not present",
     }
 
 
@@ -161,6 +208,10 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)
+    if args.cpu_baseline == "only":  # (host-only check of the cpu_baseline leg; needs no GPU)
+        kw, hw, T = WORKLOADS[args.workload]
+        print(json.dumps(cpu_baseline_reference(kw, hw, T) or cpu_baseline(kw, hw, T)))
+        return
     import torch
     import torch.distributed as dist
 
@@ -245,6 +296,19 @@ def main():
         torch.cuda.synchronize()
         lib.dgmr_profile_enable(0)
         S.ops._WGRAD_STREAM = side
+        # rows per INSTANTIATED kernel (tile, mode, launch size, arithmetic) - read before collect2, which clears the records
+        need = lib.dgmr_profile_collect_detail(None, 0)
+        dbuf = ctypes.create_string_buffer(need + 16)
+        lib.dgmr_profile_collect_detail(dbuf, need + 16)
+        detail = []
+        for line in dbuf.value.decode().splitlines():
+            name, n_l, ms_l, fl_l, ex_l = line.split("\t")
+            n_l, ms_l, fl_l, ex_l = int(n_l), float(ms_l), float(fl_l), float(ex_l)
+            pk = PEAK_F32_MFMA_TFLOPS if name.endswith("[f32]") else PEAK_BF16_MFMA_TFLOPS
+            tf = fl_l / (ms_l * 1e-3) / 1e12 if ms_l > 0 else 0.0
+            detail.append(dict(kernel=name, launches=n_l, total_ms=ms_l, avg_us=1e3 * ms_l / max(n_l, 1), flops_per_launch=fl_l / max(n_l, 1),
+                               tflops=tf, mfma_executed_tflops=ex_l / (ms_l * 1e-3) / 1e12 if ms_l > 0 else 0.0, peak_tflops=pk, frac=tf / pk))
+        detail.sort(key=lambda r: -r["total_ms"])
         nv = lib.dgmr_profile_variants()
         ms = (ctypes.c_double * nv)()
         fl = (ctypes.c_double * nv)()
@@ -279,6 +343,11 @@ def main():
                            "frac": (F_STEP_TFLOP[args.workload] * B / (ms_step * 1e-3) / peak) if args.workload in F_STEP_TFLOP else None,
                            "note": "SURVEY.md §8(d): F_step = 20 F_g + 30 F_d per sample, over the whole step time"},
             "per_kernel": rows,
+            "per_kernel_detail": detail,
+            "per_kernel_detail_note": "the class rows of per_kernel split by instantiated kernel: output-channel block / pixels per workgroup, "
+                                      "mode (plain 3x3 | phase = forward of an upsampling conv as four 2x2 convs | pooled = its data gradient), "
+                                      "ConvGRU epilogue, split-K, 1x1, launch size (small = fewer than 1024 workgroups), arithmetic of the launch; "
+                                      "tflops = flops_per_launch x launches / total_ms",
         }
         # HBM traffic of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs, FETCH_SIZE doubled per
         # MI355X_MICROARCH.md): measured on one representative launch of that kernel (tools/pmc_conv.sh), not inside this process
@@ -289,7 +358,14 @@ def main():
         if pmc_path:
             pmc = json.load(open(pmc_path))
             if pmc.get("precision") in (precision, {"mixed": "bf16x3"}.get(precision)) and dom["kernel"] in pmc.get("kernel", ""):
+                # `traffic` belongs to ONE named launch of the dominant kernel (pmc_launch: its own duration, flops and bytes);
+                # avg_launch_us / flops_per_launch above are the class averages over the step - two different things, both labelled
                 roof["traffic"] = pmc["traffic_bytes"]
+                roof["mfma_util"] = pmc.get("mfma_util")
+                roof["valu_per_mfma"] = pmc.get("valu_per_mfma")
+                roof["pmc_launch"] = {k: pmc.get(k) for k in ("kernel", "shape", "launch_us", "algorithmic_tflops", "mfma_executed_tflops",
+                                                               "traffic_bytes", "algorithmic_bytes", "traffic_over_algorithmic", "hbm_gbps",
+                                                               "mfma_util", "valu_per_mfma", "wave_cycles_split")}
                 roof["traffic_detail"] = {k: pmc[k] for k in ("shape", "launch_us", "algorithmic_bytes", "traffic_over_algorithmic",
                                                               "hbm_gbps", "mfma_util", "valu_per_mfma", "traffic_note")}
                 roof["traffic_detail"]["source"] = (f"profiles/{os.path.basename(pmc_path)} (+ raw counters in profiles/*_pmc_*.csv): "
@@ -348,7 +424,7 @@ def main():
         if also:
             out["also"] = also
         if args.cpu_baseline != "off":
-            out["cpu_baseline"] = cpu_baseline(kw, hw, T)
+            out["cpu_baseline"] = cpu_baseline_reference(kw, hw, T) or cpu_baseline(kw, hw, T)
             if args.workload in REFERENCE_MEASURED:
                 out["cpu_baseline"]["reference_measured"] = REFERENCE_MEASURED[args.workload]
         print(json.dumps(out))

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGMR_ABI_VERSION 8
+#define DGMR_ABI_VERSION 9
 
 int dgmr_abi_version(void);
 const char* dgmr_last_error(void);
@@ -442,6 +442,11 @@ int dgmr_profile_collect(double* total_ms, double* total_flops, int64_t* launche
  * as phase convs / pooled data gradients (w_phase), times the MFMAs per product of the mode the launch was issued in (3 in
  * DGMR_PREC_BF16X3, 6 in DGMR_PREC_BF16X6; ABI 8: this factor used to be the caller's to apply). */
 int dgmr_profile_collect2(double* total_ms, double* total_flops, double* executed_flops, int64_t* launches, int n);
+/* (ABI 9) The same records grouped by INSTANTIATED kernel instead of by class: tile (output-channel block, 128- / 256-pixel), mode
+ * (plain / phase / pooled 3x3, 3-D, ConvGRU epilogue, split-K, 1x1), launch size (fewer than 1024 workgroups = "small": such a launch
+ * cannot fill 256 CUs four times over) and arithmetic.  Writes "name\tlaunches\ttotal_ms\talgorithmic_flops\texecuted_flops\n" lines
+ * (NUL-terminated, truncated to cap) and returns the bytes needed.  Does not clear the records: call it BEFORE dgmr_profile_collect*. */
+int dgmr_profile_collect_detail(char* buf, int cap);
 /* Dispatch override for tools/conv_bench.py's tile / split-K sweeps (process-wide; -1 = the library's own choice, which is
  * also the state at load): variant = index of a conv_fwd_dgrad<..> tile as listed by dgmr_profile_variant_name, ksplit = number
  * of K slabs (needs a workspace in the args), window = 0 never / 1 the register-staged LDS-window 3x3 kernel whenever the geometry allows / 2 likewise, with the experimental

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdgmr_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 P = c_void_p  # every device pointer and the stream travel as void*
 
@@ -123,6 +123,7 @@ SIGNATURES = {
     "dgmr_profile_variants": [],
     "dgmr_profile_collect": [P, P, P, i],
     "dgmr_profile_collect2": [P, P, P, P, i],
+    "dgmr_profile_collect_detail": [P, i],
 }
 del i, f, L
 

@@ -11,7 +11,10 @@
 // staged global -> registers -> LDS (double-buffered, one barrier per K step) so the next tile's HBM
 // latency hides under the current tile's MFMAs; LDS rows are padded to BK+4 floats, which makes the
 // ds_read_b128 fragment reads (lane = row, 4 consecutive k) conflict-free.
+#include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "conv_bf16.h"  // split_weights_kernel (the bf16 MFMA kernels themselves are instantiated in tu_*.hip, see conv_launch.h)
@@ -236,6 +239,7 @@ __global__ void splitk_reduce4_kernel(const dgmr_conv_args p, const int M, const
 int g_precision = 0;  // (documented below, with the dispatch switches)
 struct ProfRec {
     int variant;
+    uint32_t detail;  // the instantiated kernel behind the class row: dgmr_profile_detail (prof_detail_* below)
     double flops;     // algorithmic: 2 * MACs of the dense convolution as the reference states it
     double executed;  // flops the matrix pipe really issues: x 16/36 for the phase / pooled decompositions, x MFMAs per product (3 in
                       // bf16x3, 6 in bf16x6) - the mode is the launch's own, a step may mix them
@@ -261,10 +265,11 @@ struct ProfScope {
     bool on;
     ProfRec r;
     hipStream_t s;
-    ProfScope(int variant, double flops, hipStream_t st, double exec_frac = 1.0) : on(g_prof_on), s(st) {
+    ProfScope(int variant, double flops, hipStream_t st, double exec_frac = 1.0, uint32_t detail = 0) : on(g_prof_on), s(st) {
         if (!on) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         r.variant = variant;
+        r.detail = detail | ((uint32_t)g_precision << 28);
         r.flops = flops;
         r.executed = flops * exec_frac * (g_precision == 1 ? 3.0 : (g_precision == 3 ? 6.0 : 1.0));
         r.e0 = prof_event();
@@ -756,7 +761,11 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
                    "dgmr_conv_fwd: stats_out given but the dispatched kernel has no fused statistics (ask dgmr_conv_stats_rows first)");
     if (window_plan(p, &wp)) {
         const int v = wp.bnw == 128 ? V_WIN128 : (wp.bnw == 96 ? V_WIN96 : V_WIN64);
-        ProfScope ps(v, flops, s, (phases || p.reserved0 == 2) ? 16.0 / 36.0 : 1.0);
+        const int64_t wgs = (int64_t)wp.grid_x * (phases ? 4 : 1) * ((p.Cout + wp.bnw - 1) / wp.bnw);
+        const uint32_t detail = 1u | ((wp.bnw == 48 ? 0u : (wp.bnw == 64 ? 1u : (wp.bnw == 96 ? 2u : 3u))) << 4) | ((wp.big ? 1u : 0u) << 8) |
+                                ((uint32_t)p.reserved0 << 9) | ((p.KD == 3 ? 1u : 0u) << 11) | ((wgs < 1024 ? 1u : 0u) << 12) |
+                                ((wp.glds ? 0u : 1u) << 13) | ((p.epi_mode != DGMR_EPI_PLAIN ? 1u : 0u) << 14);
+        ProfScope ps(v, flops, s, (phases || p.reserved0 == 2) ? 16.0 / 36.0 : 1.0, detail);
         if (DGMR_BY_NS(launch_window, p, wp, phases, g_tune_window, s) != 0) return -1;
         DGMR_CHECK_LAUNCH();
         return 0;
@@ -784,7 +793,12 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         }
     }
     {
-        ProfScope ps(variant, flops, s);
+        const int bm_v = variant == V_F64x64 ? 64 : 128;
+        const int bn_v = variant == V_F128x128 ? 128 : (variant == V_F128x96 ? 96 : (variant == V_F128x32 ? 32 : 64));
+        const int64_t wgs_v = ((M64 + bm_v - 1) / bm_v) * ((C + bn_v - 1) / bn_v) * (p.ksplit > 1 ? p.ksplit : 1);
+        const uint32_t detail = 2u | ((uint32_t)variant << 4) | ((p.ksplit > 1 ? 1u : 0u) << 8) | ((Ktot == p.Cin ? 1u : 0u) << 9) |
+                                ((p.KD == 3 ? 1u : 0u) << 11) | ((wgs_v < 1024 ? 1u : 0u) << 12) | ((p.epi_mode != DGMR_EPI_PLAIN ? 1u : 0u) << 14);
+        ProfScope ps(variant, flops, s, 1.0, detail);
         switch (variant) {
             case V_F128x128: launch_conv<V_F128x128, 128, 128, 2, 2>(p, M, Ktot, s); break;
             case V_F64x64: launch_conv<V_F64x64, 64, 64, 2, 2>(p, M, Ktot, s); break;
@@ -886,7 +900,10 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
     rows = (rows + 31) / 32 * 32;
     hipStream_t s = (hipStream_t)stream;
     const int kt = (Ktot + 127) / 128;
-    ProfScope ps(a->Cout <= 32 ? V_W32 : (a->Cout <= 64 ? V_W64 : V_W128), 2.0 * (double)M64 * (double)Ktot * (double)a->Cout, s);
+    const int wclass = a->Cout <= 32 ? V_W32 : (a->Cout <= 64 ? V_W64 : V_W128);
+    const uint32_t wdetail = 3u | ((wgrad_uses_window(a) ? (wgrad_ws() ? 2u : 1u) : 0u) << 4) | ((uint32_t)(wclass - V_W128) << 6) |
+                             ((a->KD == 3 ? 1u : 0u) << 8) | ((a->upsample ? 1u : 0u) << 9) | ((Ktot == a->Cin ? 1u : 0u) << 10);
+    ProfScope ps(wclass, 2.0 * (double)M64 * (double)Ktot * (double)a->Cout, s, 1.0, wdetail);
     // 3x3 convs on maps with whole rows of 32 pixels, bf16 modes: LDS-window weight gradient (wgrad_win.h)
     if (wgrad_uses_window(a)) {
         const int tw_shift = wgrad_window_tw_shift(a);
@@ -1087,6 +1104,56 @@ extern "C" const char* dgmr_profile_variant_name(int v) { return (v >= 0 && v < 
 // Synchronises the events recorded so far and returns per-variant totals; clears the records.
 extern "C" int dgmr_profile_collect(double* total_ms, double* total_flops, int64_t* launches, int n) {
     return dgmr_profile_collect2(total_ms, total_flops, nullptr, launches, n);
+}
+
+// Per instantiated kernel (class row x tile / mode / launch size): "name\tlaunches\ttotal_ms\talgorithmic_flops\texecuted_flops\n" lines,
+// NUL-terminated; returns the number of bytes needed (call before dgmr_profile_collect*, which clears the records).
+static std::string prof_detail_name(int variant, uint32_t d) {
+    static const char* const prec[] = {"f32", "bf16x3", "bf16", "bf16x6"};
+    char b[160];
+    const int kind = d & 15;
+    const char* pr = prec[(d >> 28) & 3];
+    if (kind == 1) {
+        static const int bn[] = {48, 64, 96, 128};
+        static const char* const mode[] = {"plain", "phase", "pooled", "phase4"};
+        snprintf(b, sizeof b, "win3x3<bn%d,%dpx>%s%s%s%s %s %s", bn[(d >> 4) & 3], (d >> 8) & 1 ? 256 : 128, (d >> 13) & 1 ? " reg-staged" : "",
+                 (d >> 11) & 1 ? " 3d" : "", (d >> 14) & 1 ? " gru" : "", (d >> 15) & 1 ? " ws" : "", mode[(d >> 9) & 3], (d >> 12) & 1 ? "small(<1024wg)" : "big");
+    } else if (kind == 2) {
+        snprintf(b, sizeof b, "%s%s%s%s%s %s", kVariantNames[variant], (d >> 8) & 1 ? " splitk" : "", (d >> 9) & 1 ? " 1x1" : "",
+                 (d >> 11) & 1 ? " 3d" : "", (d >> 14) & 1 ? " gru" : "", (d >> 12) & 1 ? "small(<1024wg)" : "big");
+    } else if (kind == 3) {
+        static const char* const k[] = {"im2col", "window(one-role)", "window(wave-specialised)", "?"};
+        snprintf(b, sizeof b, "%s %s%s%s%s", kVariantNames[variant], k[(d >> 4) & 3], (d >> 8) & 1 ? " 3d" : "", (d >> 9) & 1 ? " upsample" : "",
+                 (d >> 10) & 1 ? " 1x1" : "");
+    } else {
+        snprintf(b, sizeof b, "%s", variant >= 0 && variant < V_COUNT ? kVariantNames[variant] : "?");
+    }
+    return std::string(b) + " [" + pr + "]";
+}
+
+extern "C" int dgmr_profile_collect_detail(char* buf, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    struct Row { int64_t n = 0; double ms = 0, fl = 0, ex = 0; };
+    std::map<std::string, Row> rows;
+    for (auto& r : g_prof) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        Row& w = rows[prof_detail_name(r.variant, r.detail)];
+        w.n += 1, w.ms += ms, w.fl += r.flops, w.ex += r.executed;
+    }
+    std::string out;
+    char line[320];
+    for (auto& kv : rows) {
+        snprintf(line, sizeof line, "%s\t%lld\t%.6f\t%.6e\t%.6e\n", kv.first.c_str(), (long long)kv.second.n, kv.second.ms, kv.second.fl, kv.second.ex);
+        out += line;
+    }
+    if (buf && cap > 0) {
+        const size_t nb = std::min<size_t>(out.size(), (size_t)cap - 1);
+        memcpy(buf, out.data(), nb);
+        buf[nb] = 0;
+    }
+    return (int)out.size() + 1;
 }
 
 extern "C" int dgmr_profile_collect2(double* total_ms, double* total_flops, double* executed_flops, int64_t* launches, int n) {
