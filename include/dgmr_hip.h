@@ -450,7 +450,10 @@ int dgmr_profile_collect_detail(char* buf, int cap);
 /* Dispatch override for tools/conv_bench.py's tile / split-K sweeps (process-wide; -1 = the library's own choice, which is
  * also the state at load): variant = index of a conv_fwd_dgrad<..> tile as listed by dgmr_profile_variant_name, ksplit = number
  * of K slabs (needs a workspace in the args), window = 0 never / 1 the register-staged LDS-window 3x3 kernel whenever the geometry allows / 2 likewise, with the experimental
- * 256-pixel tiles / 3 the LDS-DMA window kernel where eligible (what -1 picks, but also below the automatic size threshold);
+ * 256-pixel tiles / 3 the LDS-DMA window kernel where eligible (what -1 picks, but also below the automatic size threshold) /
+ * 4 its private-weight-slice variant / 5 its 16-column-block variant for <= 48 output channels / 6 (ABI 9) the LDS-DMA kernel with
+ * the block shapes of the wave-specialised kernel (the bit-for-bit reference of 7) / 7 (ABI 9) the wave-specialised persistent
+ * kernel (conv_win_ws.h: matrix waves + loader / epilogue waves in one workgroup per CU) wherever it applies, at any size;
  * wgrad_window = 0 never an LDS-window weight-gradient kernel / 1 the one-role kernel of round 2 (wgrad_win.h) wherever the geometry
  * allows / 2 the wave-specialised one (wgrad_ws.h: loader waves + matrix waves, ds_read_b64_tr_b16 fragments) with three matrix
  * waves (32x32x16 MFMAs, one filter row each) / 3 (= automatic) with four (16x16x32 MFMAs, one per SIMD; bf16x6: three). */

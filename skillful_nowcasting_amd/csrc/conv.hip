@@ -11,6 +11,7 @@
 // staged global -> registers -> LDS (double-buffered, one barrier per K step) so the next tile's HBM
 // latency hides under the current tile's MFMAs; LDS rows are padded to BK+4 floats, which makes the
 // ds_read_b128 fragment reads (lane = row, 4 consecutive k) conflict-free.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -582,6 +583,21 @@ __global__ void zero_n_kernel(float* p, int n) {
 
 }  // namespace
 
+static int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+// DGMR_WS_AUTO=0 in the environment: the library never picks the wave-specialised window kernel by itself (A/B runs of the whole step)
+static const bool g_ws_auto = []() {
+    const char* e = getenv("DGMR_WS_AUTO");
+    return !(e && e[0] == '0');
+}();
+
 // Which LDS-window 3x3 kernel (if any) takes a conv, and with which tiling: shared by the launch and by dgmr_conv_stats_rows.
 static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     const int64_t M64 = (int64_t)p.N * p.D * p.H * p.W;
@@ -612,7 +628,29 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     // 96- / 64-channel layers of the sampler at T x B maps (gpurun r2o), -10 ... -20 % on launches of a few hundred workgroups:
     // automatic only when the 256-pixel tiles still fill the chip four times over
     const int64_t big_wgs = (M64 / 256) * ((C + w->bnw - 1) / w->bnw) * (p.reserved0 ? 4 : 1);
-    w->big = !small8 && w->bnw != 128 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 && g_precision != 3 &&  // (bf16x6: 102 KB of LDS)
+    // Wave-specialised persistent kernel (conv_win_ws.h; dgmr_conv_tune window = 7 forces it wherever it applies, -1 takes it when
+    // every CU gets a run of items): 2-D, plain epilogue in its 16-byte form, at most ONE fused epilogue operand, 96 / 128-column
+    // blocks, 32-bit element offsets, and enough taps per item to hide the previous item's epilogue behind (ws_ups)
+    w->ws = false;
+    w->ws_ups = 1;
+    if (glds_ok && g_precision != 3 && p.KD == 1 && p.D == 1 && !p.upsample && p.epi_mode == DGMR_EPI_PLAIN && (p.reserved1 & 4) &&
+        !p.addend && !(p.residual && p.mask_src) && (w->bnw == 96 || w->bnw == 128) && M64 * (int64_t)C < (1ll << 32) &&
+        !(p.reserved1 & (3 | 64 | 128)) && (g_tune_window == 7 || g_tune_window < 0)) {
+        const int mode = p.reserved0;                       // 0 plain, 1 phase, 2 pooled
+        const int T = mode == 0 ? 9 : 4, D = mode == 0 ? 8 : 3, upsmax = mode == 1 ? 2 : 1;  // (ws_mode<> in conv_win_ws.h)
+        const int nchunks = (p.Cin + 31) / 32, nsl = (mode == 2 ? 4 * nchunks : nchunks) * T;
+        const int NU = w->bnw == 96 ? 12 : 16;              // epilogue units per loader wave and item
+        int ups = 0;
+        for (int u = 1; u <= upsmax && !ups; ++u)
+            if ((NU + u - 1) / u + D <= nsl - 1) ups = u;
+        const int64_t items = (M64 / 128) * ((C + w->bnw - 1) / w->bnw) * (mode == 1 ? 4 : 1);
+        const bool eop_ok = mode != 1 || (!p.residual && !p.mask_src);
+        if (ups && eop_ok && (g_tune_window == 7 || (g_ws_auto && items >= 4 * (int64_t)num_cus()))) {
+            w->ws = true;
+            w->ws_ups = ups;
+        }
+    }
+    w->big = !w->ws && !small8 && w->bnw != 128 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 && g_precision != 3 &&  // (bf16x6: 102 KB of LDS)
              (g_tune_window == 2 || (g_tune_window < 0 && big_wgs >= 2048));
     w->glds = glds_ok || w->big;
     const int TWv = 1 << w->tw_shift, THv = ((w->big ? 256 : 128) >> w->tw_shift) >> w->g_shift;
@@ -765,7 +803,17 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         const uint32_t detail = 1u | ((wp.bnw == 48 ? 0u : (wp.bnw == 64 ? 1u : (wp.bnw == 96 ? 2u : 3u))) << 4) | ((wp.big ? 1u : 0u) << 8) |
                                 ((uint32_t)p.reserved0 << 9) | ((p.KD == 3 ? 1u : 0u) << 11) | ((wgs < 1024 ? 1u : 0u) << 12) |
                                 ((wp.glds ? 0u : 1u) << 13) | ((p.epi_mode != DGMR_EPI_PLAIN ? 1u : 0u) << 14);
-        ProfScope ps(v, flops, s, (phases || p.reserved0 == 2) ? 16.0 / 36.0 : 1.0, detail);
+        ProfScope ps(v, flops, s, (phases || p.reserved0 == 2) ? 16.0 / 36.0 : 1.0, detail | ((wp.ws ? 1u : 0u) << 15));
+        if (wp.ws) {
+            const int64_t items = (int64_t)wp.grid_x * (phases ? 4 : 1) * ((p.Cout + wp.bnw - 1) / wp.bnw);
+            const int grid = (int)std::min<int64_t>(items, num_cus());
+            int rc;
+            if (g_precision == 1) rc = p.reserved0 == 0 ? dgmr_tu::launch_window_ws_ns3_m0(p, wp, grid, s) : (p.reserved0 == 1 ? dgmr_tu::launch_window_ws_ns3_m1(p, wp, grid, s) : dgmr_tu::launch_window_ws_ns3_m2(p, wp, grid, s));
+            else rc = p.reserved0 == 0 ? dgmr_tu::launch_window_ws_ns1_m0(p, wp, grid, s) : (p.reserved0 == 1 ? dgmr_tu::launch_window_ws_ns1_m1(p, wp, grid, s) : dgmr_tu::launch_window_ws_ns1_m2(p, wp, grid, s));
+            if (rc != 0) return -1;
+            DGMR_CHECK_LAUNCH();
+            return 0;
+        }
         if (DGMR_BY_NS(launch_window, p, wp, phases, g_tune_window, s) != 0) return -1;
         DGMR_CHECK_LAUNCH();
         return 0;
@@ -1076,7 +1124,7 @@ extern "C" int dgmr_set_precision(int mode) {
 extern "C" int dgmr_get_precision(void) { return g_precision; }
 
 extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window) {
-    DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 5 && wgrad_window >= -1 &&
+    DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 7 && wgrad_window >= -1 &&
                        wgrad_window <= 3,
                    "dgmr_conv_tune: variant %d ksplit %d window %d wgrad_window %d", variant, ksplit, window, wgrad_window);
     g_tune_variant = variant;

@@ -14,6 +14,8 @@ enum { V_F128x128 = 0, V_F64x64, V_F128x96, V_F128x64, V_F128x32, V_W128, V_W64,
 struct WinPlan {
     int tw_shift, g_shift, tiles_w, tiles_hw, bnw, grid_x;
     bool big, glds;  // 256-pixel tiles; LDS-DMA kernel (has the fused output statistics)
+    bool ws;         // the wave-specialised persistent kernel (conv_win_ws.h): 128-pixel tiles, one workgroup per CU
+    int ws_ups;      // its epilogue units per tap (1 | 2)
 };
 
 namespace dgmr_tu {
@@ -34,6 +36,16 @@ DGMR_TU_DECLARE(1)
 DGMR_TU_DECLARE(3)
 DGMR_TU_DECLARE(6)
 #undef DGMR_TU_DECLARE
+// wave-specialised window kernels (tu_ws.hip): one translation unit per (arithmetic, kernel mode: 0 plain, 1 phase, 2 pooled)
+#define DGMR_TU_DECLARE_WS(NS, MODE) \
+    DGMR_HIDDEN int launch_window_ws_ns##NS##_m##MODE(const dgmr_conv_args& p, const WinPlan& wp, int grid, hipStream_t s);
+DGMR_TU_DECLARE_WS(1, 0)
+DGMR_TU_DECLARE_WS(1, 1)
+DGMR_TU_DECLARE_WS(1, 2)
+DGMR_TU_DECLARE_WS(3, 0)
+DGMR_TU_DECLARE_WS(3, 1)
+DGMR_TU_DECLARE_WS(3, 2)
+#undef DGMR_TU_DECLARE_WS
 
 }  // namespace dgmr_tu
 

@@ -23,6 +23,10 @@ int DGMR_TU_CAT(launch_window_ns, DGMR_NS)(const dgmr_conv_args& p, const WinPla
         // weight stages by LDS-DMA (conv_win_glds.h; measured +4..17 % over the register-staged kernel below, bit-identical results)
         if (bnw == 48) DGMR_GLDS(48, 4, 1, 128, false, true);
 #if DGMR_NS != 6
+        // dgmr_conv_tune window = 6: the one-role kernels with the wave-specialised kernels' own block shapes (conv_win_ws.h: 16 x 16
+        // blocks at 96 columns, four row waves at 128) - the bit-for-bit reference of tests/test_gpu_kernels.py
+        else if (bnw == 96 && tune_window == 6) DGMR_GLDS(96, 4, 1, 128, false, true);
+        else if (bnw == 128 && tune_window == 6) DGMR_GLDS(128, 4, 1, 128);
         else if (bnw == 128 && tune_window == 4) DGMR_GLDS(128, 1, 4, 128, true);
         else if (bnw == 64 && tune_window == 4) DGMR_GLDS(64, 2, 2, 128, true);
 #endif
