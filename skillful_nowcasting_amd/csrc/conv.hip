@@ -592,10 +592,13 @@ static int num_cus() {
     }
     return n;
 }
-// DGMR_WS_AUTO=0 in the environment: the library never picks the wave-specialised window kernel by itself (A/B runs of the whole step)
+// DGMR_WS_AUTO=1 in the environment: the library picks the wave-specialised window kernel by itself wherever it applies and every
+// CU gets a run of items (A/B runs of the whole step).  Off by default: measured on the paper configuration's layers it is
+// bit-identical to the one-role kernels and faster on launches of at most one workgroup per CU (+10 ... +40 %), but 10 - 25 % slower
+// than the 256-pixel-tile one-role kernel on the big launches (profiles/r04_ws_*.log)
 static const bool g_ws_auto = []() {
     const char* e = getenv("DGMR_WS_AUTO");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
 }();
 
 // Which LDS-window 3x3 kernel (if any) takes a conv, and with which tiling: shared by the launch and by dgmr_conv_stats_rows.
@@ -635,7 +638,7 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     w->ws_ups = 1;
     if (glds_ok && g_precision != 3 && p.KD == 1 && p.D == 1 && !p.upsample && p.epi_mode == DGMR_EPI_PLAIN && (p.reserved1 & 4) &&
         !p.addend && !(p.residual && p.mask_src) && (w->bnw == 96 || w->bnw == 128) && M64 * (int64_t)C < (1ll << 32) &&
-        !(p.reserved1 & (3 | 64 | 128)) && (g_tune_window == 7 || g_tune_window < 0)) {
+        !(p.reserved1 & (64 | 128)) && (g_tune_window == 7 || g_tune_window < 0)) {
         const int mode = p.reserved0;                       // 0 plain, 1 phase, 2 pooled
         const int T = mode == 0 ? 9 : 4, D = mode == 0 ? 8 : 3, upsmax = mode == 1 ? 2 : 1;  // (ws_mode<> in conv_win_ws.h)
         const int nchunks = (p.Cin + 31) / 32, nsl = (mode == 2 ? 4 * nchunks : nchunks) * T;

@@ -28,8 +28,10 @@ bucket is known.  In later backwards a bucket is launched once the sequence has 
 bucket's last one (a kernel is issued at most two touches after its ``grad_buffer`` call — `MARGIN` = 4): the
 collective is enqueued behind the CURRENT state of the main and the weight-gradient streams, i.e. behind every
 kernel that writes the bucket, and overlaps whatever the backward pass still has to do for the layers in front.
-A sequence that deviates from the recording falls back to reducing the remaining buckets at ``sync()``; a touch
-of a bucket that has already been launched raises (never a silent wrong gradient).
+A sequence that deviates from the recording stops launching early and reduces the remaining buckets at ``sync()`` - IN THE RECORDED
+ORDER: every rank issues its collectives in one canonical order (the recorded launch order, cross-checked between the ranks when
+it is recorded), whether it launched a bucket during the backward pass or late, so equal-sized buckets can never be paired across
+ranks by accident.  A touch of a bucket that has already been launched raises (never a silent wrong gradient).
 
 The CPU branch of ``_scale`` exists only so the collective logic can be exercised under gloo in tests.
 """
@@ -192,7 +194,19 @@ class GradSync:
         self._locals = {}
         self._next = 0
         self._deviated = False
+        self._main_stream = torch.cuda.current_stream() if torch.cuda.is_available() and self.gen.flat.is_cuda else None
         ops.set_grad_touch_hook(self._touch)
+
+    def abort(self):
+        """Drop the touch hook and the pass state without exchanging anything (a backward pass that raised): whatever runs backward
+        next must not find this pass's hook.  Collectives already launched are waited for, so that no rank is left behind."""
+        from . import ops
+
+        ops.set_grad_touch_hook(None)
+        self._active = None
+        for work in self._launched.values():
+            work.wait()
+        self._launched = {}
 
     def _touch(self, p):
         which = self._active
@@ -223,11 +237,17 @@ class GradSync:
         if piece.is_cuda:
             from . import ops
 
+            # a touch may fire on the weight-gradient stream (grad_buffer() inside weight_grad()) or, with DGMR_BRANCH_STREAM=1, on the
+            # branch stream: order the collective behind the stream begin() was called on, the CURRENT one, the device's default
+            # stream and every side stream - whichever of them carries kernels that write this bucket
             main = torch.cuda.current_stream(piece.device)
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=piece.device)
             comm = self._comm_stream
             comm.wait_stream(main)
+            comm.wait_stream(torch.cuda.default_stream(piece.device))
+            if getattr(self, "_main_stream", None) is not None:
+                comm.wait_stream(self._main_stream)
             for st in ops.side_streams(piece.device):  # the weight-gradient kernels run there
                 comm.wait_stream(st)
             with torch.cuda.stream(comm):
@@ -256,7 +276,10 @@ class GradSync:
         ops.set_grad_touch_hook(None)
         self._active = None
         nb = self._nbuckets(fg)
-        for b in range(nb - 1, -1, -1):  # back to front: the order in which the optimiser's late buckets were completed
+        # ONE canonical order on every rank: the recorded launch order once there is one (a rank that stopped launching early - a
+        # deviation - continues exactly where the others went on), back to front before that (the recording pass itself)
+        canonical = ps.order if (ps.recorded is not None and self.overlap) else list(range(nb - 1, -1, -1))
+        for b in canonical:
             if b not in self._launched:
                 self._launch(fg, b, overlapped=False)
         for b, work in self._launched.items():
@@ -279,6 +302,16 @@ class GradSync:
                 last[b] = i
         ps.last_touch = last  # -1: a bucket nothing writes (dead parameters only): launchable from the start
         ps.order = sorted(range(nb), key=lambda b: last[b])
+        # the launch order IS the pairing of the collectives across ranks: it must be the same list everywhere
+        if self.world > 1:
+            h = 0
+            for b in ps.order:
+                h = (h * 1000003 + b + 1) % 2147483629
+            t = torch.tensor([h, -h], dtype=torch.int64, device=fg.flat.device if fg.flat.is_cuda else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+            if int(t[0]) != h or int(t[1]) != -h:
+                raise RuntimeError("the ranks recorded different gradient-bucket launch orders: the backward passes are not the same "
+                                   "static graph on every rank; run with overlap=False")
 
     def _verify_exchange(self, fg: FlatGrads):
         """check_exchange: the reduced bucket must equal the sum over ranks of what each rank held when it launched the bucket (fp32

@@ -239,8 +239,13 @@ class DGMR(
             discriminator_loss = self._disc_losses(images, future_images, predictions)
             if self.grad_sync is not None:
                 self.grad_sync.begin("d")  # gradient buckets are all-reduced as the backward pass completes them (ddp.py)
-            with ops.defer_side_join():
-                self.manual_backward(discriminator_loss)
+            try:
+                with ops.defer_side_join():
+                    self.manual_backward(discriminator_loss)
+            except BaseException:
+                if self.grad_sync is not None:
+                    self.grad_sync.abort()  # (no stale touch hook for whatever runs backward next)
+                raise
             d_step_pending = True
         ######################
         # Optimize Generator #
@@ -256,7 +261,12 @@ class DGMR(
             g_opt.zero_grad()
             if self.grad_sync is not None:
                 self.grad_sync.begin("g")
-            self.manual_backward(generator_loss)
+            try:
+                self.manual_backward(generator_loss)
+            except BaseException:
+                if self.grad_sync is not None:
+                    self.grad_sync.abort()
+                raise
             if self.grad_sync is not None:
                 self.grad_sync.sync("g")
             g_opt.step()
