@@ -273,6 +273,19 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_in_sync = bool((lo == hi).all().item())
+    pg_info = None
+    if world > 1:
+        # who is in the job: every rank reports (rank, device index, device name, PCI bus id); RCCL's version as torch reports it
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(dev),
+                "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        pg_info = {"backend": backend, "world_size_reported": dist.get_world_size(), "rccl_version": ver, "ranks_seen": seen,
+                   "grad_sync": dict(model.grad_sync.stats) if getattr(model, "grad_sync", None) is not None else None}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -418,7 +431,7 @@ def main():
         }
         if replicas_in_sync is not None:
             out["replicas_in_sync"] = replicas_in_sync  # parameter checksums agree bit for bit across the ranks after the timed steps
-            out["process_group"] = {"backend": backend, "world_size_reported": dist.get_world_size()}
+            out["process_group"] = pg_info
         if roofline:
             out["roofline"] = roofline
         if also:

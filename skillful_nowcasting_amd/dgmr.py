@@ -40,6 +40,21 @@ except Exception:  # pragma: no cover - depends on the environment
         def log_dict(self, metrics, *args, **kwargs):
             self.logged_metrics = metrics  # tensors are kept on device: no host sync in the step
 
+        @property
+        def logger(self):
+            """What `visualize_step` writes to (dgmr/dgmr.py:307: `self.logger.experiment[0].add_image(...)`).  Under Lightning this
+            is the Trainer's logger; without it, an in-memory recorder with the same `add_image(tag, img, global_step)` surface
+            (`model.logger.experiment[0].images`) unless the caller assigns a logger of their own (e.g. an object whose
+            `experiment` is `[torch.utils.tensorboard.SummaryWriter(...)]`)."""
+            lg = self.__dict__.get("_logger")
+            if lg is None:
+                lg = self.__dict__["_logger"] = MemoryImageLogger()
+            return lg
+
+        @logger.setter
+        def logger(self, value):
+            self.__dict__["_logger"] = value
+
         def manual_backward(self, loss):
             loss.backward()
 
@@ -54,7 +69,15 @@ except Exception:  # pragma: no cover - depends on the environment
             built from the stored hyper-parameters (keyword overrides win) and the state dict loaded into it.
             `weights_only=True` (default) unpickles tensors and plain containers only; a checkpoint that carries other Python
             objects needs `weights_only=False`, which executes whatever the pickle contains - only for files you trust."""
-            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=weights_only)
+            try:
+                ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=weights_only)
+            except Exception as e:  # pickle.UnpicklingError from the safe unpickler: Lightning's AttributeDict, callback / loop state
+                if weights_only and "weights_only" in str(e).lower() or type(e).__name__ == "UnpicklingError":
+                    raise RuntimeError(
+                        f"{checkpoint_path}: this checkpoint carries Python objects the safe unpickler refuses (older Lightning "
+                        "versions store `hyper_parameters` as an AttributeDict, some store callback state). If you trust the file, "
+                        f"load it with load_from_checkpoint(..., weights_only=False). Original error: {e}") from e
+                raise
             if "state_dict" not in ckpt:
                 raise KeyError(f"{checkpoint_path}: not a Lightning checkpoint (no 'state_dict' entry)")
             import inspect
@@ -65,6 +88,20 @@ except Exception:  # pragma: no cover - depends on the environment
             model = cls(**hp)
             model.load_state_dict(ckpt["state_dict"], strict=strict)
             return model
+
+
+class MemoryImageLogger:
+    """Stand-in for a Lightning logger whose `experiment[0]` is a TensorBoard SummaryWriter: keeps what `add_image` receives."""
+
+    class _Writer:
+        def __init__(self):
+            self.images = []  # (tag, [3, H, W] CPU tensor, global_step)
+
+        def add_image(self, tag, img_tensor, global_step=None, **kwargs):
+            self.images.append((tag, img_tensor.detach().cpu(), global_step))
+
+    def __init__(self):
+        self.experiment = [MemoryImageLogger._Writer()]
 
 
 def weight_fn(y, precip_weight_cap=24.0):

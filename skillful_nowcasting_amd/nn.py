@@ -197,7 +197,12 @@ def _export_hook(module, state_dict, prefix, local_metadata):
         copy = hit[1]() if hit is not None and hit[0]() is state_dict else None
         if copy is None:
             copy = t.detach().contiguous()
-            cache[name] = (weakref.ref(state_dict), weakref.ref(copy))
+            try:
+                cache[name] = (weakref.ref(state_dict), weakref.ref(copy))
+            except TypeError:
+                # a destination that cannot be weakly referenced (state_dict(destination={}): a plain dict): no per-call cache, the
+                # second name of a shared tensor gets its own copy - correct, merely not deduplicated
+                cache.pop(name, None)
         state_dict[key] = copy
 
 

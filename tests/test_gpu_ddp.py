@@ -136,3 +136,79 @@ def test_two_ranks_on_one_gpu_real_steps():
     assert err <= 2.1 * 2 * 2e-4, f"overlapped vs late exchange: parameters differ by {err:.3e}"
     assert cos >= 0.98 and 1.0 - cos <= 3.0 * (1.0 - cos0) + 1e-4, (cos, cos0)
     assert frac <= 3.0 * max(frac0, 0.02), (frac, frac0)
+
+
+def test_margin_covers_every_gradient_kernel(monkeypatch):
+    """`ddp.MARGIN` rests on one invariant: a kernel that writes `p.grad` is issued at most a few touches after the `grad_buffer(p)`
+    call that announced it (ops.py hands the destination to an argument struct first and touches the weight / 1-over-sigma parameters
+    of the same launch before it issues it).  Measured here on a real backward pass instead of assumed: every C-ABI call is logged
+    with its pointer arguments (plain integers and the pointer fields of argument structs), every touch with its parameter; for each
+    call that carries an address inside some parameter's gradient the distance - touches of OTHER parameters since that parameter's
+    own last touch - must stay <= MARGIN - 2 (two touches of head-room)."""
+    import bisect
+    import ctypes
+
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import _core, _head_ops, _layout_ops, _streams, ddp, ops
+
+    torch.manual_seed(3)
+    model = S.DGMR(**KW).to("cuda")
+    S.set_precision("mixed")
+    x, y = torch.rand(2, 4, 1, 128, 128, device="cuda"), torch.rand(2, 2, 1, 128, 128, device="cuda")
+    model.training_step((x, y), 0)  # gradients exist, optimiser state allocated
+    torch.cuda.synchronize()
+    params = [p for p in model.parameters() if p.grad is not None]
+    starts = sorted((p.grad.data_ptr(), p.grad.data_ptr() + p.grad.numel() * 4, i) for i, p in enumerate(params))
+    keys = [s[0] for s in starts]
+    index_of = {id(p): i for i, p in enumerate(params)}
+
+    def owner(ptr):
+        j = bisect.bisect_right(keys, ptr) - 1
+        return starts[j][2] if j >= 0 and starts[j][0] <= ptr < starts[j][1] else None
+
+    def pointers(args):
+        for a in args:
+            if isinstance(a, int):
+                yield a
+            elif isinstance(a, ctypes.c_void_p):
+                if a.value:
+                    yield a.value
+            elif hasattr(a, "_obj") and isinstance(a._obj, ctypes.Structure):  # ctypes.byref(struct)
+                for name, typ in a._obj._fields_:
+                    v = getattr(a._obj, name)
+                    if isinstance(v, int) and typ in (ctypes.c_void_p,) and v:
+                        yield v
+
+    touches, last_touch, worst = [0], {}, [0, ""]
+
+    def hook(p):
+        i = index_of.get(id(p))
+        touches[0] += 1
+        if i is not None:
+            last_touch[i] = touches[0]
+
+    real_call = ops.call
+
+    def logged(name, *args):
+        if name not in ("dgmr_adam",):
+            for ptr in pointers(args):
+                i = owner(ptr)
+                if i is not None and i in last_touch:
+                    d = touches[0] - last_touch[i]
+                    if d > worst[0]:
+                        worst[0], worst[1] = d, name
+        return real_call(name, *args)
+
+    for mod in (ops, _core, _head_ops, _layout_ops, _streams):
+        if hasattr(mod, "call"):
+            monkeypatch.setattr(mod, "call", logged)
+    ops.set_grad_touch_hook(hook)
+    try:
+        model.training_step((x, y), 1)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_grad_touch_hook(None)
+        S.set_precision("f32")
+    assert touches[0] > 100, touches
+    print(f"\ngradient kernels are issued at most {worst[0]} touches after their grad_buffer() call (worst: {worst[1]}); MARGIN = {ddp.MARGIN}")
+    assert worst[0] <= ddp.MARGIN - 2, f"{worst[1]} writes a gradient {worst[0]} touches after its grad_buffer(): raise ddp.MARGIN"

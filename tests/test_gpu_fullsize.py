@@ -354,6 +354,67 @@ def test_generator_forward_cfg5_512(setup):
         assert err <= 1e-3, f"cfg5 {precision}: generator forward rel err {err:.3e}"
 
 
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-3), ("bf16x3", 2e-3)])
+def test_generator_fwd_bwd_cfg5_512(precision, tol):
+    """BASELINE.json configs[4] (512 x 512): generator forward, MSE, BACKWARD at B = 1 against the oracle in float32 and float64 (round 4:
+    the 512 x 512 configuration had a forward check only, its backward was benched but unchecked).  Same 15 gradients and the same
+    float64-anchored band as the paper-configuration test above - the 128 x 128 ... 256 x 256 maps of this configuration put four times
+    the tiles through every window / weight-gradient kernel and twice the rows through the ConvGRU steps."""
+    import skillful_nowcasting_amd as S
+    from oracle import dgmr_oracle as O
+
+    kw = dict(forecast_steps=18, output_shape=512, latent_channels=768, context_channels=384, generation_steps=6)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.manual_seed(0)
+    model = S.DGMR(**kw)
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(3)
+    x = torch.rand(1, 4, 1, 512, 512)
+    y = torch.rand(1, 18, 1, 512, 512)
+    res = _CFG5_ORACLE.get("res")
+    if res is None:
+        res = {}
+        for dt in (torch.float32, torch.float64):
+            sd = {k[len("generator."):]: v.clone().to(dt) if v.is_floating_point() else v.clone() for k, v in sd_cpu.items()
+                  if k.startswith("generator.")}
+            with torch.no_grad():
+                sd["latent_stack.att_block.gamma"].fill_(0.3)
+            for k in G_GRAD_KEYS:
+                sd[k].requires_grad_(True)
+            torch.manual_seed(11)
+            z = O.draw_latent((8, 16, 16)).to(dt)
+            out = O.generator(sd, "", x.to(dt), z, 18, True)
+            loss = torch.nn.functional.mse_loss(out, y.to(dt))
+            loss.backward()
+            res[dt] = (loss.detach(), {k: sd[k].grad.clone() for k in G_GRAD_KEYS}, out.detach())
+        _CFG5_ORACLE["res"] = res
+    (l32, g32, o32), (l64, g64, o64) = res[torch.float32], res[torch.float64]
+    model = model.to("cuda")
+    with torch.no_grad():
+        model.generator.latent_stack.att_block.gamma.fill_(0.3)
+    S.ops.bump_weights_epoch()
+    model.train()
+    S.set_precision(precision)
+    try:
+        torch.manual_seed(11)
+        out = model(x.cuda())
+        loss = ((out - y.cuda()) ** 2).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        S.set_precision("f32")
+    named = dict(model.generator.named_parameters())
+    rows = {"output": (out.detach().cpu(), o32, o64), "loss": (loss.detach().cpu(), l32, l64)}
+    for k in G_GRAD_KEYS:
+        rows["grad " + k] = (named[k].grad.detach().cpu().float().reshape(g64[k].shape), g32[k], g64[k])
+    _band_check("generator fwd + MSE + bwd, cfg5 (512 x 512), B = 1", precision, tol, rows)
+    del model
+    torch.cuda.empty_cache()
+
+
+_CFG5_ORACLE = {}
+
+
 def test_cfg2_bf16_forward_and_step():
     """BASELINE.json configs[1]: T = 4, 384 / 192 channels, 256 x 256, plain `bf16` arithmetic (operands rounded to bf16, fp32
     accumulation).  bf16 carries 8 mantissa bits (2^-9 per operand), so the 1e-3 fp32 bound cannot apply to this mode: through ~60

@@ -20,6 +20,11 @@ What is compared (float32 oracle = the reference's arithmetic, float64 oracle = 
     relu flips by count with a one-channel allowance - the oracle's step cannot be re-run on the implementation's relu masks per
     arithmetic mode at ~8 min a run; the mask-aligned, allowance-free gradient check of the discriminator at this configuration is
     tests/test_gpu_fullsize.py::test_discriminator_fwd_bwd_paper_config);
+  * EVERY other generator gradient the oracle captured (round 4; 300-odd tensors): within max(5e-2, 10 x the float32 oracle's own
+    distance from float64) of the float64 oracle relative to the tensor's max, cosine >= 0.999 (the scalar att_block.gamma - one
+    cancelling sum - 1.5e-1): the grid-cell gradient is sign(mean - y) * w summed over pixels, a cancelling +-const sum in which one
+    relu flip moves deep-layer gradients by ~0.5 % (conditioning note; tests/test_training_step.py holds the small
+    golden to the same bounds); the table of all of them goes to the band log;
   * the discriminator gradients of the second pass (after one Adam update, whose +-lr steps on noise elements differ between any two
     fp32 implementations): cosine >= 0.9999 and 2e-2 of max;
   * every buffer after the step (u, v, BatchNorm running mean / var / num_batches_tracked): within max(floor, factor x the distance
@@ -76,7 +81,7 @@ def oracle_step(initial):
         losses = O.training_step(sd, x.to(dt), y.to(dt), HP, {"step": {}, "m": {}, "v": {}}, cap)
         keep = {k: g for k, g in cap["g_grads"].items() if k.startswith(G_LAST)}
         res[dt] = dict(losses=losses, backward_losses=cap["backward_losses"], d_grads=cap["d_grads"], g_last=keep,
-                       g_touched=set(cap["g_grads"]), buffers={k: v.detach().clone() for k, v in sd.items() if k.endswith(BUFFER_SUFFIXES)})
+                       g_all={k: g.detach().clone() for k, g in cap["g_grads"].items()}, g_touched=set(cap["g_grads"]), buffers={k: v.detach().clone() for k, v in sd.items() if k.endswith(BUFFER_SUFFIXES)})
         del cap
     return res
 
@@ -147,6 +152,31 @@ def test_training_step_paper_config_vs_oracle(initial, oracle_step, precision, t
     for k, g64 in r64["g_last"].items():
         rows["G " + k[len("generator."):]] = (g_grads[k].cpu().float().reshape(g64.shape), r32["g_last"][k], g64)
     band_check(f"training_step, paper config, B = {B}", precision, tol, rows, flips_row=True)
+    # ---- every other generator gradient (ill-conditioned: see the module docstring) ----
+    from conftest import _log_band
+
+    lines, bad_g, n_g = [], [], 0
+    for k, g64 in sorted(r64["g_all"].items()):
+        if k.startswith(G_LAST):
+            continue
+        got = g_grads[k].cpu().float().reshape(g64.shape)
+        scale = g64.abs().max().item()
+        if scale == 0.0:
+            assert got.abs().max().item() == 0.0, k
+            continue
+        e, c = rel_err(got, g64), cos_sim(got, g64)
+        band = rel_err(r32["g_all"][k], g64)
+        lim = 1.5e-1 if k.endswith("att_block.gamma") else max(5e-2, 10.0 * band)
+        ok = e <= lim and (c >= 0.999 or g64.numel() < 2)
+        lines.append(f"  {k[len('generator.'):]:70s} err {e:.2e}  fp32-oracle {band:.2e}  cos {c:.6f}  {'ok' if ok else 'FAIL'}")
+        n_g += 1
+        if not ok:
+            bad_g.append((k, e, band, c))
+    worst_g = max(lines, key=lambda l: float(l.split("err ")[1].split()[0]))
+    _log_band(f"training_step, paper config, B = {B} [{precision}] generator gradients (all {n_g} tensors below the last layer) against the float64 oracle:\n" + "\n".join(lines))
+    print(f"\nG gradients [{precision}]: {n_g} tensors, worst:{worst_g}")
+    assert n_g >= 100, n_g
+    assert not bad_g, f"{len(bad_g)} generator gradients beyond max(5e-2, 10 x fp32 band) / cosine 0.999: {sorted(bad_g, key=lambda t: -t[1])[:8]}"
     # ---- second discriminator pass (after one Adam update) ----
     worst = (0.0, 1.0, "")
     for k, g64 in r64["d_grads"][1].items():
@@ -181,4 +211,9 @@ def test_training_step_paper_config_vs_oracle(initial, oracle_step, precision, t
         n_buf += 1
         n_tight += err <= 1e-3
     print(f"buffers after the step [{precision}]: worst {worst[1]} at {worst[0]:.2e} of its max; {n_tight} of {n_buf} within 1e-3")
+    _log_band(f"training_step, paper config, B = {B} [{precision}] buffers after the step: worst {worst[1]} at {worst[0]:.2e} of its max; "
+              f"{n_tight} of {n_buf} within 1e-3 of the float64 oracle")
+    # the small golden holds buffers to 1e-3 (tests/test_training_step.py); here Adam's +-lr noise steps stand between two fp32
+    # implementations (module docstring), so the bound is a share: nearly all buffers must still be that close
+    assert n_tight >= (0.90 if precision == "mixed" else 0.95) * n_buf, f"only {n_tight} of {n_buf} buffers within 1e-3 of the float64 oracle"
     assert not bad, f"{len(bad)} buffers beyond max({floor:g}, {factor:g} x fp32 band) after the step: {sorted(bad, key=lambda t: -t[1])[:8]}"

@@ -288,3 +288,37 @@ def test_visualize_step_logs_the_reference_image_set():
     assert len(calls) == 12  # 4 input frames x (input, target, generated)
     assert calls[0] == ("train/Input_Image_Stack_Frame_0", (3, 8, 8), 5)
     assert {c[0] for c in calls} == {f"train/{n}_Frame_{i}" for n in ("Input_Image_Stack", "Target_Image", "Generated_Image") for i in range(4)}
+
+
+def test_default_logger_is_an_in_memory_recorder():
+    """Without Lightning `model.logger` exists (dgmr/dgmr.py:307 reads `self.logger.experiment[0]`) and records the images."""
+    model = S.DGMR(forecast_steps=4, output_shape=128, latent_channels=384, context_channels=192)
+    x, y, y_hat = torch.rand(1, 4, 1, 8, 8), torch.rand(1, 4, 1, 8, 8), torch.rand(1, 4, 1, 8, 8)
+    model.visualize_step(x, y, y_hat, 7, step="val")
+    imgs = model.logger.experiment[0].images
+    assert len(imgs) == 12 and imgs[0][0] == "val/Input_Image_Stack_Frame_0" and imgs[0][2] == 7
+    assert tuple(imgs[0][1].shape) == (3, 8, 8) and torch.equal(imgs[0][1][0], x[0, 0, 0])
+
+
+@pytest.mark.gpu
+def test_training_and_validation_step_with_visualize_on_gpu():
+    """visualize=True through a real step on the HIP path (dgmr/dgmr.py:213-218,285-290): the logging forward's output is what gets
+    drawn - 4 input-frame indices x (input, target, generated) per call, finite, the generated frame equal to an eval of the
+    same state is not expected (train-mode forward), so only shapes, tags, steps and the input / target pixels are pinned."""
+    torch.manual_seed(0)
+    model = S.DGMR(forecast_steps=4, output_shape=128, latent_channels=384, context_channels=192, generation_steps=2, visualize=True).to("cuda")
+    x, y = torch.rand(2, 4, 1, 128, 128, device="cuda"), torch.rand(2, 4, 1, 128, 128, device="cuda")
+    model.training_step((x, y), 0)
+    model.validation_step((x, y), 0)
+    torch.cuda.synchronize()
+    imgs = model.logger.experiment[0].images
+    assert len(imgs) == 24
+    tags = [t for t, _, _ in imgs]
+    assert tags[:3] == ["train/Input_Image_Stack_Frame_0", "train/Target_Image_Frame_0", "train/Generated_Image_Frame_0"]
+    assert tags[12] == "val/Input_Image_Stack_Frame_0"
+    assert all(step == 1 for _, _, step in imgs)  # global_iteration after the first training_step
+    for tag, img, _ in imgs:
+        assert tuple(img.shape) == (3, 128, 128) and torch.isfinite(img).all(), tag
+    assert torch.equal(imgs[0][1][0], x[0, 0, 0].cpu()) and torch.equal(imgs[1][1][0], y[0, 0, 0].cpu())
+    gen = imgs[2][1][0]
+    assert gen.abs().max().item() > 0 and not torch.equal(gen, imgs[14][1][0])  # a real forward; the val forward is another draw
