@@ -299,6 +299,10 @@ const char* const kVariantNames[V_COUNT] = {
 // dgmr_conv_tune(): -1 = automatic
 int g_tune_variant = -1, g_tune_ksplit = -1, g_tune_window = -1, g_tune_wgrad_window = -1;
 int g_debug_flags = 0;  // dgmr_debug_flags(): kernel-phase timing switches of tools/conv_bench.py, 0 in every product launch
+static const bool g_thin_auto = []() {  // DGMR_THIN_TILE=0: A/B switch for the 16-column tile of <= 16-channel outputs
+    const char* e = getenv("DGMR_THIN_TILE");
+    return !(e && e[0] == '0');
+}();
 bool g_m16_auto = true;  // 16-column blocks for <= 48 output channels: measured +14 ... +28 % on the 48-channel layers (tune window 3 = the 64-column tile)
 
 // WM x WN: wave grid of the f32 kernel (the bf16 kernels of the same tile: tu_gemm.hip)
@@ -622,6 +626,8 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     // <= 48 output channels in 16-column blocks (v_mfma_f32_16x16x32): three blocks instead of two 32-column ones, a quarter less
     // matrix work (LDS-DMA kernel, 128-pixel tiles)
     if (glds_ok && C <= 48 && C % 16 == 0 && (g_tune_window == 5 || (g_tune_window < 0 && g_m16_auto))) w->bnw = 48;
+    // <= 8 output channels (16-column blocks; the discriminators' first convs backwards: Cout = 4): 16-column tile
+    if (glds_ok && C <= 8 && C % 4 == 0 && (g_tune_window == 5 || g_tune_window < 0) && g_thin_auto) w->bnw = 16;  // (measured: 1.5 - 1.8 x at 4 and 8 channels, slower at 16)
     // few pixels, many channels (the ConvGRU steps on 8x8 / 16x16 maps: 6144 pixels x 384 channels): 128-column tiles would leave
     // half the CUs without a workgroup - 64-column tiles double the grid (measured 146 -> see profiles/README.md, us per step conv)
     if (g_tune_window < 0 && C % 64 == 0 && (M64 / 128) * ((C + w->bnw - 1) / w->bnw) * (p.reserved0 ? 4 : 1) < 256) w->bnw = 64;
@@ -803,7 +809,7 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     if (window_plan(p, &wp)) {
         const int v = wp.bnw == 128 ? V_WIN128 : (wp.bnw == 96 ? V_WIN96 : V_WIN64);
         const int64_t wgs = (int64_t)wp.grid_x * (phases ? 4 : 1) * ((p.Cout + wp.bnw - 1) / wp.bnw);
-        const uint32_t detail = 1u | ((wp.bnw == 48 ? 0u : (wp.bnw == 64 ? 1u : (wp.bnw == 96 ? 2u : 3u))) << 4) | ((wp.big ? 1u : 0u) << 8) |
+        const uint32_t detail = 1u | ((wp.bnw == 48 ? 0u : (wp.bnw == 64 ? 1u : (wp.bnw == 96 ? 2u : (wp.bnw == 128 ? 3u : 4u)))) << 4) | ((wp.big ? 1u : 0u) << 8) |
                                 ((uint32_t)p.reserved0 << 9) | ((p.KD == 3 ? 1u : 0u) << 11) | ((wgs < 1024 ? 1u : 0u) << 12) |
                                 ((wp.glds ? 0u : 1u) << 13) | ((p.epi_mode != DGMR_EPI_PLAIN ? 1u : 0u) << 14);
         ProfScope ps(v, flops, s, (phases || p.reserved0 == 2) ? 16.0 / 36.0 : 1.0, detail | ((wp.ws ? 1u : 0u) << 15));
@@ -1165,9 +1171,9 @@ static std::string prof_detail_name(int variant, uint32_t d) {
     const int kind = d & 15;
     const char* pr = prec[(d >> 28) & 3];
     if (kind == 1) {
-        static const int bn[] = {48, 64, 96, 128};
+        static const int bn[] = {48, 64, 96, 128, 16, 0, 0, 0};
         static const char* const mode[] = {"plain", "phase", "pooled", "phase4"};
-        snprintf(b, sizeof b, "win3x3<bn%d,%dpx>%s%s%s%s %s %s", bn[(d >> 4) & 3], (d >> 8) & 1 ? 256 : 128, (d >> 13) & 1 ? " reg-staged" : "",
+        snprintf(b, sizeof b, "win3x3<bn%d,%dpx>%s%s%s%s %s %s", bn[(d >> 4) & 7], (d >> 8) & 1 ? 256 : 128, (d >> 13) & 1 ? " reg-staged" : "",
                  (d >> 11) & 1 ? " 3d" : "", (d >> 14) & 1 ? " gru" : "", (d >> 15) & 1 ? " ws" : "", mode[(d >> 9) & 3], (d >> 12) & 1 ? "small(<1024wg)" : "big");
     } else if (kind == 2) {
         snprintf(b, sizeof b, "%s%s%s%s%s %s", kVariantNames[variant], (d >> 8) & 1 ? " splitk" : "", (d >> 9) & 1 ? " 1x1" : "",

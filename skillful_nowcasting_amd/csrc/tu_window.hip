@@ -16,12 +16,16 @@ int DGMR_TU_CAT(launch_window_ns, DGMR_NS)(const dgmr_conv_args& p, const WinPla
 #define DGMR_GLDS(BN_, WM_, WN_, ...) \
     hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, NS, __VA_ARGS__>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift)
     if (wp.big) {  // 256-pixel tiles (never with 128 columns: window_plan)
-        if (bnw == 96) DGMR_GLDS(96, 4, 1, 256);
+        if (bnw == 16) DGMR_GLDS(16, 4, 1, 256, false, true);
+        else if (bnw == 96) DGMR_GLDS(96, 4, 1, 256);
         else if (bnw == 48) DGMR_GLDS(48, 4, 1, 256, false, true);
         else DGMR_GLDS(64, 4, 1, 256);
     } else if (wp.glds) {
         // weight stages by LDS-DMA (conv_win_glds.h; measured +4..17 % over the register-staged kernel below, bit-identical results)
         if (bnw == 48) DGMR_GLDS(48, 4, 1, 128, false, true);
+        // <= 16 output channels (the data gradients towards the discriminators' 4-channel inputs, discriminators.py:113,189 backwards):
+        // ONE 16-column block per wave row instead of a 64-column tile that is 94 % padding
+        else if (bnw == 16) DGMR_GLDS(16, 4, 1, 128, false, true);
 #if DGMR_NS != 6
         // dgmr_conv_tune window = 6: the one-role kernels with the wave-specialised kernels' own block shapes (conv_win_ws.h: 16 x 16
         // blocks at 96 columns, four row waves at 128) - the bit-for-bit reference of tests/test_gpu_kernels.py

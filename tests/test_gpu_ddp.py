@@ -157,14 +157,17 @@ def test_margin_covers_every_gradient_kernel(monkeypatch):
     x, y = torch.rand(2, 4, 1, 128, 128, device="cuda"), torch.rand(2, 2, 1, 128, 128, device="cuda")
     model.training_step((x, y), 0)  # gradients exist, optimiser state allocated
     torch.cuda.synchronize()
-    params = [p for p in model.parameters() if p.grad is not None]
-    starts = sorted((p.grad.data_ptr(), p.grad.data_ptr() + p.grad.numel() * 4, i) for i, p in enumerate(params))
-    keys = [s[0] for s in starts]
+    params = [p for p in model.parameters() if p.requires_grad]
     index_of = {id(p): i for i, p in enumerate(params)}
+    # gradient tensors are dropped by zero_grad() and re-created by grad_buffer(): address ranges are taken at the touch and forgotten
+    # when the optimiser clears them (the freed memory is reused by activations right away)
+    ranges = {}  # parameter index -> (first byte, one past the last byte) of its gradient, for parameters touched in this pass
 
     def owner(ptr):
-        j = bisect.bisect_right(keys, ptr) - 1
-        return starts[j][2] if j >= 0 and starts[j][0] <= ptr < starts[j][1] else None
+        for i, (lo, hi) in ranges.items():
+            if lo <= ptr < hi:
+                return i
+        return None
 
     def pointers(args):
         for a in args:
@@ -186,6 +189,17 @@ def test_margin_covers_every_gradient_kernel(monkeypatch):
         touches[0] += 1
         if i is not None:
             last_touch[i] = touches[0]
+            ranges[i] = (p.grad.data_ptr(), p.grad.data_ptr() + p.grad.numel() * 4)
+
+    for opt in model.optimizers():
+        orig_zero = opt.zero_grad
+
+        def zero(*a, _orig=orig_zero, **k):
+            ranges.clear()
+            last_touch.clear()
+            return _orig(*a, **k)
+
+        monkeypatch.setattr(opt, "zero_grad", zero)
 
     real_call = ops.call
 

@@ -155,7 +155,13 @@ def test_training_step_paper_config_vs_oracle(initial, oracle_step, precision, t
     # ---- every other generator gradient (ill-conditioned: see the module docstring) ----
     from conftest import _log_band
 
-    lines, bad_g, n_g = [], [], 0
+    lines, bad_g, n_g, n_noise = [], [], 0, 0
+    # A conv bias that feeds (through linear shortcuts at most) straight into a train-mode BatchNorm has an EXACT gradient of zero:
+    # what any implementation holds there is its own rounding noise (the float32 oracle is >= 100 % away from the float64 oracle on
+    # exactly these tensors - 12 biases of the sampler).  They carry no signal to compare; what can be required is that the noise
+    # is noise: far below the size of the real gradients.
+    g_scale = max(g.abs().max().item() for k, g in r64["g_all"].items() if rel_err(r32["g_all"][k], g) < 0.5)
+    worst_e = (0.0, "")
     for k, g64 in sorted(r64["g_all"].items()):
         if k.startswith(G_LAST):
             continue
@@ -164,15 +170,27 @@ def test_training_step_paper_config_vs_oracle(initial, oracle_step, precision, t
         if scale == 0.0:
             assert got.abs().max().item() == 0.0, k
             continue
-        e, c = rel_err(got, g64), cos_sim(got, g64)
         band = rel_err(r32["g_all"][k], g64)
+        if band >= 0.5:
+            mag = got.abs().max().item()
+            ok = mag <= 1e-4 * g_scale
+            lines.append(f"  {k[len('generator.'):]:70s} exact gradient is zero: |hip| {mag:.2e}  |fp32 oracle| {r32['g_all'][k].abs().max().item():.2e}  "
+                         f"|fp64 oracle| {scale:.2e}  (largest real gradient {g_scale:.2e})  {'ok' if ok else 'FAIL'}")
+            n_noise += 1
+            if not ok:
+                bad_g.append((k, mag, band, 0.0))
+            continue
+        e, c = rel_err(got, g64), cos_sim(got, g64)
         lim = 1.5e-1 if k.endswith("att_block.gamma") else max(5e-2, 10.0 * band)
         ok = e <= lim and (c >= 0.999 or g64.numel() < 2)
         lines.append(f"  {k[len('generator.'):]:70s} err {e:.2e}  fp32-oracle {band:.2e}  cos {c:.6f}  {'ok' if ok else 'FAIL'}")
         n_g += 1
+        if e > worst_e[0]:
+            worst_e = (e, lines[-1])
         if not ok:
             bad_g.append((k, e, band, c))
-    worst_g = max(lines, key=lambda l: float(l.split("err ")[1].split()[0]))
+    worst_g = worst_e[1]
+    assert n_noise <= 16, n_noise
     _log_band(f"training_step, paper config, B = {B} [{precision}] generator gradients (all {n_g} tensors below the last layer) against the float64 oracle:\n" + "\n".join(lines))
     print(f"\nG gradients [{precision}]: {n_g} tensors, worst:{worst_g}")
     assert n_g >= 100, n_g
