@@ -299,16 +299,6 @@ const char* const kVariantNames[V_COUNT] = {
 // dgmr_conv_tune(): -1 = automatic
 int g_tune_variant = -1, g_tune_ksplit = -1, g_tune_window = -1, g_tune_wgrad_window = -1;
 int g_debug_flags = 0;  // dgmr_debug_flags(): kernel-phase timing switches of tools/conv_bench.py, 0 in every product launch
-// DGMR_STAGGER=1|2: start the second resident set of window-conv workgroups half a tile late (conv_win_glds.h); DGMR_STAGGER_PCT: the
-// delay in percent of one tile's matrix-pipe time (default 100)
-static const int g_stagger_mode = []() {
-    const char* e = getenv("DGMR_STAGGER");
-    return e ? atoi(e) & 3 : 0;
-}();
-static const int g_stagger_pct = []() {
-    const char* e = getenv("DGMR_STAGGER_PCT");
-    return e ? std::max(1, atoi(e)) : 100;
-}();
 static const bool g_thin_auto = []() {  // DGMR_THIN_TILE=0: A/B switch for the 16-column tile of <= 16-channel outputs
     const char* e = getenv("DGMR_THIN_TILE");
     return !(e && e[0] == '0');
@@ -833,19 +823,6 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
             DGMR_CHECK_LAUNCH();
             return 0;
         }
-        // co-resident workgroups out of phase (conv_win_glds.h): mode from dgmr_debug_flags bits 8 / 9 (experiment) or DGMR_STAGGER
-        {
-            const int mode = (g_debug_flags >> 8) & 3 ? (g_debug_flags >> 8) & 3 : g_stagger_mode;
-            const int64_t wgs_l = (int64_t)wp.grid_x * (phases ? 4 : 1) * ((p.Cout + wp.bnw - 1) / wp.bnw);
-            if (mode && wp.glds && wgs_l >= 4 * (int64_t)num_cus()) {
-                const int nchunks = (p.Cin + 31) / 32, taps = p.reserved0 == 0 ? 9 * p.KD : (p.reserved0 == 1 ? 4 : 16);
-                // matrix-pipe cycles of one tile at the full rate ~ half a tile's wall time with two workgroups sharing the pipe
-                const int64_t mf = (int64_t)nchunks * taps * ((wp.big ? 256 : 128) / 4 / 32) * ((wp.bnw + 31) / 32) * 2 * (g_precision == 1 ? 3 : (g_precision == 3 ? 6 : 1)) * 32;
-                const int units = (int)std::min<int64_t>(std::max<int64_t>(mf * g_stagger_pct / 100 / 8128, 1), 4000);
-                p.reserved1 |= mode << 8;
-                p.reserved2 = units | (num_cus() << 16);
-            }
-        }
         if (DGMR_BY_NS(launch_window, p, wp, phases, g_tune_window, s) != 0) return -1;
         DGMR_CHECK_LAUNCH();
         return 0;
@@ -1167,7 +1144,7 @@ extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_win
 }
 
 extern "C" int dgmr_debug_flags(int flags) {
-    DGMR_CHECK_ARG(flags >= 0 && flags <= 1023 && !(flags & 4), "dgmr_debug_flags: %d", flags);
+    DGMR_CHECK_ARG(flags >= 0 && flags <= 255 && !(flags & 4), "dgmr_debug_flags: %d", flags);
     g_debug_flags = flags;
     return 0;
 }

@@ -107,20 +107,6 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    // Stagger (set by the library for launches of >= 4 workgroups per CU, conv.hip): the workgroups that co-reside on a CU all start
-    // together and - equal work per tile - stay IN PHASE for the whole launch: both in their epilogue at the same time, both in
-    // their matrix loop at the same time.  The second resident set starts half a tile later; every later workgroup inherits the
-    // phase of the one whose slot it takes.  reserved2 = delay in units of s_sleep 127 (~8 k cycles) | CUs << 16; mode 1 delays the
-    // workgroups [CUs, 2 CUs), mode 2 the odd ones below 2 CUs (which of the two sets shares a CU is the dispatcher's business).
-    {
-        const int stag = (p.reserved1 >> 8) & 3;
-        if (stag) {
-            const int lin = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, ncu = p.reserved2 >> 16;
-            const bool late = stag == 1 ? (lin >= ncu && lin < 2 * ncu) : (lin < 2 * ncu && (lin & 1));
-            if (late)
-                for (int i = 0; i < (p.reserved2 & 0xffff); ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
     const int TW = 1 << tw_shift, TH = (BM >> tw_shift) >> g_shift;
     const int sub_shift = LOG_BM - g_shift;
     // phase mode: blockIdx.x = 4 x tiles.  The four phases of a tile read the same input halo: they get workgroup ids 8 apart, i.e.
