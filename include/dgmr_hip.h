@@ -428,6 +428,23 @@ int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_stride, const fl
  * each to float once; the kernel does the same (lerp for the first moment, as torch's foreach implementation). */
 int dgmr_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
               int step, void* stream);
+/* (ABI 9) All tensors of one optimiser (dgmr/dgmr.py:292-300: one Adam per network) in ONE launch.  descs: device array, one entry per
+ * tensor in ascending block0 order; block0 = first workgroup of the tensor when every tensor gets ceil(n / dgmr_adam_chunk())
+ * workgroups; step_size = lr / (1 - beta1^step) and bc2_sqrt = sqrt(1 - beta2^step) rounded from double by the caller, as dgmr_adam
+ * forms them (torch keeps one step counter per parameter: they travel per tensor).  Same arithmetic per element as dgmr_adam. */
+typedef struct dgmr_adam_desc {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+    int32_t block0;
+    float step_size;
+    float bc2_sqrt;
+    int32_t reserved;
+} dgmr_adam_desc;
+int dgmr_adam_chunk(void);
+int dgmr_adam_multi(const dgmr_adam_desc* descs, int n_tensors, int total_blocks, double beta1, double beta2, double eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py's roofline leg; not part of the reference's surface).  When enabled, every conv /

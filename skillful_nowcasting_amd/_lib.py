@@ -54,6 +54,23 @@ class SNDesc(Structure):
     ]
 
 
+class AdamDesc(Structure):
+    """Mirror of ``dgmr_adam_desc``."""
+
+    _fields_ = [("p", P), ("g", P), ("m", P), ("v", P), ("n", c_int64), ("block0", c_int32), ("step_size", c_float), ("bc2_sqrt", c_float),
+                ("reserved", c_int32)]
+
+
+def _adam_desc_dtype():
+    import numpy as np
+
+    return np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("block0", "<i4"), ("step_size", "<f4"),
+                     ("bc2_sqrt", "<f4"), ("reserved", "<i4")])
+
+
+ADAM_DESC_DTYPE = _adam_desc_dtype()  # the same 56 bytes as a numpy record (descriptor tables are filled on the host with numpy)
+assert ADAM_DESC_DTYPE.itemsize == 56
+
 i, f, L = c_int, c_float, c_int64
 # name -> argtypes (every function returns int except the two noted below); must match include/dgmr_hip.h
 SIGNATURES = {
@@ -105,6 +122,8 @@ SIGNATURES = {
     "dgmr_hinge_disc": [P, P, P, P, P, i, i, P],
     "dgmr_grid_cell_loss": [P, i, L, P, P, f, P, P, f, P, L, P],
     "dgmr_adam": [P, P, P, P, L, c_double, c_double, c_double, c_double, i, P],
+    "dgmr_adam_chunk": [],
+    "dgmr_adam_multi": [P, i, i, c_double, c_double, c_double, P],
     "dgmr_upsample_phase_weights": [P, P, i, i, P],
     "dgmr_pool2_phase_weights": [P, P, i, i, P],
     "dgmr_upsample_wgrad_sums": [P, P, i, i, i, i, P],

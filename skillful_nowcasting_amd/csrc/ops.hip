@@ -1066,6 +1066,31 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Every tensor of an optimiser in ONE launch: block b works on chunk (b - d.block0) of tensor d, found by bisection over the
+// descriptors' first blocks.  Same per-element arithmetic as adam_kernel (bit-identical updates).
+constexpr int ADAM_CHUNK = 4096;  // elements per block
+__global__ __launch_bounds__(256) void adam_multi_kernel(const dgmr_adam_desc* __restrict__ descs, int n_tensors, float w1, float beta2, float w2,
+                                                         float eps) {
+    int lo = 0, hi = n_tensors - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {  // last descriptor whose block0 <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const dgmr_adam_desc d = descs[lo];
+    const int64_t i0 = (int64_t)(b - d.block0) * ADAM_CHUNK, i1 = i0 + ADAM_CHUNK < d.n ? i0 + ADAM_CHUNK : d.n;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float gi = d.g[i], m0 = d.m[i];
+        const float diff = gi - m0;
+        const float mi = w1 < 0.5f ? fmaf(w1, diff, m0) : gi - diff * (1.f - w1);
+        const float vi = fmaf(w2 * gi, gi, beta2 * d.v[i]);
+        d.m[i] = mi;
+        d.v[i] = vi;
+        d.p[i] -= d.step_size * (mi / (sqrtf(vi) / d.bc2_sqrt + eps));
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -1755,6 +1780,17 @@ extern "C" int dgmr_adam(float* p, const float* g, float* m, float* v, int64_t n
     const double bc2 = 1.0 - std::pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
                        (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)std::sqrt(bc2));
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_adam_chunk(void) { return ADAM_CHUNK; }
+
+extern "C" int dgmr_adam_multi(const dgmr_adam_desc* descs, int n_tensors, int total_blocks, double beta1, double beta2, double eps,
+                               void* stream) {
+    DGMR_CHECK_ARG(descs && n_tensors > 0 && total_blocks > 0, "dgmr_adam_multi: bad args");
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(total_blocks), dim3(256), 0, ST, descs, n_tensors, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)eps);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

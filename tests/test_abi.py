@@ -57,7 +57,7 @@ def test_struct_layouts_match_header():
 
     src = open(HEADER).read()
     for cname, pyt in (("dgmr_conv_args", _lib.ConvArgs), ("dgmr_wgrad_args", _lib.WgradArgs),
-                       ("dgmr_sn_desc", _lib.SNDesc)):
+                       ("dgmr_sn_desc", _lib.SNDesc), ("dgmr_adam_desc", _lib.AdamDesc)):
         m = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S)
         if m is None and pyt is None:
             continue
@@ -72,6 +72,12 @@ def test_struct_layouts_match_header():
             for nm in names.split(","):
                 fields.append(nm.strip().lstrip("*").strip())
         assert fields == [f[0] for f in pyt._fields_], (cname, fields, [f[0] for f in pyt._fields_])
+    # the numpy record the optimiser fills on the host is the same 56 bytes, field for field
+    import ctypes
+
+    assert _lib.ADAM_DESC_DTYPE.itemsize == ctypes.sizeof(_lib.AdamDesc)
+    for name, _t in _lib.AdamDesc._fields_:
+        assert _lib.ADAM_DESC_DTYPE.fields[name][1] == getattr(_lib.AdamDesc, name).offset, name
 
 
 def test_argument_errors_are_reported_without_a_gpu(lib):

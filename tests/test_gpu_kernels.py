@@ -353,3 +353,67 @@ def test_upsampling_conv_weight_gradient_paths_agree(n, h, w, cin, cout, groups)
         for g, r, name in zip(got, ref, ("weight", "bias", "input")):
             err = float((g.double() - r.double()).abs().max()) / float(r.double().abs().max())
             assert err <= 1e-4, f"{what}: {name} gradient rel err {err:.2e}"
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the wave-specialised persistent window kernel (conv_win_ws.h, dgmr_conv_tune window = 7) and the 16-column tile
+# ------------------------------------------------------------------------------------------------------------------------------
+def _ws_cases():
+    import importlib.util
+    import os
+
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("ws_check", os.path.join(ROOT, "tools", "ws_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_wave_specialised_window_conv_is_bit_identical_to_the_one_role_kernel(prec):
+    """Every mode of conv3x3_ws_kernel (plain / phase / pooled; 96- and 128-column blocks; residual, half-resolution residual, relu
+    mask with and without BatchNorm affine; ragged item counts; 8- and 16-pixel-wide maps; Cin and Cout tails) against the one-role
+    LDS-DMA kernel with the same block shapes (window = 6): y bit for bit - the same MFMA sequence and the same epilogue
+    expressions per element - and the fused BatchNorm partial sums, which the loaders add in another order, to 1e-6 after folding
+    all rows in float64.  The library's own choice (window = -1: other tiles) differs by summation order only."""
+    import skillful_nowcasting_amd as S
+
+    ws = _ws_cases()
+    S.set_precision(prec)
+    try:
+        for case in ws.SMALL:
+            r = ws.run_case(case, prec)
+            assert r["nan"] == 0 and r["exact"], (case[0], r)
+            assert r["stats_rel"] < 1e-6, (case[0], r)
+            assert r["vs_lib"] < (2e-5 if prec == "bf16x3" else 2e-2), (case[0], r)
+    finally:
+        S.set_precision("f32")
+
+
+@pytest.mark.parametrize("n,d,h,w,cin,cout,kd", [(24, 1, 64, 64, 48, 4, 1), (4, 6, 32, 32, 48, 4, 3), (16, 1, 32, 32, 96, 8, 1)])
+def test_thin_output_tile_matches_the_other_window_tiles(tuned, n, d, h, w, cin, cout, kd):
+    """<= 8 output channels (the data gradients towards the discriminators' 4-channel inputs, 2-D and 3-D) through the 16-column window
+    tile (the library's choice) against the 64-column tile (window = 3) and the implicit-GEMM kernel (window = 0)."""
+    from skillful_nowcasting_amd import ops
+    from skillful_nowcasting_amd._lib import call
+
+    torch.manual_seed(5)
+    x = torch.randn(n * d * h * w * cin, device=DEV)
+    wt = torch.randn(cout * kd * 9 * cin, device=DEV) * 0.05
+    bias = torch.randn(cout, device=DEV)
+    scale = torch.full((1,), 0.7, device=DEV)
+    msk = torch.randn(n * d * h * w * cout, device=DEV)
+    wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
+    call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * kd * 9, cin, 0, 0, 2, 0, ops._stream())
+    ys = []
+    for win in (-1, 3, 0):
+        tuned(-1, -1, win, -1)
+        y = torch.full((n * d * h * w * cout,), float("nan"), device=DEV)
+        ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, d, h, w, cin, cout, kd, 3, 3, mask_src=msk, w_split=wsp)
+        torch.cuda.synchronize()
+        ys.append(y)
+    sc = ys[2].abs().max().item()
+    assert not torch.isnan(ys[0]).any()
+    assert (ys[0] - ys[1]).abs().max().item() <= 2e-6 * sc
+    assert (ys[0] - ys[2]).abs().max().item() <= 5e-6 * sc

@@ -275,3 +275,42 @@ def test_fused_adam_matches_torch_adam(betas):
         assert int(sa["step"]) == sb["step"]
         assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-7)
         assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_fused_adam_multi_tensor_equals_per_tensor_launches():
+    """`dgmr_adam_multi` (one launch per parameter group: a descriptor table filled on the host, workgroups mapped to tensors by
+    bisection) against one `dgmr_adam` launch per tensor: bit-identical parameters and moments over five steps - tensors shorter and
+    longer than a workgroup's chunk, a channels-last conv weight, and a parameter that gets no gradient in two of the steps (its step
+    counter - and so its bias corrections - lag behind the others')."""
+    from skillful_nowcasting_amd.optim import FusedAdam
+
+    torch.manual_seed(11)
+    shapes = [(3,), (4097,), (16, 8, 3, 3), (20000,), (1,), (129, 65)]
+
+    def make():
+        torch.manual_seed(12)
+        ps = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+        ps[2].data = ps[2].data.contiguous(memory_format=torch.channels_last)
+        return ps
+
+    pa, pb = make(), make()
+    oa, ob = FusedAdam(pa, lr=2e-3, betas=(0.0, 0.999)), FusedAdam(pb, lr=2e-3, betas=(0.0, 0.999))
+    oa.multi_tensor, ob.multi_tensor = True, False
+    for step in range(5):
+        torch.manual_seed(100 + step)
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 3 and step in (1, 2):
+                a.grad = b.grad = None
+                continue
+            g = torch.randn_like(a) * (10.0 ** (step % 3 - 1))
+            a.grad, b.grad = g.clone(memory_format=torch.preserve_format), g.clone(memory_format=torch.preserve_format)
+        oa.step()
+        ob.step()
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert torch.equal(a, b), (step, i)
+    for a, b in zip(pa, pb):
+        sa, sb = oa.state[a], ob.state[b]
+        assert sa["step"] == sb["step"] and torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+    assert oa.state[pa[3]]["step"] == 3
