@@ -72,6 +72,18 @@ __device__ __forceinline__ f32x4 quad_transpose(float a0, float a1, float a2, fl
     return (f32x4){a0, a1, a2, a3};
 }
 
+// Swizzle of the bare 64-byte LDS rows: logical 16-byte k-slot s of row r lives at slot s ^ lds_swz<M16>(r).
+//   32 x 32 blocks (fragment = row lane & 31, k-slot 2 kk + (lane >> 5)):  (r >> 2) & 3  - conflict-free for any first row.
+//   16 x 16 blocks (fragment = row lane & 15, k-slot lane >> 4): the four k-slots of a row group are read by ONE instruction, and
+//   gfx950's 16-lane ds_read_b128 groups ({0-3, 12-15, 20-27}, ...) mix rows 0-3 / 12-15 at one k-slot with rows 4-11 at the next:
+//   under (r >> 2) & 3 every group collides 2-way for 14 of 16 first rows (PMC, round 4: 44 % of the LDS cycles of an M16 kernel were
+//   bank conflicts, the 32 x 32 kernels have none).  2 * ((r >> 2) & 1) is conflict-free for every first row
+//   (tests/test_lds_layouts.py enumerates both).
+template <bool M16>
+__device__ __forceinline__ int lds_swz(int r) {
+    return M16 ? ((r >> 2) & 1) * 2 : (r >> 2) & 3;
+}
+
 // PRIV: every wave streams ITS OWN 32 x TN output-channel slice of the weights into a private double buffer and nothing but the
 // activation halo is shared: no barrier between taps (one pair per 32-channel chunk, when the halo is replaced), the waves of a
 // workgroup drift apart and the SIMDs interleave them freely - the per-tap barrier made every workgroup wait for its slowest SIMD
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
             u32x2 pl[NP];
             split_planes4<NP>(v, pl);
             if (pix < AMAX) {
-                uint32_t* dst = As + pix * ROW + ((((cq >> 1) ^ (pix >> 2)) & 3) << 2) + (cq & 1) * 2;
+                uint32_t* dst = As + pix * ROW + (((cq >> 1) ^ lds_swz<M16>(pix)) << 2) + (cq & 1) * 2;
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * AMAX * ROW) = pl[q];
             }
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
         const int u = min(tid + i * 256, BUNITS - 1);  // (lanes of a wave beyond the stage never issue: see dma_b)
         const int plane = PRIV ? i / (TN * 2) : u / (BN * 4);
         const int r = PRIV ? wn * TN * 32 + (i % (TN * 2)) * 16 + (lane >> 2) : (u >> 2) % BN;
-        const int ch = (((PRIV ? lane : u) ^ (r >> 2)) & 3) * 8;  // first channel (inside a chunk) of the logical k-slot held by physical slot u & 3
+        const int ch = (((PRIV ? lane : u) & 3) ^ lds_swz<M16>(r)) * 8;  // first channel (inside a chunk) of the logical k-slot held by physical slot u & 3
         const uint32_t row = (uint32_t)(plane * plane_stride) + (uint32_t)(ph * p.Cout + min(n0 + r, p.Cout - 1)) * (uint32_t)taps * p.Cin;
         b_off[i] = row + ch;
         b_tail[i] = row + (c_last + ch < p.Cin ? c_last + ch : 0);  // absolute channel: the tail's scalar base has no chunk offset
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
         }
     }
     const int kg = M16 ? lane >> 4 : lane >> 5;  // this lane's 16-byte k-slot inside a 16-channel step (M16: inside the 32-channel chunk)
-    const int bsw = (lane >> 2) & 3;  // swizzle of this lane's weight rows (row = MB j + (lane & (MB - 1)))
+    const int bsw = lds_swz<M16>(lane);  // swizzle of this lane's weight rows (row = MB j + (lane & (MB - 1)): block offsets are multiples of 16)
     const uint32_t* Bb0 = PRIV ? Bs + wid * WSLICE + (lane & 31) * ROW : Bs + (wn * TN * MB + (lane & (MB - 1))) * ROW;
     constexpr int BPLANE = PRIV ? TN * 32 : BN;  // rows between the hi and the lo plane of a stage
     // half: the chunk holds <= 16 real channels (Cin = 48, 144: the last chunk) - its second 16-channel step is all zeros, skipped
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
         for (int i = 0; i < TM; ++i) {
             const int pix = rowpix[i][dyi] + colpix[i][dxi];
             Ab[i] = As + pix * ROW;
-            asw[i] = (pix >> 2) & 3;
+            asw[i] = lds_swz<M16>(pix);
         }
         const uint32_t* Bb = Bb0 + stage * BSTAGE;
 #pragma unroll

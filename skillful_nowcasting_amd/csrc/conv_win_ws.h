@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * (4 * WN + 4)) void conv3x3_ws_kernel(const dgm
             rp0[i] = (q >> sub_shift) * HP + ((q >> tw_shift) & (TH - 1)) * HTw + (q & (TW - 1));
         }
         const int kg = M16 ? lane >> 4 : lane >> 5;
-        const int bsw = (lane >> 2) & 3;
+        const int bsw = lds_swz<M16>(lane);
         const uint32_t* Bb0 = Bs + (wn * TN * MB + (lane & (MB - 1))) * ROW;
         const bool tail16 = has_tail && (p.Cin & (CK - 1)) <= 16;
         auto mma = [&](int dyi, int dxi, int abuf, int stage, bool half) {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64 * (4 * WN + 4)) void conv3x3_ws_kernel(const dgm
             for (int i = 0; i < TM; ++i) {
                 const int pix = rp0[i] + dyi * HTw + dxi;
                 Ab[i] = As + abuf * ASIZE + pix * ROW;
-                asw[i] = (pix >> 2) & 3;
+                asw[i] = lds_swz<M16>(pix);
             }
             const uint32_t* Bb = Bb0 + stage * BSTAGE;
 #pragma unroll
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * (4 * WN + 4)) void conv3x3_ws_kernel(const dgm
                 const int u = min(tid + i * NMT, BUNITS - 1);
                 const int plane = u / (BN * 4);
                 const int r = (u >> 2) % BN;
-                const int ch = ((u ^ (r >> 2)) & 3) * 8;
+                const int ch = ((u & 3) ^ lds_swz<M16>(r)) * 8;
                 const uint32_t row = (uint32_t)(plane * plane_stride) + (uint32_t)(g.ph * p.Cout + min(g.n0 + r, p.Cout - 1)) * (uint32_t)taps_w * p.Cin;
                 b_off[i] = row + ch;
                 b_tail[i] = row + (c_last + ch < p.Cin ? c_last + ch : 0);
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * (4 * WN + 4)) void conv3x3_ws_kernel(const dgm
             u32x2 pl[NP];
             split_planes4<NP>(v, pl);
             if (pix < AMAX) {
-                uint32_t* dst = As + buf * ASIZE + pix * ROW + ((((cq >> 1) ^ (pix >> 2)) & 3) << 2) + (cq & 1) * 2;
+                uint32_t* dst = As + buf * ASIZE + pix * ROW + (((cq >> 1) ^ lds_swz<M16>(pix)) << 2) + (cq & 1) * 2;
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * AMAX * ROW) = pl[q];
             }

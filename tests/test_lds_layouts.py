@@ -48,6 +48,21 @@ def test_xor_swizzled_rows_of_the_lds_dma_kernel():
         assert sorted(s ^ ((r >> 2) & 3) for s in range(4)) == [0, 1, 2, 3]
 
 
+def test_16x16_block_fragments_need_their_own_swizzle():
+    """16 x 16 x 32 MFMA fragments (conv_win_glds.h / conv_win_ws.h, M16): row = lane & 15, k-slot = lane >> 4 - one instruction reads
+    all four k-slots of 16 rows.  Under the 32 x 32 kernels' swizzle (r >> 2) & 3 every 16-lane group collides 2-way for 14 of 16
+    first rows (measured: 44 % of an M16 kernel's LDS cycles were bank conflicts); lds_swz<true>(r) = 2 * ((r >> 2) & 1) is
+    conflict-free for every first row, weights (first row a multiple of 16) and activations (any first pixel) alike."""
+    old = lambda r: (r >> 2) & 3
+    new = lambda r: ((r >> 2) & 1) * 2
+    bad_old = sum(not conflict_free(lambda l: (start + (l & 15)) * 16 + (((l >> 4) ^ old(start + (l & 15))) << 2)) for start in range(16))
+    assert bad_old == 14
+    for start in range(0, 48):
+        assert conflict_free(lambda l: (start + (l & 15)) * 16 + (((l >> 4) ^ new(start + (l & 15))) << 2))
+    for r in range(96):
+        assert sorted(s ^ new(r) for s in range(4)) == [0, 1, 2, 3]
+
+
 def test_transposed_images_of_the_window_weight_gradient():
     # wgrad_win.h: [channel][pixel] images, 100 dwords per input channel (4 halo rows of 24 dwords + pad; or 6 rows of 16),
     # 36 dwords per output channel; fragment = channel (lane & 31), 8 pixels at a 16-byte aligned offset
