@@ -83,6 +83,12 @@ template <bool M16>
 __device__ __forceinline__ int lds_swz(int r) {
     return M16 ? ((r >> 2) & 1) * 2 : (r >> 2) & 3;
 }
+// Activation rows are swizzled by their halo COLUMN, not by their pixel index, and the halo rows of 16-pixel-wide tiles are 20 pixels
+// apart instead of 18: the 32 rows of a 32 x 32 block's fragment are then two tile rows whose columns line up modulo 4, and the
+// fragment reads are conflict-free for every tap shift (by pixel index they collided 2-way on every 16-wide map - PMC, round 4: 31 %
+// of the LDS cycles of the 128-column kernel on 16 x 16 maps - whatever the row stride; tests/test_lds_layouts.py enumerates
+// tile widths, strides and shifts).  8-pixel-wide tiles (two 8 x 8 images per tile) stay 2-way conflicted (3-way by pixel index).
+__host__ __device__ constexpr int halo_row_stride(int halo_cols) { return halo_cols == 18 ? 20 : halo_cols; }
 
 // PRIV: every wave streams ITS OWN 32 x TN output-channel slice of the weights into a private double buffer and nothing but the
 // activation halo is shared: no barrier between taps (one pair per 32-channel chunk, when the halo is replaced), the waves of a
@@ -91,7 +97,7 @@ __device__ __forceinline__ int lds_swz(int r) {
 // M16: the wave's tile is made of 16 x 16 blocks (v_mfma_f32_16x16x32_bf16: one instruction per 32-channel chunk and block) instead
 // of 32 x 32 ones: 48 output channels are three blocks - the 64-column tile spent a quarter of its matrix work on padding.
 template <int BN, int WM, int WN, int NS, int BM = 128, bool PRIV = false, bool M16 = false>
-__global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift,
+__global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || (M16 && BN >= 96)) ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift,
                                                                                           const int tiles_w, const int tiles_hw,
                                                                                           const int g_shift) {
     constexpr int CK = 32;
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
     constexpr int TM = BM / WM / MB, TN = BN / WN / MB;
     static_assert(!M16 || (!PRIV && BN % 16 == 0), "M16 tile");
     typedef float accv_t __attribute__((ext_vector_type(RPB)));
-    constexpr int AMAX = BM == 256 ? 10 * 34 : 6 * 34;  // halo pixels: 6 x 34 / 10 x 18 (BM 128), 10 x 34 / 18 x 18 (BM 256)
+    constexpr int AMAX = BM == 256 ? 10 * 34 : 6 * 34;  // halo pixels: 6 x 34 / 10 x 20 (BM 128: rows of 16-wide tiles 20 apart), 10 x 34 / 18 x 18 (BM 256)
     constexpr int APASS = (AMAX * 8 + 255) / 256;
     constexpr int BUNITS = BN * 4 * NP;  // 16-byte units of one weight stage
     // PRIV: a wave's slice is TN x 32 rows per plane = TN * 2 DMA instructions (16 rows each) per plane
@@ -150,7 +156,9 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
     const int us = p.upsample ? 1 : 0;
     const int Hs = p.H >> us, Ws = p.W >> us;
     const int oh = (h0 - 1) >> us, ow = (w0 - 1) >> us;
-    const int HTw = (TW >> us) + 2;
+    // (256-pixel tiles on 16-wide maps keep 18: 18 x 20 pixels would need a twelfth staging register set in a kernel that sits at 243
+    //  registers - and no layer of the step runs them: 16 x 16 maps carry 384 channels = the 128-column kernel, 128-pixel tiles)
+    const int HTw = BM == 128 ? halo_row_stride((TW >> us) + 2) : (TW >> us) + 2;
     const int HP = ((TH >> us) + 2) * HTw;
     const int npix = HP << g_shift;
     const int nchunks = (p.Cin + CK - 1) / CK;
@@ -160,6 +168,10 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
     const int cq = tid & 7;
     uint32_t a_goff[APASS];
     unsigned a_valid = 0;
+    // (the 256-pixel-tile kernels keep the pixel-index swizzle: they run 32-wide tiles, where it is conflict-free, and the dominant one has
+    //  no register to spare for anything else)
+    constexpr bool BYCOL = BM == 128;
+    unsigned a_swz = 0;  // 2 bits per item: lds_swz of the item's halo column
     // (pix / HP and prem / HTw by reciprocal multiplication: an integer division by a run-time divisor is ~35 VALU instructions, and
     //  the 2 x APASS of them were a third of a tile's set-up.  Exact: pix + 0.5 is at least 0.5 / HP = 1.5e-3 away from every multiple
     //  of HP in relative terms, the float error is 1e-6.)
@@ -175,6 +187,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
                     : pooled ? (((uint32_t)(n + sub) * 2 * Hs + 2 * ih) * 2 * Ws + 2 * iw) * p.Cin + cq * 4  // pixel (2 ih, 2 iw): plane (0, 0)
                              : (((uint32_t)(n + sub) * Hs + ih) * Ws + iw) * p.Cin + cq * 4;
         a_valid |= (ok ? 1u : 0u) << i;
+        a_swz |= (unsigned)lds_swz<M16>(BYCOL ? lc : pix) << (2 * i);
     }
     const float* pa_base = p.pre_a ? p.pre_a : p.x;
     const float* pb_base = p.pre_a ? p.pre_b : p.x;
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
             u32x2 pl[NP];
             split_planes4<NP>(v, pl);
             if (pix < AMAX) {
-                uint32_t* dst = As + pix * ROW + (((cq >> 1) ^ lds_swz<M16>(pix)) << 2) + (cq & 1) * 2;
+                uint32_t* dst = As + pix * ROW + (((cq >> 1) ^ (BYCOL ? (int)((a_swz >> (2 * i)) & 3) : lds_swz<M16>(pix))) << 2) + (cq & 1) * 2;
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * AMAX * ROW) = pl[q];
             }
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6) ? 
         for (int i = 0; i < TM; ++i) {
             const int pix = rowpix[i][dyi] + colpix[i][dxi];
             Ab[i] = As + pix * ROW;
-            asw[i] = lds_swz<M16>(pix);
+            asw[i] = lds_swz<M16>(BYCOL ? colpix[i][dxi] : pix);
         }
         const uint32_t* Bb = Bb0 + stage * BSTAGE;
 #pragma unroll

@@ -8,17 +8,23 @@
 //   * 4 x WN MATRIX waves (two per SIMD at WN = 2): LDS-DMA of the next tap's weights, fragment reads, MFMAs - nothing else.  At
 //     the last tap of an item they park the accumulators in LDS (lane-linear 16-byte stores) and start the next item at once.
 //   * 4 LOADER waves (one per SIMD): while chunk s is multiplied they write the halo of chunk s + 1 into the other A buffer - from
-//     registers filled one whole step earlier (two register sets: the HBM latency has a step to pass) - and run the EPILOGUE of the
-//     PREVIOUS item out of the parked accumulators: its fused operand (residual or relu-mask source) arrives through a small ring
-//     of registers loaded D taps ahead, per-column constants through a parameter block in LDS, so that no loader instruction
-//     ever waits for a load it has just issued (every load is unconditional on a clamped address: exact s_waitcnt counts, the
-//     lesson of wgrad_ws.h).
+//     registers loaded earlier (nine-tap steps: one register set, loaded at the first tap and stored from the third on; four-tap
+//     steps: two sets, each loaded a whole step ahead) - and run the EPILOGUE of the PREVIOUS item out of the parked accumulators,
+//     in the accumulators' own layout (lane = output channel: per-column constants are one value per lane, the BatchNorm sums are
+//     in-lane adds plus one or two lane exchanges; only the result is transposed across the quad for the 16-byte store).  Its fused
+//     operand (residual or relu-mask source) arrives through a small ring of registers loaded D taps ahead, per-column constants
+//     through a parameter block in LDS, so that no loader instruction waits for a load it has just issued (every load is
+//     unconditional on a clamped address and goes through an explicit global address space - a pointer SELECTED among kernel
+//     arguments turns into flat_load, which is waited for with vmcnt(0): exact s_waitcnt counts, the lesson of wgrad_ws.h).
 //   * The hardware has ONE barrier per workgroup, and a weight stage shared by the matrix waves needs one per tap: all waves meet
 //     at every tap.  The loaders' work is therefore cut into per-tap slices (a few halo items, UPS epilogue units, one ring load);
 //     both roles are disjoint programs with the same loop skeleton and so the same barrier count by construction.
-// Arithmetic per output element is the glds kernel's (same MFMA sequence, same epilogue expressions, same statistics tree):
-// results are bit-identical to conv3x3_glds_kernel<BN, 4, 1, NS, 128, false, M16> (tests/test_gpu_kernels.py).
+// Arithmetic per output element is the glds kernel's (same MFMA sequence, same epilogue expressions): y is bit-identical to
+// conv3x3_glds_kernel<BN, 4, 1, NS, 128, false, M16> (dgmr_conv_tune window = 6; tests/test_gpu_kernels.py, tools/ws_check.py); the
+// BatchNorm partial sums are added in another order (1e-8 apart).
 // Scope: 2-D 3x3 (plain, phase, pooled modes), epi_mode PLAIN with the 16-byte epilogue, at most one fused epilogue operand.
+// Status (round 4): correct, faster than the one-role kernels on launches of at most one workgroup per CU, 10 - 25 %
+// slower than the 256-pixel-tile one-role kernel on the big launches - opt-in (DGMR_WS_AUTO=1 / dgmr_conv_tune window = 7).
 #pragma once
 #include "conv_win_glds.h"
 
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(64 * (4 * WN + 4)) void conv3x3_ws_kernel(const dgm
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int TW = 1 << tw_shift, TH = (BM >> tw_shift) >> g_shift;
     const int sub_shift = LOG_BM - g_shift;
-    const int HTw = TW + 2, HP = (TH + 2) * HTw, npix = HP << g_shift;
+    const int HTw = halo_row_stride(TW + 2), HP = (TH + 2) * HTw, npix = HP << g_shift;  // (rows of 16-wide tiles 20 apart: conv_win_glds.h)
     const int nchunks = (p.Cin + CK - 1) / CK;
     const int spi = MODE == 2 ? 4 * nchunks : nchunks;     // steps per item
     const int nsl = spi * T;                               // slices (= barriers) per item
@@ -122,11 +128,12 @@ __global__ __launch_bounds__(64 * (4 * WN + 4)) void conv3x3_ws_kernel(const dgm
 #pragma unroll
                 for (int r = 0; r < RPB; ++r) acc[i][j][r] = 0.f;
         // halo pixel of this lane's rows under tap (dy, dx) = rp0 + dy * HTw + dx  (no upsampling here: the window is linear)
-        int rp0[TM];
+        int rp0[TM], cp0[TM];  // (cp0: the halo column under tap dx = 0 - what the activation rows are swizzled by)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int q = wm * TM * MB + i * MB + (lane & (MB - 1));
-            rp0[i] = (q >> sub_shift) * HP + ((q >> tw_shift) & (TH - 1)) * HTw + (q & (TW - 1));
+            cp0[i] = q & (TW - 1);
+            rp0[i] = (q >> sub_shift) * HP + ((q >> tw_shift) & (TH - 1)) * HTw + cp0[i];
         }
         const int kg = M16 ? lane >> 4 : lane >> 5;
         const int bsw = lds_swz<M16>(lane);
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(64 * (4 * WN + 4)) void conv3x3_ws_kernel(const dgm
             for (int i = 0; i < TM; ++i) {
                 const int pix = rp0[i] + dyi * HTw + dxi;
                 Ab[i] = As + abuf * ASIZE + pix * ROW;
-                asw[i] = lds_swz<M16>(pix);
+                asw[i] = lds_swz<M16>(cp0[i] + dxi);
             }
             const uint32_t* Bb = Bb0 + stage * BSTAGE;
 #pragma unroll
@@ -272,6 +279,14 @@ __global__ __launch_bounds__(64 * (4 * WN + 4)) void conv3x3_ws_kernel(const dgm
     uint32_t a_goff[APASS];
     unsigned a_valid = 0;
     uint32_t f_grp = 0;
+    unsigned a_swz = 0;  // 2 bits per halo item of this thread: lds_swz of its halo column (the same for every tile)
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+        const int pix = (lt >> 3) + i * 32;
+        const int sub = (int)(((float)pix + 0.5f) * inv_hp), prem = pix - sub * HP;
+        const int lr = (int)(((float)prem + 0.5f) * inv_htw), lc = prem - lr * HTw;
+        a_swz |= (unsigned)lds_swz<M16>(lc) << (2 * i);
+    }
     int f_rel = 0, f_step = 0, f_chunk = 0, f_pl = 0;
     auto f_setup = [&](int rel) {
         const WsGeom g = decode(item0 + rel);
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(64 * (4 * WN + 4)) void conv3x3_ws_kernel(const dgm
             u32x2 pl[NP];
             split_planes4<NP>(v, pl);
             if (pix < AMAX) {
-                uint32_t* dst = As + buf * ASIZE + pix * ROW + (((cq >> 1) ^ lds_swz<M16>(pix)) << 2) + (cq & 1) * 2;
+                uint32_t* dst = As + buf * ASIZE + pix * ROW + (((cq >> 1) ^ ((a_swz >> (2 * i)) & 3)) << 2) + (cq & 1) * 2;
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(dst + q * AMAX * ROW) = pl[q];
             }

@@ -48,6 +48,40 @@ def test_xor_swizzled_rows_of_the_lds_dma_kernel():
         assert sorted(s ^ ((r >> 2) & 3) for s in range(4)) == [0, 1, 2, 3]
 
 
+def _halo_fragment_conflict_free(tw, stride, m16, swz):
+    """Fragment reads of the activation halo: lane -> tile pixel q = lane & 31 (or & 15), halo row r0 + q // tw, halo column
+    c0 + q % tw, pixel = row * stride + column; k-slot as the block shape reads it; swizzle by `swz(row, column, pixel)`."""
+    for r0 in range(0, 12):
+        for c0 in range(0, 3):  # tap shifts dx = 0 .. 2 (tile origins are multiples of the tile width)
+            for c16 in ((0, 16) if (m16 and tw == 32) else (0,)):
+                for kk in ((0,) if m16 else (0, 1)):
+                    def addr(l):
+                        q = (l & 15) if m16 else (l & 31)
+                        r, c = r0 + q // tw, c0 + c16 + q % tw
+                        pix = r * stride + c
+                        ks = (l >> 4) if m16 else kk * 2 + (l >> 5)
+                        return pix * 16 + ((ks ^ swz(r, c, pix)) << 2)
+                    if not conflict_free(addr):
+                        return False
+    return True
+
+
+def test_activation_rows_are_swizzled_by_halo_column():
+    """conv_win_glds.h / conv_win_ws.h (round 4): activation rows swizzled by their halo COLUMN, halo rows of 16-wide tiles 20 pixels
+    apart (halo_row_stride).  Conflict-free for 32- and 16-pixel-wide tiles, 32 x 32 and 16 x 16 blocks, every tap shift and wave
+    origin - where the pixel-index swizzle collided 2-way on every 16-wide map for 32 x 32 blocks, at any stride."""
+    by_col_32 = lambda r, c, p: (c >> 2) & 3
+    by_col_16 = lambda r, c, p: ((c >> 2) & 1) * 2
+    by_pix_32 = lambda r, c, p: (p >> 2) & 3
+    for tw, stride in ((32, 34), (16, 20)):
+        assert _halo_fragment_conflict_free(tw, stride, False, by_col_32), (tw, stride)
+        assert _halo_fragment_conflict_free(tw, stride, True, by_col_16), (tw, stride)
+    assert _halo_fragment_conflict_free(32, 34, False, by_pix_32)          # what the 32-wide tiles had all along
+    for stride in range(18, 26):                                           # ... and what no stride could repair on 16-wide maps
+        assert not _halo_fragment_conflict_free(16, stride, False, by_pix_32)
+    assert not _halo_fragment_conflict_free(16, 18, False, by_col_32)      # the column swizzle needs the 20-pixel stride
+
+
 def test_16x16_block_fragments_need_their_own_swizzle():
     """16 x 16 x 32 MFMA fragments (conv_win_glds.h / conv_win_ws.h, M16): row = lane & 15, k-slot = lane >> 4 - one instruction reads
     all four k-slots of 16 rows.  Under the 32 x 32 kernels' swizzle (r >> 2) & 3 every 16-lane group collides 2-way for 14 of 16
