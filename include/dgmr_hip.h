@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGMR_ABI_VERSION 9
+#define DGMR_ABI_VERSION 10
 
 int dgmr_abi_version(void);
 const char* dgmr_last_error(void);
@@ -101,7 +101,11 @@ typedef struct dgmr_conv_args {
     int32_t pool2;           /* 1: y = 2x2 sum pool of the conv, [N][H/2][W/2][Cout] (H, W stay the conv's map; mask_src / stats_out refer to
                                 the pooled output) - the data gradient of an upsampling conv (common.py:142,148 backwards) without
                                 writing the full-resolution gradient.  Needs w_phase = dgmr_pool2_phase_weights + dgmr_split_weights
-                                ([2][Cout][16][Cin]) and a conv the window kernel takes: ask dgmr_conv_pool2_supported. */
+                                ([2][Cout][16][Cin]) and a conv the window kernel takes: ask dgmr_conv_pool2_supported.
+                                ABI 10: also the FORWARD of a DBlock's last conv + AvgPool (common.py:233-237; tap sums x 0.25): `residual`
+                                is then [N][H/2][W/2][Cout]; and 3x3x3 convs (KD = 3, D > 1), plane by plane, w_phase =
+                                [2][Cout][3 * 16][Cin] (dgmr_pool2_phase_weights per depth tap): y = [N][D][H/2][W/2][Cout], the 2 x 2
+                                spatial half of AvgPool3d - dgmr_pool_depth2 finishes it. */
     int32_t reserved1;
     /* -- ABI 8 -- DGMR_EPI_GRU_GATES2: the ConvGRU's read AND update gate convs in one launch (ConvGRU.py:69-76: both convolve the same
        cat[x, h]); see the define below */
@@ -332,6 +336,10 @@ int dgmr_pool_fwd(const float* x, const float* addend, float* y, int N, int D, i
                   const float* mask_src, const float* mask_a, const float* mask_b, int mask_group, void* stream);
 /* dx[N][D][H][W][C] = dy[n][d/pd][h/2][w/2][c] * scale  (scale = 1/window for avg-pool backward). */
 int dgmr_pool_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, int pd, float scale, void* stream);
+/* y[N][D/2][plane] = (x[n][2j] + x[n][2j+1]) / 2 (+ addend): the depth half of nn.AvgPool3d(2) (common.py:189) over planes of `plane`
+ * floats (H/2 * W/2 * C), when the 2 x 2 spatial half already rode in the 3x3x3 conv that produced x (dgmr_conv_args.pool2).  A last
+ * odd plane of x is dropped, like AvgPool3d does. */
+int dgmr_pool_depth2(const float* x, const float* addend, float* y, int N, int D, int64_t plane, void* stream);
 /* frames [B][T][C][H][W] (reference layout) -> channels-last space-to-depth tiles.
  * out[(b*F+f)][H/(2p)][W/(2p)][4C] with channel (c*4 + dy*2 + dx) (PixelUnshuffle(2) order), frame = idx[f],
  * p = pool ? 2 : 1 (AvgPool2d(2) first).  idx == NULL -> frames 0..F-1.  out_frame_major: 1 -> row (f*B+b).

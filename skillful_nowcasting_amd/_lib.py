@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdgmr_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 P = c_void_p  # every device pointer and the stream travel as void*
 
@@ -96,6 +96,7 @@ SIGNATURES = {
     "dgmr_affine": [P, P, P, P, i, L, i, i, P],
     "dgmr_pool_fwd": [P, P, P, i, i, i, i, i, i, f, P, P, P, i, P],
     "dgmr_pool_bwd": [P, P, i, i, i, i, i, i, f, P],
+    "dgmr_pool_depth2": [P, P, P, i, i, L, P],
     "dgmr_frames_s2d": [P, P, P, i, i, i, i, i, i, i, i, i, P],
     "dgmr_frames_s2d_bwd": [P, P, P, i, i, i, i, i, i, i, i, i, P],
     "dgmr_d2s_frames": [P, P, i, i, i, i, i, i, P],

@@ -97,16 +97,17 @@ class DBlock(torch.nn.Module):
         ops.CallLayout when the groups are not in call order."""
         kw = dict(calls=calls, layout=layout)
         if self.input_channels != self.output_channels:
-            x1 = self.conv_1x1(x, **kw)
-            if not self.keep_same_output:
-                x1 = ops.avg_pool_add(x1, None, self._pd)
+            # shortcut: pool(conv1x1(x)) == conv1x1(pool(x)) (a 1x1 conv acts per pixel, the bias is a constant, pooling is linear),
+            # so the 1x1 conv runs on the pooled map: 4x (3-D: 8x) fewer rows, and the pooling pass reads the narrow input
+            # instead of the wide output (the reference: dgmr/common.py:222-226; differs by fp32 reassociation only)
+            x1 = self.conv_1x1(x if self.keep_same_output else ops.avg_pool_add(x, None, self._pd), **kw)
         else:
             x1 = x
         h = self.first_conv_3x3(x, pre_relu=self.first_relu, **kw)
         if self.keep_same_output:
             return self.last_conv_3x3(h, pre_relu=True, residual=x1, **kw)
-        h = self.last_conv_3x3(h, pre_relu=True, **kw)
-        return ops.avg_pool_add(h, x1, self._pd)
+        # last conv + pooling + shortcut in one operator (bf16 modes: "3x3 conv, then 2x2 average" as a 4x4 stride-2 pass, ops.ConvFn)
+        return self.last_conv_3x3(h, pre_relu=True, residual=x1, pool_out=True, **kw)
 
 
 class LBlock(torch.nn.Module):

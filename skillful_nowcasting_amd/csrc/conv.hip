@@ -653,7 +653,7 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
         for (int u = 1; u <= upsmax && !ups; ++u)
             if ((NU + u - 1) / u + D <= nsl - 1) ups = u;
         const int64_t items = (M64 / 128) * ((C + w->bnw - 1) / w->bnw) * (mode == 1 ? 4 : 1);
-        const bool eop_ok = mode != 1 || (!p.residual && !p.mask_src);
+        const bool eop_ok = (mode != 1 || (!p.residual && !p.mask_src)) && !(mode == 2 && p.residual);
         if (ups && eop_ok && (g_tune_window == 7 || (g_ws_auto && items >= 4 * (int64_t)num_cus()))) {
             w->ws = true;
             w->ws_ups = ups;
@@ -690,9 +690,11 @@ static bool phase_plan(dgmr_conv_args& p, WinPlan* w) {
 
 // 3x3 conv followed by a 2x2 sum pool (pool2: the data gradient of an upsampling conv) as ONE pass of the window kernel over the four
 // pixel-parity planes of the input with the 2x2 tap sums of w_phase; p then describes the pooled (output) map, reserved0 = 2.
+// (round 4: also the FORWARD of a DBlock's last conv + AvgPool - a residual at the pooled resolution rides in the epilogue - and 3x3x3
+//  convs, plane by plane: w_phase then holds 16 tap sums per depth tap and the pool is the 2 x 2 spatial part of AvgPool3d)
 static bool pooled_plan(dgmr_conv_args& p, WinPlan* w) {
-    if (!(p.pool2 && !p.upsample && p.w_phase && g_precision != 0 && p.KD == 1 && p.D == 1 && p.KH == 3 && p.KW == 3 &&
-          p.epi_mode == DGMR_EPI_PLAIN && !p.addend && !p.residual && p.H % 2 == 0 && p.W % 2 == 0))
+    if (!(p.pool2 && !p.upsample && p.w_phase && g_precision != 0 && ((p.KD == 1 && p.D == 1) || (p.KD == 3 && p.D > 1)) && p.KH == 3 &&
+          p.KW == 3 && p.epi_mode == DGMR_EPI_PLAIN && !p.addend && !p.residual_up && p.H % 2 == 0 && p.W % 2 == 0))
         return false;
     dgmr_conv_args q = p;
     q.H = p.H / 2;

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
     const int HP = ((TH >> us) + 2) * HTw;
     const int npix = HP << g_shift;
     const int nchunks = (p.Cin + CK - 1) / CK;
-    const int taps = phase ? 4 : (pooled ? 16 : 9 * KD);
+    const int taps = phase ? 4 : (pooled ? 16 * KD : 9 * KD);
 
     // ---- activation halo (registers -> prologue -> split -> swizzled ds_write), as conv3x3_win_kernel ----
     const int cq = tid & 7;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
     const float* pa_base = p.pre_a ? p.pre_a : p.x;
     const float* pb_base = p.pre_a ? p.pre_b : p.x;
     const uint32_t grp_off = (uint32_t)(smp / p.pre_group) * p.Cin;
-    const uint32_t plane_elems = (uint32_t)Hs * Ws * p.Cin;
+    const uint32_t plane_elems = (uint32_t)Hs * Ws * p.Cin * (pooled ? 4u : 1u);  // one depth plane of the input (pooled: at full resolution)
 
     // measurement switches (dgmr_debug_flags, tools/conv_bench.py --dbg=): 1 = return before the epilogue, 2 = stage only the first halo -
     // the MFMA loop then runs on stale LDS contents; results are garbage, only the timing is meaningful.  0 in every product launch.
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
     };
 
     // ---- weights: stage s = chunk * 9 + tap, written by LDS-DMA; unit u of a stage = 16 bytes at LDS offset 16 u ----
-    const size_t plane_stride = (phase || pooled) ? (size_t)p.Cout * 16 * p.Cin : (size_t)p.Cout * 9 * p.KD * p.Cin;  // bf16 elements per plane
+    const size_t plane_stride = phase ? (size_t)p.Cout * 16 * p.Cin : (size_t)p.Cout * (pooled ? 16 : 9) * p.KD * p.Cin;  // bf16 elements per plane
     // per-lane element offsets of the row / k-slot this lane fills (32 bits: a weight plane is < 2^31 elements); the tap / chunk part of
     // the address is wave-uniform and goes into the scalar base of global_load_lds.  b_tail: the same with k-slots beyond Cin
     // redirected to channel group 0 (only the last chunk of a Cin % 32 != 0 layer uses it)
@@ -334,25 +334,31 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
     __syncthreads();
     const int ngroups = (phase || pooled) ? 0 : nchunks * KD;  // groups of nine taps: (chunk, kd)
     if (pooled) {
-        // groups of four taps: (parity plane, chunk).  Input row 2r - 1 + u, u = 0..3, of output row r: even rows (plane bit 0) are
-        // u = 1, 3 = plane rows r, r + 1; odd rows u = 0, 2 = plane rows r - 1, r - hence the window row  a + 1 - parity  of tap a
+        // groups of four taps: (parity plane, chunk [, depth tap]).  Input row 2r - 1 + u, u = 0..3, of output row r: even rows (plane
+        // bit 0) are u = 1, 3 = plane rows r, r + 1; odd rows u = 0, 2 = plane rows r - 1, r - hence the window row  a + 1 - parity  of
+        // tap a.  KD = 3 (a DBlock's 3x3x3 conv followed by the 2 x 2 spatial part of its AvgPool3d): the same over the three depth
+        // planes, 16 tap sums each ([48 taps] = kd * 16 + plane * 4 + tap), walked as virtual chunks vc = chunk * 3 + kd like the plain
+        // 3-D loop below; the depth pair average is a separate streaming pass over the small map (dgmr_pool_depth2)
+        const int nvc = nchunks * KD;
 #pragma unroll
         for (int pl = 0; pl < 4; ++pl) {
             const int pp = pl >> 1, qq = pl & 1;
 #pragma unroll 1
-            for (int chunk = 0; chunk < nchunks; ++chunk) {
-                const bool last_chunk = chunk + 1 == nchunks;
-                const bool more = !(pl == 3 && last_chunk);
-                const int nchunk = last_chunk ? 0 : chunk + 1, npl = last_chunk ? pl + 1 : pl;
+            for (int vc = 0; vc < nvc; ++vc) {
+                const int chunk = KD == 3 ? vc / 3 : vc, kd = KD == 3 ? vc - chunk * 3 : 0;
+                const bool last_vc = vc + 1 == nvc;
+                const bool more = !(pl == 3 && last_vc);
+                const int nv = last_vc ? 0 : vc + 1, npl = last_vc ? pl + 1 : pl;
+                const int nchunk = KD == 3 ? nv / 3 : nv, nkd = KD == 3 ? nv - nchunk * 3 : 0;
 #pragma unroll
                 for (int tap = 0; tap < 4; ++tap) {
                     const int st = tap & 1;
-                    if (tap < 3) dma_b(chunk, pl * 4 + tap + 1, st ^ 1);
-                    else if (more) dma_b(nchunk, npl * 4, st ^ 1);
-                    mma((tap >> 1) + 1 - pp, (tap & 1) + 1 - qq, st, tail16 && last_chunk);
+                    if (tap < 3) dma_b(chunk, kd * 16 + pl * 4 + tap + 1, st ^ 1);
+                    else if (more) dma_b(nchunk, nkd * 16 + npl * 4, st ^ 1);
+                    mma((tap >> 1) + 1 - pp, (tap & 1) + 1 - qq, st, tail16 && chunk == nchunks - 1);
                     if (tap == 3 && more) {
                         __syncthreads();
-                        stage_a(nchunk, 0, (uint32_t)(((npl >> 1) * 2 * Ws + (npl & 1)) * p.Cin));
+                        stage_a(nchunk, nkd, (uint32_t)(((npl >> 1) * 2 * Ws + (npl & 1)) * p.Cin));
                     }
                     dma_drain();
                     if (!PRIV || (tap == 3 && more)) __syncthreads();

@@ -25,6 +25,7 @@ extern "C" int dgmr_abi_version(void) { return DGMR_ABI_VERSION; }
 namespace {
 
 constexpr int EW_THREADS = 256;
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 inline int ew_blocks(int64_t n_items) { return (int)std::min<int64_t>((n_items + EW_THREADS - 1) / EW_THREADS, 256 * 16); }
 
 #define GRID_STRIDE(i, n) \
@@ -578,6 +579,47 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
     }
 }
 
+// The same, 16 bytes per lane: the grid stride is a multiple of C / 4, so a thread's channel quad - and its five coefficient quads -
+// never change over its rows (the scalar kernel spends a 64-bit modulo and seven dependent loads per element: 4.3 TB/s of HBM
+// traffic where a streaming kernel reaches ~6).  Same expression per element as above.
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const f32x4* __restrict__ gy, const f32x4* __restrict__ x,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                             const f32x4* __restrict__ dx_add, f32x4* __restrict__ dx,
+                                                             int64_t n4, int C, float invR, int train) {
+    const int g = blockIdx.y;
+    const int C4 = C >> 2;
+    const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % C4) * 4;
+    f32x4 mn, rs, k0, k1, gr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const size_t gc = (size_t)g * C + c + j;
+        mn[j] = mean[gc];
+        rs[j] = rstd[gc];
+        k0[j] = (float)sums[((size_t)g * 2 + 0) * C + c + j];
+        k1[j] = (float)sums[((size_t)g * 2 + 1) * C + c + j];
+        gr[j] = (gamma ? gamma[c + j] : 1.f) * rs[j];
+    }
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const size_t base = (size_t)g * n4;
+    for (int64_t i = i0; i < n4; i += stride) {
+        f32x4 v = __builtin_nontemporal_load(gy + base + i);
+        if (train) {
+            const f32x4 xv = __builtin_nontemporal_load(x + base + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xv[j] - mn[j]) * rs[j];
+                v[j] = v[j] - k0[j] * invR - xh * k1[j] * invR;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= gr[j];
+        if (dx_add) v += __builtin_nontemporal_load(dx_add + base + i);
+        dx[base + i] = v;
+    }
+}
+
 __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int G,
                                      int C) {
     GRID_STRIDE(c, C) {
@@ -644,6 +686,23 @@ __global__ void pool_fwd_kernel(const float* __restrict__ x, const float* __rest
             for (int j = 0; j < 4; ++j) s[j] = m[j] > 0.f ? s[j] : 0.f;
         }
         *reinterpret_cast<f32x4*>(y + o) = s;
+    }
+}
+
+// y[n][j] = (x[n][2j] + x[n][2j + 1]) / 2 (+ addend[n][j]): the depth half of AvgPool3d(2) over planes of `plane4` float4 (the spatial
+// half already rode in the conv that produced x: dgmr_conv_args.pool2 on a 3x3x3 conv).  blockIdx.y walks the output planes.
+__global__ __launch_bounds__(256) void pool_depth2_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ addend,
+                                                           f32x4* __restrict__ y, int N, int D, int64_t plane4) {
+    const int Do = D / 2;
+    for (int op = blockIdx.y; op < N * Do; op += gridDim.y) {
+        const int n = op / Do, j = op - n * Do;
+        const f32x4* x0 = x + ((size_t)n * D + 2 * j) * plane4;
+        const size_t ob = (size_t)op * plane4;
+        GRID_STRIDE(i, plane4) {
+            f32x4 v = (x0[i] + x0[plane4 + i]) * 0.5f;
+            if (addend) v += addend[ob + i];
+            y[ob + i] = v;
+        }
     }
 }
 
@@ -1206,8 +1265,21 @@ extern "C" int dgmr_bn_bwd_apply(const float* gy, const float* x, const float* m
                                  const double* sums, const float* dx_add, float* dx, float* dgamma, float* dbeta, int G,
                                  int64_t R, int C, int train, void* stream) {
     DGMR_CHECK_ARG(gy && x && mean && rstd && sums && dx, "dgmr_bn_bwd_apply: null pointer");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(R * C), G), dim3(EW_THREADS), 0, ST, gy, x, mean, rstd, gamma, sums,
-                       dx_add, dx, R, C, train);
+    const int64_t n4 = R * C / 4;
+    if (C % 4 == 0 && C / 4 <= 4096 && al16(gy) && al16(x) && al16(dx) && al16(dx_add)) {
+        // blocks: a multiple of m = (C/4) / gcd(C/4, 256) so that blocks * 256 is a multiple of C/4; ~2 float4 per thread per operand
+        const int C4 = C / 4;
+        int a = C4, b = 256;
+        while (b) { const int t = a % b; a = b; b = t; }
+        const int m = C4 / a;
+        int64_t blocks = (n4 + 2 * 256 - 1) / (2 * 256);
+        blocks = std::min<int64_t>(std::max<int64_t>((blocks + m - 1) / m * m, m), (int64_t)(65536 / m) * m);
+        hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)blocks, G), dim3(256), 0, ST, (const f32x4*)gy, (const f32x4*)x, mean, rstd,
+                           gamma, sums, (const f32x4*)dx_add, (f32x4*)dx, n4, C, 1.f / (float)R, train);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(R * C), G), dim3(EW_THREADS), 0, ST, gy, x, mean, rstd, gamma, sums,
+                           dx_add, dx, R, C, train);
+    }
     if (dgamma || dbeta)
         hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, sums, dgamma, dbeta, G, C);
     DGMR_CHECK_LAUNCH();
@@ -1277,6 +1349,18 @@ extern "C" int dgmr_pool_fwd(const float* x, const float* addend, float* y, int 
     const int64_t total = (int64_t)N * (D / pd) * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, x, addend, y, N, D, H, W, C, pd, scale,
                        mask_src, mask_a, mask_b, mask_group);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_pool_depth2(const float* x, const float* addend, float* y, int N, int D, int64_t plane, void* stream) {
+    DGMR_CHECK_ARG(x && y, "dgmr_pool_depth2: null pointer");
+    DGMR_CHECK_ARG(N > 0 && D >= 2 && plane > 0 && plane % 4 == 0 && al16(x) && al16(y) && al16(addend),
+                   "dgmr_pool_depth2: N=%d D=%d plane=%lld (planes of whole, aligned float4)", N, D, (long long)plane);
+    const int64_t plane4 = plane / 4;
+    const int planes = N * (D / 2);
+    hipLaunchKernelGGL(pool_depth2_kernel, dim3((unsigned)std::min<int64_t>((plane4 + 255) / 256, 1024), (unsigned)std::min(planes, 65535)),
+                       dim3(256), 0, ST, (const f32x4*)x, (const f32x4*)addend, (f32x4*)y, N, D, plane4);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

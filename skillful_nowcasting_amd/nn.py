@@ -308,7 +308,7 @@ class SNConv(_SpectralNormBase):
 
     def forward(self, x, *, pre_relu: bool = False, bn: Optional[BNState] = None, upsample: bool = False, residual=None,
                 act_relu: bool = False, calls: int = 1, sn: Optional[ops.SNCall] = None, residual_up: bool = False,
-                layout: Optional[ops.CallLayout] = None, want_stats: bool = False):
+                layout: Optional[ops.CallLayout] = None, want_stats: bool = False, pool_out: bool = False):
         """`calls` > 1: x is a batch of `calls` groups (forecast steps / frames [x generator draws]), each group being one call of
         this module in the reference (own power iteration, own sigma); `layout`: which call each group is (ops.CallLayout).
         `sn`: a record drawn earlier with `_sigma` (ConvGRU steps)."""
@@ -318,8 +318,9 @@ class SNConv(_SpectralNormBase):
             sn = self._sigma(calls, layout)
         # want_stats: -> (y, partials): per-tile sums of y and y^2 from the conv's epilogue for the BatchNorm that follows (None when
         # the dispatched kernel has none; BatchNorm.prepare then reads y)
+        # pool_out: -> AvgPool2d(2) / AvgPool3d(2) of the conv (+ `residual`, which is then at the pooled resolution): DBlock's tail
         spec = ConvSpec(upsample=upsample, pre_relu=pre_relu, bn=bn, sn=sn, act_relu=act_relu, residual_up=residual_up,
-                        want_stats=want_stats and self.training)
+                        want_stats=want_stats and self.training, pool_out=pool_out)
         out = ops.conv(x, self.weight_orig, self.bias, sn.inv_sigma, residual, spec)
         if want_stats and not spec.want_stats:
             return out, None

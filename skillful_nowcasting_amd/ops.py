@@ -169,6 +169,7 @@ class ConvSpec:
     act_relu: bool = False  # relu on the output (F.relu(conv(..)), common.py:424)
     residual_up: bool = False  # the residual is at half resolution and is added with nearest-2x upsampling
     want_stats: bool = False  # also return per-tile partial sums (sum y, sum y^2) of the output: the next BatchNorm's batch statistics
+    pool_out: bool = False  # y = AvgPool2d(2) / AvgPool3d(2) of the conv (+ residual at the pooled resolution): DBlock (common.py:233-237)
 
     @property
     def groups(self) -> int:
@@ -300,6 +301,29 @@ def _pool2_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
     return out
 
 
+def _pool2_fwd_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """bf16 planes of "3x3 conv, then 2x2 AVERAGE pool" as a 4x4 stride-2 kernel grouped by input-pixel parity (dgmr_conv_args.pool2 in
+    the forward direction: a DBlock's last conv + pooling); 3x3x3 weights: 16 tap sums per depth tap.  The 1/4 is folded into the tap
+    sums (a power of two: no rounding).  None where the window kernels cannot take the conv."""
+    if _PRECISION_CODE == 0 or _NO_PHASES or w.dim() not in (4, 5) or any(k != 3 for k in w.shape[2:]) or w.shape[1] % 8:
+        return None
+    cout, cin = w.shape[0], w.shape[1]
+    kd = 3 if w.dim() == 5 else 1
+    planes = _PLANES[_PRECISION_CODE]
+    key = (id(w), "pool2f", planes)
+    tag = (w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    hit = _phase_cache.get(key)
+    if hit is not None and hit[0] == tag and hit[2]() is w:
+        return hit[1]
+    sums = torch.empty(16 * kd * cout * cin, device=w.device, dtype=torch.float32)
+    call("dgmr_pool2_phase_weights", _p(w), _p(sums), cout * kd, cin, _stream())  # rows (co, kd): [co][kd * 16 + t][ci]
+    call("dgmr_axpby", _p(sums), None, _p(sums), 0.25, 0.0, sums.numel(), _stream())
+    out = torch.empty(planes * sums.numel(), device=w.device, dtype=torch.int16)
+    call("dgmr_split_weights", _p(sums), _p(out), 16 * kd * cout, cin, 0, 0, planes, 0, _stream())
+    _phase_cache[key] = (tag, out, weakref.ref(w, lambda _r, k=key: _phase_cache.pop(k, None)))
+    return out
+
+
 def _kdims(w: torch.Tensor):
     ks = list(w.shape[2:])
     return tuple([1] + ks) if len(ks) == 2 else tuple(ks)
@@ -376,16 +400,18 @@ class ConvFn(Function):
         if w.shape[1] != cin:
             raise RuntimeError(f"conv: input has {cin} channels, weight expects {w.shape[1]}")
         oshape = (n, cout, h, wd) if x.dim() == 4 else (n, cout, d, h, wd)
+        bn = spec.bn
+        groups = spec.groups
+        if n % groups:
+            raise RuntimeError(f"conv: batch {n} is not divisible into {groups} spectral-norm call groups")
+        if spec.pool_out:
+            return ConvFn._forward_pooled(ctx, x, w, bias, scale, residual, spec, (n, cin, cout, d, h, wd, kd, kh, kw))
         y = empty_cl(oshape, x)
         if residual is not None:
             residual = to_cl(residual)
             want = (n, cout, h // 2, wd // 2) if spec.residual_up else (oshape)
             if tuple(residual.shape) != tuple(want):
                 raise RuntimeError(f"conv: residual has shape {tuple(residual.shape)}, expected {tuple(want)}")
-        bn = spec.bn
-        groups = spec.groups
-        if n % groups:
-            raise RuntimeError(f"conv: batch {n} is not divisible into {groups} spectral-norm call groups")
         partials = _launch_conv(x, _p(w), bias, scale, y, n, d, h, wd, cin, cout, kd, kh, kw, upsample=spec.upsample,
                                 pre_relu=spec.pre_relu, pre_a=bn.a if bn else None, pre_b=bn.b if bn else None,
                                 pre_group=bn.group_size if bn else 1, residual=residual, act_relu=spec.act_relu,
@@ -409,6 +435,49 @@ class ConvFn(Function):
         return y
 
     @staticmethod
+    def _forward_pooled(ctx, x, w, bias, scale, residual, spec: ConvSpec, geom):
+        """conv + AvgPool (+ residual at the pooled resolution), DBlock's tail (common.py:233-237).  In the bf16 modes the window kernel
+        evaluates "3x3 conv, then 2x2 average" as ONE 4x4 stride-2 pass over the input's pixel-parity planes (16 instead of 36 multiply
+        steps per input pixel; the full-resolution conv output is never written or read back); a 3x3x3 conv gets the spatial half of its
+        AvgPool3d that way and the depth pair average as a streaming pass over the small map.  Elsewhere: the conv, then the pooling
+        kernel.  The backward pass is the composite's: dy is spread back over the windows first, the rest is the plain conv's."""
+        n, cin, cout, d, h, wd, kd, kh, kw = geom
+        if spec.upsample or spec.act_relu or spec.want_stats or spec.bn is not None or spec.residual_up:
+            raise RuntimeError("conv: pool_out combines with pre_relu / a pooled-resolution residual only")
+        is3d = x.dim() == 5
+        pd = 2 if is3d else 1
+        if h % 2 or wd % 2 or (is3d and d < 2):
+            raise RuntimeError(f"conv: pool_out needs even maps (got {d}x{h}x{wd})")
+        oshape = (n, cout, d // pd, h // 2, wd // 2) if is3d else (n, cout, h // 2, wd // 2)
+        if residual is not None:
+            residual = to_cl(residual)
+            if tuple(residual.shape) != oshape:
+                raise RuntimeError(f"conv: residual has shape {tuple(residual.shape)}, expected {oshape}")
+        groups = spec.groups
+        y = empty_cl(oshape, x)
+        done = NotImplemented
+        w_pool = _pool2_fwd_planes(w) if (kd, kh, kw) in ((1, 3, 3), (3, 3, 3)) else None
+        if w_pool is not None:
+            sp = empty_cl((n, cout, d, h // 2, wd // 2), x) if is3d else y
+            done = _launch_conv(x, _p(w), bias, scale, sp, n, d, h, wd, cin, cout, kd, kh, kw, pre_relu=spec.pre_relu,
+                                residual=None if is3d else residual, scale_group=n // groups, w_split=_split_planes(w, False),
+                                w_phase=w_pool, pool2=True)
+            if done is not NotImplemented and is3d:
+                call("dgmr_pool_depth2", _p(sp), _p(residual), _p(y), n, d, (h // 2) * (wd // 2) * cout, _stream())
+        if done is NotImplemented:
+            full = empty_cl((n, cout, d, h, wd) if is3d else (n, cout, h, wd), x)
+            _launch_conv(x, _p(w), bias, scale, full, n, d, h, wd, cin, cout, kd, kh, kw, pre_relu=spec.pre_relu,
+                         scale_group=n // groups, w_split=_split_planes(w, False))
+            call("dgmr_pool_fwd", _p(full), _p(residual), _p(y), n, d, h, wd, cout, pd, 0.0, None, None, None, 1, _stream())
+        ctx.spec = spec
+        ctx.has_residual = residual is not None
+        ctx.params = (w, bias, scale if spec.gamma_scale else None)
+        sn = spec.sn
+        ctx.save_for_backward(x, scale, None, sn.u if sn else None, sn.v if sn else None, None, None, None, None)
+        ctx.geom = geom
+        return y
+
+    @staticmethod
     def backward(ctx, dy, _dpartials=None):
         spec: ConvSpec = ctx.spec
         x, scale, y_act, sn_u, sn_v, bn_a, bn_b, bn_mean, bn_rstd = ctx.saved_tensors
@@ -416,6 +485,11 @@ class ConvFn(Function):
         n, cin, cout, d, h, wd, kd, kh, kw = ctx.geom
         dy = to_cl(dy)
         dev = dy.device
+        dy_pooled = None
+        if spec.pool_out:  # gradient of the pooling first (dy / window over every window): the rest is the plain conv's backward
+            dy_pooled = dy
+            dy = empty_cl((n, cout, h, wd) if x.dim() == 4 else (n, cout, d, h, wd), dy_pooled)
+            call("dgmr_pool_bwd", _p(dy_pooled), _p(dy), n, d, h, wd, cout, 2 if x.dim() == 5 else 1, 0.0, _stream())
         if y_act is not None:  # relu epilogue (never combined with a residual on this path)
             assert not ctx.has_residual
             dz = torch.empty_like(dy)
@@ -538,7 +612,9 @@ class ConvFn(Function):
                 call("dgmr_bn_bwd_apply", _p(g), _p(x), _p(bn_mean), _p(bn_rstd), _p(bn.gamma), _p(sums), None, _p(dx), _p(dgam),
                      _p(dbet), bn.groups, r, c, int(bn.train), st)
         d_res = None
-        if ctx.has_residual:
+        if ctx.has_residual and dy_pooled is not None:
+            d_res = dy_pooled
+        elif ctx.has_residual:
             if spec.residual_up:  # backward of the nearest-2x upsample: sum over the 2x2 window
                 d_res = empty_cl((n, cout, h // 2, wd // 2), dy)
                 call("dgmr_pool_fwd", _p(dy), None, _p(d_res), n, 1, h, wd, cout, 1, 1.0, None, None, None, 1, st)

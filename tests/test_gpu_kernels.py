@@ -417,3 +417,77 @@ def test_thin_output_tile_matches_the_other_window_tiles(tuned, n, d, h, w, cin,
     assert not torch.isnan(ys[0]).any()
     assert (ys[0] - ys[1]).abs().max().item() <= 2e-6 * sc
     assert (ys[0] - ys[2]).abs().max().item() <= 5e-6 * sc
+
+
+# conv + AvgPool (+ shortcut) as one operator (ops.ConvSpec.pool_out: DBlock's tail) against the conv followed by the pooling kernel.
+# n, d, h, w (the conv's map), cin, cout, shortcut
+POOL_OUT_CASES = [
+    (24, 1, 64, 64, 96, 96, True),     # 96-column tile, 32-wide pooled map
+    (24, 1, 64, 64, 48, 48, True),     # 16 x 16 blocks
+    (96, 1, 32, 32, 192, 192, False),  # 16-wide pooled map
+    (400, 1, 16, 16, 96, 128, True),   # 8 x 8 pooled map: two images per tile
+    (2, 12, 64, 64, 48, 48, True),     # 3x3x3: spatial half in the conv, depth pair average behind it
+    (5, 5, 64, 64, 48, 96, True),      # odd depth: the last plane is dropped like AvgPool3d does
+    (2, 1, 8, 8, 96, 96, True),        # too small for the window kernel: conv + pooling kernel (the fallback must agree with itself)
+]
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-4), ("bf16x6", 5e-6), ("bf16", 2e-2), ("f32", 2e-6)])
+@pytest.mark.parametrize("n,d,h,w,cin,cout,res", POOL_OUT_CASES)
+def test_conv_with_pooled_output_matches_conv_then_pool(n, d, h, w, cin, cout, res, prec, tol):
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import ops
+
+    torch.manual_seed(3)
+    is3d = d > 1
+    pd = 2 if is3d else 1
+    mf = torch.channels_last_3d if is3d else torch.channels_last
+    xs = (n, cin, d, h, w) if is3d else (n, cin, h, w)
+    ws = (cout, cin, 3, 3, 3) if is3d else (cout, cin, 3, 3)
+    os_ = (n, cout, d // 2, h // 2, w // 2) if is3d else (n, cout, h // 2, w // 2)
+    x0 = torch.randn(xs, device=DEV).contiguous(memory_format=mf)
+    w0 = (torch.randn(ws, device=DEV) * 0.05).contiguous(memory_format=mf)
+    b0 = torch.randn(cout, device=DEV)
+    r0 = torch.randn(os_, device=DEV).contiguous(memory_format=mf) if res else None
+    scale = torch.rand(1, device=DEV) + 0.5
+    gy = torch.randn(os_, device=DEV).contiguous(memory_format=mf)
+    launched = []
+    orig = ops._launch_conv
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        if k.get("pool2"):
+            launched.append(out is not NotImplemented)
+        return out
+
+    def run(fused):
+        x, wt, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if res else None
+        for t in (wt, b):
+            t.grad = torch.zeros_like(t)
+        if fused:
+            y = ops.conv(x, wt, b, scale, r, ops.ConvSpec(pre_relu=True, pool_out=True))
+        else:
+            y = ops.avg_pool_add(ops.conv(x, wt, b, scale, None, ops.ConvSpec(pre_relu=True)), r, pd)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return y.detach(), x.grad, wt.grad, b.grad, (r.grad if res else None)
+
+    S.set_precision(prec)
+    ops._launch_conv = spy
+    try:
+        got = run(True)
+        ref = run(False)
+    finally:
+        ops._launch_conv = orig
+        S.set_precision("f32")
+    if prec != "f32" and h > 8:
+        assert launched and all(launched), "the single-pass kernel was not taken"
+    names = ("y", "dx", "dw", "dbias", "dresidual")
+    for name, g, r_ in zip(names, got, ref):
+        if g is None:
+            assert r_ is None
+            continue
+        err = (g - r_).abs().max().item() / max(r_.abs().max().item(), 1e-30)
+        # the backward pass runs the same kernels on the same dy either way: only y carries the different summation
+        assert err <= (tol if name == "y" else 1e-6), f"{name}: {err:.2e}"
