@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${1:-r4_run9}
 mkdir -p "$OUT"
 cd "$ROOT"
-timeout 900 python -m pytest tests -m gpu -q -x --deselect tests/test_gpu_fullstep.py > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; tail -25 "$OUT/pytest_gpu.log" | cut -c1-300
+timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_gpu_fullstep.py > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; tail -25 "$OUT/pytest_gpu.log" | cut -c1-300
 timeout 400 python bench.py --steps 8 --warmup 3 --also off --cpu-baseline off > "$OUT/bench.json" 2>"$OUT/bench.err"; echo "bench rc=$?"; tail -3 "$OUT/bench.err"
 python - <<P
 import json
