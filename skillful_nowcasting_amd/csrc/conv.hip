@@ -21,6 +21,7 @@
 #include "conv_bf16.h"  // split_weights_kernel (the bf16 MFMA kernels themselves are instantiated in tu_*.hip, see conv_launch.h)
 #include "conv_device.h"
 #include "conv_launch.h"
+#include "conv_stem4.h"
 
 namespace {
 
@@ -718,6 +719,17 @@ extern "C" int dgmr_conv_pool2_supported(const dgmr_conv_args* a) {
 }
 
 static inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+// DGMR_STEM4=0: A/B switch for the four-channel first-conv kernel
+static const bool g_stem4 = []() {
+    const char* e = getenv("DGMR_STEM4");
+    return !(e && e[0] == '0');
+}();
+static bool stem4_ok(const dgmr_conv_args& p) {
+    return g_stem4 && g_tune_variant < 0 && p.Cin == 4 && p.w_cin == 4 && p.w_coff == 0 && p.KH == 3 && p.KW == 3 &&
+           ((p.KD == 1 && p.D == 1) || (p.KD == 3 && p.D >= 1)) && p.Cout % STEM_BN == 0 && p.H % STEM_TH == 0 && p.W % STEM_TW == 0 &&
+           p.epi_mode == DGMR_EPI_PLAIN && !p.upsample && !p.pool2 && !p.pre_a && !p.addend && !p.residual && !p.mask_src && !p.stats_out &&
+           al16(p.x) && al16(p.y) && al16(p.bias) && (int64_t)p.N * p.D * (p.H / STEM_TH) * (p.W / STEM_TW) < (1ll << 31);
+}
 static void conv_args_defaults(dgmr_conv_args& p) {
     p.reserved0 = 0;
     p.reserved1 = g_debug_flags & (3 | 64 | 128);
@@ -802,6 +814,18 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
     // 64 x 64 tile keeps two resident, which is what the short-K layers that land here need (the discriminators' Cin = 4 first convs)
     if (g_precision == 3 && (variant == V_F128x64 || variant == V_F128x96)) variant = V_F64x64;
     if (g_tune_variant >= V_F128x128 && g_tune_variant <= V_F128x32) variant = g_tune_variant;
+    // 3x3 / 3x3x3 convs of four-channel maps (the first convs behind a space-to-depth): exact fp32 on v_mfma_f32_16x16x4_f32, whatever
+    // the arithmetic mode (conv_stem4.h)
+    if (stem4_ok(p)) {
+        const uint32_t detail = 4u | ((p.KD == 3 ? 1u : 0u) << 11);
+        ProfScope ps(V_F64x64, flops, s, g_precision == 1 ? 1.0 / 3.0 : (g_precision == 3 ? 1.0 / 6.0 : 1.0), detail);
+        const int tiles_w = p.W / STEM_TW, tiles_hw = tiles_w * (p.H / STEM_TH);
+        const dim3 grid((unsigned)(p.N * p.D * tiles_hw), (unsigned)(p.Cout / STEM_BN));
+        if (p.KD == 3) hipLaunchKernelGGL(conv_stem4_kernel<3>, grid, dim3(256), 0, s, p, tiles_w, tiles_hw);
+        else hipLaunchKernelGGL(conv_stem4_kernel<1>, grid, dim3(256), 0, s, p, tiles_w, tiles_hw);
+        DGMR_CHECK_LAUNCH();
+        return 0;
+    }
     // 3x3 convs of the big feature maps in the bf16 modes: LDS-window kernel (needs pre-split weights)
     WinPlan wp;
     const bool phases = phase_plan(p, &wp);  // (rewrites p to the low-resolution map when it applies)
@@ -1180,6 +1204,8 @@ static std::string prof_detail_name(int variant, uint32_t d) {
     } else if (kind == 2) {
         snprintf(b, sizeof b, "%s%s%s%s%s %s", kVariantNames[variant], (d >> 8) & 1 ? " splitk" : "", (d >> 9) & 1 ? " 1x1" : "",
                  (d >> 11) & 1 ? " 3d" : "", (d >> 14) & 1 ? " gru" : "", (d >> 12) & 1 ? "small(<1024wg)" : "big");
+    } else if (kind == 4) {
+        snprintf(b, sizeof b, "stem3x3 Cin=4 <f32 mfma 16x16x4>%s", (d >> 11) & 1 ? " 3d" : "");
     } else if (kind == 3) {
         static const char* const k[] = {"im2col", "window(one-role)", "window(wave-specialised)", "?"};
         snprintf(b, sizeof b, "%s %s%s%s%s", kVariantNames[variant], k[(d >> 4) & 3], (d >> 8) & 1 ? " 3d" : "", (d >> 9) & 1 ? " upsample" : "",

@@ -489,5 +489,43 @@ def test_conv_with_pooled_output_matches_conv_then_pool(n, d, h, w, cin, cout, r
             assert r_ is None
             continue
         err = (g - r_).abs().max().item() / max(r_.abs().max().item(), 1e-30)
-        # the backward pass runs the same kernels on the same dy either way: only y carries the different summation
-        assert err <= (tol if name == "y" else 1e-6), f"{name}: {err:.2e}"
+        # the backward pass runs the same kernels on the same dy either way: only y carries the different summation (the bias gradient's
+        # per-workgroup sums meet in float atomics: 1e-6-level run-to-run differences)
+        assert err <= (tol if name == "y" else 1e-5), f"{name}: {err:.2e}"
+
+
+# The four-channel first-conv kernel (conv_stem4.h: exact fp32 on v_mfma_f32_16x16x4_f32, weights in registers) against the exact-f32
+# implicit-GEMM kernel (forcing a tile variant through dgmr_conv_tune switches the special kernel off).
+@pytest.mark.parametrize("n,d,h,w,cout,relu", [(6, 1, 64, 64, 96, False), (5, 1, 128, 128, 48, True), (2, 6, 64, 64, 48, False),
+                                               (3, 3, 32, 32, 96, True), (1, 1, 8, 32, 48, False)])
+@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3"])
+def test_four_channel_first_conv_kernel_matches_implicit_gemm(n, d, h, w, cout, relu, prec):
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import ops
+    from skillful_nowcasting_amd._lib import call
+
+    torch.manual_seed(5)
+    is3d = d > 1
+    mf = torch.channels_last_3d if is3d else torch.channels_last
+    x = torch.randn((n, 4, d, h, w) if is3d else (n, 4, h, w), device=DEV).contiguous(memory_format=mf)
+    wt = (torch.randn((cout, 4, 3, 3, 3) if is3d else (cout, 4, 3, 3), device=DEV) * 0.2).contiguous(memory_format=mf)
+    bias = torch.randn(cout, device=DEV)
+    scale = torch.rand(1, device=DEV) + 0.5
+    spec = ops.ConvSpec(pre_relu=relu)
+    try:
+        S.set_precision(prec)
+        y = ops.conv(x, wt, bias, scale, None, spec)  # the library's choice: the stem kernel, in every mode
+        S.set_precision("f32")
+        call("dgmr_conv_tune", 1, -1, -1, -1)
+        ref = ops.conv(x, wt, bias, scale, None, spec)
+        torch.cuda.synchronize()
+    finally:
+        call("dgmr_conv_tune", -1, -1, -1, -1)
+        S.set_precision("f32")
+    assert not torch.isnan(y).any()
+    err = (y - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err  # exact fp32 products on both sides, another summation order
+    xr = torch.relu(x) if relu else x
+    tref = (torch.nn.functional.conv3d if is3d else torch.nn.functional.conv2d)(xr.double(), wt.double(), None, padding=1) * scale.double() \
+        + bias.double().view(1, -1, *([1] * (x.dim() - 2)))
+    assert (y.double() - tref).abs().max().item() / tref.abs().max().item() < 2e-6

@@ -109,7 +109,9 @@ def _check_post(sd0, sd1, rec, keys, kw, steps):
     for i, k in enumerate(keys):
         if _is_param(k):
             net = "generator." if k.startswith("generator.") else "discriminator."
-            tol = 0.05 * 2.2 * lr[net] * updates[net] * sd1[k].numel() + 1e-4 * ref[i, 1].item() + 1e-6
+            # (0.05: the element-wise differences of a tensor average out in its abs-sum - not for a single scalar like att_block.gamma,
+            #  whose abs-sum IS the value and may differ by the full Adam step bound)
+            tol = (0.05 if sd1[k].numel() >= 20 else 1.0) * 2.2 * lr[net] * updates[net] * sd1[k].numel() + 1e-4 * ref[i, 1].item() + 1e-6
         else:
             tol = 2e-3 * ref[i, 1].item() + 1e-5
         assert abs(cs[i, 1].item() - ref[i, 1].item()) <= tol, f"{k}: abs-sum {cs[i, 1].item()} vs {ref[i, 1].item()}"
