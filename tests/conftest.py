@@ -94,10 +94,7 @@ def band_check(what, precision, tol, rows, factor=None, flips_row=False):
     summation order and its whole gradient toggles; behind batch-statistics BatchNorm over a handful of samples the gradients are
     heavy-tailed, so ONE flipped element can move a max-abs comparison by 5e-2 while every other element agrees to 1e-6 (the
     unmodified reference shows the same between CPU thread counts, tests/golden/training_steps_adv `noise.*`).  They are accepted
-    by COUNT, never by a norm: at most 0.1 % of a tensor's elements - one element of a tensor with 256 ... 1999 of them, where 0.1 %
-    rounds to none and a single flip would otherwise decide the test (round 4: a 864-element latent-stack gradient sat at 87 % of its
-    bound in pure bf16x3; any change of a summation order in the discriminator moves such a value by +- 20 %) - may exceed the bound
-    (`flips_row`: or one output channel's worth -
+    by COUNT, never by a norm: at most 0.1 % of a tensor's elements may exceed the bound (`flips_row`: or one output channel's worth -
     one bias element, one weight row - where the oracle cannot be aligned to the implementation's relu masks, see KinkAligner), none
     by more than 100 x, and the cosine criterion still applies - a uniform error of any size (every element beyond the bound) fails."""
     if factor is None:
@@ -114,7 +111,7 @@ def band_check(what, precision, tol, rows, factor=None, flips_row=False):
         n_over = int(over.sum().item())
         # one flipped activation reaches one output channel: one element of a bias gradient, one row of a weight gradient
         row = r64.numel() // r64.shape[0] if r64.dim() >= 2 else 1
-        allowed = max(int(1e-3 * r64.numel()), row) if flips_row else max(int(1e-3 * r64.numel()), 1 if r64.numel() >= 256 else 0)
+        allowed = max(int(1e-3 * r64.numel()), row) if flips_row else int(1e-3 * r64.numel())
         l2 = ((hip.double() - r64.double()).pow(2).sum().sqrt() / r64.double().pow(2).sum().sqrt().clamp_min(1e-300)).item()
         within = e_hip <= bound
         flips = (not within) and n_over <= allowed and e_hip <= 100.0 * bound
