@@ -235,6 +235,15 @@ class DGMR(
 
     def training_step(self, batch, batch_idx):
         """One GAN step (dgmr/dgmr.py:137-218)."""
+        from .nn import SNScope
+
+        # (the generator's spectral-norm sequences of one step repeat from step to step: each is issued one forward ahead, nn.SNScope)
+        with SNScope.step(self.generator):
+            return self._training_step(batch, batch_idx)
+
+    def _training_step(self, batch, batch_idx):
+        from .nn import SNScope
+
         images, future_images = batch
         images = images.float()
         future_images = future_images.float()
@@ -307,6 +316,7 @@ class DGMR(
             if self.grad_sync is not None:
                 self.grad_sync.sync("g")
             g_opt.step()
+            SNScope.weights_changed(self.generator)
         finally:  # an exception (OOM, a refused launch) must not leave the discriminator frozen for a caller that retries
             for p in d_params:
                 p.requires_grad_(True)

@@ -88,6 +88,7 @@ class SNPlan:
         for m, _, _ in self.entries:
             m._gram()  # refresh W W^T in place if the optimiser moved W
         arena = torch.empty(self.total, device=self.device, dtype=torch.float32)
+        self.last_arena = arena  # (SNScope._prefetch: the allocation every record of this run is a view of)
         ops.call("dgmr_spectral_sigma_seq_multi", self.descs_dev.data_ptr(), len(self.entries), self.rows, self.cols, self.iters,
                  self.max_cout, self.max_calls, arena.data_ptr(), ops._stream())
         out = {}
@@ -108,11 +109,80 @@ class SNScope:
 
     _active = None
     _plans = {}
+    # Prefetch (DGMR.training_step): the generator's weights do not change between the optimiser steps, so the power iterations of its
+    # NEXT forward depend on nothing but u / v after the current one.  Inside `with SNScope.step(owner):` the sequence of scope keys
+    # of one step is recorded; once two consecutive steps have shown the same sequence, each scope entry issues the plan of the next
+    # key on a stream of its own, beside the forward that is about to run, and the next entry only waits for its event
+    # (17 ms of latency-bound launches per paper-size step sat on the main stream; two thirds of them can run ahead).
+    _steps = {}     # id(owner) -> {"seen": [...keys of this step], "last": [... of the step before], "plan": [...] or None, "pos": int}
+    _pending = {}   # (id(owner), key) -> (records, event, arena)
+    _streams = {}
+    _PREFETCH = __import__("os").environ.get("DGMR_SN_PREFETCH", "1") != "0"
 
     def __init__(self, owner: nn.Module, key=()):
         self.owner, self.key = owner, (id(owner), key)
         self.records = None
         self.trace = None
+
+    class step:
+        """`with SNScope.step(module):` brackets one training step of `module` (see above).  Leaving it with a prefetched sequence
+        unconsumed (an exception mid-step) drops the records; u / v have then advanced by that forward's iterations."""
+
+        def __init__(self, owner: nn.Module):
+            self.oid = id(owner)
+
+        def __enter__(self):
+            st = SNScope._steps.setdefault(self.oid, {"seen": [], "last": None, "plan": None, "pos": 0})
+            st["seen"], st["pos"] = [], 0
+            return self
+
+        def __exit__(self, *exc):
+            st = SNScope._steps.get(self.oid)
+            if st is None:
+                return False
+            for k in [k for k in SNScope._pending if k[0] == self.oid]:
+                del SNScope._pending[k]
+            complete = exc[0] is None and (st["plan"] is None or st["pos"] == len(st["plan"]))
+            # the next step prefetches only if this one repeated the one before (and followed the plan it was given, if any)
+            st["plan"] = list(st["seen"]) if (complete and st["last"] == st["seen"] and st["seen"]) else None
+            st["last"] = list(st["seen"]) if exc[0] is None else None
+            st["seen"] = None  # outside a step: nothing is recorded, nothing prefetched
+            return False
+
+    @classmethod
+    def weights_changed(cls, owner: nn.Module):
+        """An optimiser step has just changed `owner`'s weights: nothing behind this point of the step may be prefetched from in front
+        of it (recorded in the step's sequence like a scope)."""
+        st = cls._steps.get(id(owner))
+        if st is None or st["seen"] is None:
+            return
+        key = (id(owner), "weights changed")
+        st["seen"].append(key)
+        seq = st["plan"]
+        if seq is not None:
+            if st["pos"] < len(seq) and seq[st["pos"]] == key:
+                st["pos"] += 1
+            else:
+                st["plan"] = None
+
+    def _prefetch(self, key):
+        if key[1] == "weights changed":
+            return False
+        hit = SNScope._plans.get(key)
+        if hit is None or hit[0]() is not self.owner or not hit[1].valid():
+            return False
+        plan = hit[1]
+        dev = plan.device
+        side = SNScope._streams.get(dev)
+        if side is None:
+            side = SNScope._streams[dev] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)  # behind this forward's own sequence (u / v) and every optimiser update issued so far
+        with torch.cuda.stream(side):
+            records = plan.run()
+            ev = side.record_event()
+        SNScope._pending[key] = (records, ev, plan.last_arena)
+        return True
 
     def __enter__(self):
         self.prev = SNScope._active
@@ -120,14 +190,37 @@ class SNScope:
             self.noop = True
             return self
         self.noop = False
+        st = SNScope._steps.get(self.key[0])
+        if st is not None and st["seen"] is None:
+            st = None
+        pend = SNScope._pending.pop(self.key, None)
+        if any(k[0] == self.key[0] for k in SNScope._pending):
+            raise RuntimeError("spectral norm: a prefetched power-iteration sequence is pending for another forward of this module "
+                               "(the step did not repeat the previous one; DGMR_SN_PREFETCH=0 switches the prefetch off)")
         hit = SNScope._plans.get(self.key)
         plan = None
         if hit is not None and hit[0]() is self.owner and hit[1].valid():  # same live owner, pointers unchanged
             plan = hit[1]
-        if plan is not None:
+        if pend is not None:
+            records, ev, arena = pend
+            cur = torch.cuda.current_stream(arena.device)
+            cur.wait_event(ev)
+            arena.record_stream(cur)
+            self.records = records
+        elif plan is not None:
             self.records = plan.run()
         else:
             self.trace = []
+        if st is not None:
+            st["seen"].append(self.key)
+            seq = st["plan"]
+            if seq is not None:
+                if st["pos"] < len(seq) and seq[st["pos"]] == self.key:
+                    st["pos"] += 1
+                    if SNScope._PREFETCH and st["pos"] < len(seq):
+                        self._prefetch(seq[st["pos"]])
+                else:
+                    st["plan"] = None  # not the announced sequence: no more prefetching in this step
         SNScope._active = self
         return self
 

@@ -1,0 +1,64 @@
+"""GPU: the generator's spectral-norm sequences issued one forward ahead on their own stream (nn.SNScope.step / _prefetch) leave the
+training trajectory unchanged: the same plans run in the same order, every prefetched sequence is consumed, losses and state after five
+steps agree with the run that issues every sequence in line (up to the run-to-run noise of the float atomics in the bias gradients)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(forecast_steps=3, output_shape=128, latent_channels=256, context_channels=128, generation_steps=2)
+
+
+def _run(prefetch: bool, steps: int = 5):
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd.nn import SNPlan, SNScope
+
+    old = SNScope._PREFETCH
+    SNScope._PREFETCH = prefetch
+    log = []
+    orig = SNPlan.run
+
+    def spy(self):
+        main = torch.cuda.current_stream() == torch.cuda.default_stream()
+        log.append((len(self.entries), self.max_calls, main))
+        return orig(self)
+
+    SNPlan.run = spy
+    try:
+        torch.manual_seed(7)
+        model = S.DGMR(**KW).to("cuda").train()
+        torch.manual_seed(8)
+        x, y = torch.rand(2, 4, 1, 128, 128, device="cuda"), torch.rand(2, 3, 1, 128, 128, device="cuda")
+        losses = []
+        for i in range(steps):
+            torch.manual_seed(100 + i)
+            out = model.training_step((x, y), i)
+            losses.append([float(out[k]) for k in ("d_loss", "g_loss", "grid_loss")])
+        torch.cuda.synchronize()
+        assert not SNScope._pending
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    finally:
+        SNPlan.run = orig
+        SNScope._PREFETCH = old
+    return log, losses, sd
+
+
+def test_prefetched_spectral_norm_sequences_leave_the_trajectory_unchanged():
+    log0, loss0, sd0 = _run(False)
+    log1, loss1, sd1 = _run(True)
+    assert all(m for _, _, m in log0)  # in line: everything on the step's own stream
+    assert [(n, t) for n, t, _ in log0] == [(n, t) for n, t, _ in log1], "another sequence of spectral-norm plans"
+    ahead = sum(1 for _, _, m in log1 if not m)
+    assert ahead >= 4, f"only {ahead} sequences ran ahead"  # steps 3 .. 5: at least the second D-pass forward and the generator pass each
+    for a, b in zip(loss0, loss1):
+        for u, v in zip(a, b):
+            assert abs(u - v) <= 1e-4 * max(abs(u), abs(v), 1e-6), (loss0, loss1)
+    for k in sd0:
+        if not sd0[k].is_floating_point():
+            assert torch.equal(sd0[k], sd1[k]), k
+            continue
+        scale = sd0[k].abs().max().item()
+        err = (sd0[k] - sd1[k]).abs().max().item()
+        # parameters: Adam's +- lr steps may flip on 1e-6-level gradient noise (bias-gradient atomics); buffers: 1e-4
+        tol = 2.5 * 5 * 2e-4 if "original" in k or k.endswith(("weight", "bias", "gamma")) else 1e-4 * scale + 1e-6
+        assert err <= tol, f"{k}: {err:.3e} (scale {scale:.3e})"

@@ -90,3 +90,87 @@ def test_call_layout_slots():
     assert CallLayout(1, 5).is_identity() and CallLayout(4, 1).is_identity() and CallLayout(1, 5, reverse=True).is_identity()
     for lay in (CallLayout(6, 18), CallLayout(6, 18, reverse=True), CallLayout(6, 4, time_major=False, reverse=True)):
         assert sorted(lay.slots()) == list(range(lay.calls))
+
+
+def test_prefetch_schedule_state_machine(monkeypatch):
+    """SNScope.step: a step's sequence of scope keys is prefetched one forward ahead only after two identical steps, never across an
+    optimiser step, and a forward that leaves the announced sequence with a prefetched one pending is an error (host logic only: plans
+    and streams are replaced by recorders)."""
+    import pytest
+    import torch
+
+    from skillful_nowcasting_amd.nn import SNScope
+
+    class Owner(torch.nn.Module):
+        pass
+
+    owner = Owner().train()
+    issued, ran = [], []
+
+    def fake_prefetch(self, key):
+        if key[1] == "weights changed":
+            return False
+        issued.append(key[1])
+        SNScope._pending[key] = ({}, None, None)
+        return True
+
+    monkeypatch.setattr(SNScope, "_prefetch", fake_prefetch)
+    orig_enter = SNScope.__enter__
+
+    def enter(self):  # the pending records of the fake carry no event / arena: consume them here, then run the real bookkeeping
+        if self.key in SNScope._pending:
+            SNScope._pending.pop(self.key)
+            ran.append(("prefetched", self.key[1]))
+        else:
+            ran.append(("inline", self.key[1]))
+        return orig_enter(self)
+
+    monkeypatch.setattr(SNScope, "__enter__", enter)
+
+    def one_step(keys, change_after=None):
+        with SNScope.step(owner):
+            for i, k in enumerate(keys):
+                with SNScope(owner, k):
+                    pass
+                if change_after == i:
+                    SNScope.weights_changed(owner)
+
+    seq = ["a", "a", "b", "c", "d"]
+    try:
+        one_step(seq, change_after=3)
+        one_step(seq, change_after=3)
+        assert issued == []  # two identical steps first
+        one_step(seq, change_after=3)
+        # a -> a -> b -> c prefetched one ahead; nothing from in front of the optimiser step for d; the step's first scope never
+        assert issued == ["a", "b", "c"]
+        assert ran[-5:] == [("inline", "a"), ("prefetched", "a"), ("prefetched", "b"), ("prefetched", "c"), ("inline", "d")]
+        assert not SNScope._pending
+        # a step that leaves the sequence: the prefetch stops where it diverges ...
+        del issued[:]
+        with SNScope.step(owner):
+            with SNScope(owner, "x"):
+                pass
+        assert issued == [] and not SNScope._pending
+        # ... and needs two identical steps again
+        one_step(seq, change_after=3)
+        assert issued == []
+        one_step(seq, change_after=3)
+        assert issued == []
+        one_step(seq, change_after=3)
+        assert issued == ["a", "b", "c"]
+        # leaving the sequence while a prefetched forward is pending cannot be repaired (u / v have advanced): refused loudly
+        with pytest.raises(RuntimeError, match="prefetched"):
+            with SNScope.step(owner):
+                with SNScope(owner, "a"):
+                    pass
+                with SNScope(owner, "zzz"):
+                    pass
+        assert not SNScope._pending  # the step's exit dropped it
+        # outside a step nothing is recorded or prefetched
+        del issued[:]
+        with SNScope(owner, "a"):
+            pass
+        assert issued == []
+    finally:
+        SNScope._steps.pop(id(owner), None)
+        SNScope._pending.clear()
