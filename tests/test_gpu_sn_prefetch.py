@@ -47,7 +47,11 @@ def test_prefetched_spectral_norm_sequences_leave_the_trajectory_unchanged():
     log0, loss0, sd0 = _run(False)
     log1, loss1, sd1 = _run(True)
     assert all(m for _, _, m in log0)  # in line: everything on the step's own stream
-    assert [(n, t) for n, t, _ in log0] == [(n, t) for n, t, _ in log1], "another sequence of spectral-norm plans"
+    # per plan shape (the generator's plans, the discriminator's, the one-module plans) the same sequence; a plan issued ahead is merely
+    # INVOKED earlier relative to the other networks' plans
+    for sig in sorted({(n, t) for n, t, _ in log0}):
+        assert [x[:2] for x in log0 if x[:2] == sig] == [x[:2] for x in log1 if x[:2] == sig], f"another sequence of plans {sig}"
+    assert len(log0) == len(log1)
     ahead = sum(1 for _, _, m in log1 if not m)
     assert ahead >= 4, f"only {ahead} sequences ran ahead"  # steps 3 .. 5: at least the second D-pass forward and the generator pass each
     for a, b in zip(loss0, loss1):
