@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 KW = dict(forecast_steps=3, output_shape=128, latent_channels=256, context_channels=128, generation_steps=2)
 
 
-def _run(prefetch: bool, steps: int = 5):
+def _run(prefetch: bool, steps: int = 5, **kw):
     import skillful_nowcasting_amd as S
     from skillful_nowcasting_amd.nn import SNPlan, SNScope
 
@@ -26,7 +26,7 @@ def _run(prefetch: bool, steps: int = 5):
     SNPlan.run = spy
     try:
         torch.manual_seed(7)
-        model = S.DGMR(**KW).to("cuda").train()
+        model = S.DGMR(**KW, **kw).to("cuda").train()
         torch.manual_seed(8)
         x, y = torch.rand(2, 4, 1, 128, 128, device="cuda"), torch.rand(2, 3, 1, 128, 128, device="cuda")
         losses = []
@@ -43,26 +43,54 @@ def _run(prefetch: bool, steps: int = 5):
     return log, losses, sd
 
 
-def test_prefetched_spectral_norm_sequences_leave_the_trajectory_unchanged():
-    log0, loss0, sd0 = _run(False)
-    log1, loss1, sd1 = _run(True)
-    assert all(m for _, _, m in log0)  # in line: everything on the step's own stream
+def _same_plan_sequences(log0, log1):
     # per plan shape (the generator's plans, the discriminator's, the one-module plans) the same sequence; a plan issued ahead is merely
     # INVOKED earlier relative to the other networks' plans
     for sig in sorted({(n, t) for n, t, _ in log0}):
         assert [x[:2] for x in log0 if x[:2] == sig] == [x[:2] for x in log1 if x[:2] == sig], f"another sequence of plans {sig}"
     assert len(log0) == len(log1)
+    assert all(m for _, _, m in log0)  # in line: everything on the step's own stream
     ahead = sum(1 for _, _, m in log1 if not m)
     assert ahead >= 4, f"only {ahead} sequences ran ahead"  # steps 3 .. 5: at least the second D-pass forward and the generator pass each
-    for a, b in zip(loss0, loss1):
-        for u, v in zip(a, b):
-            assert abs(u - v) <= 1e-4 * max(abs(u), abs(v), 1e-6), (loss0, loss1)
+
+
+def test_prefetched_sequences_are_the_same_power_iterations_bit_for_bit():
+    """With both learning rates at zero the weights never move, so every u / v after five steps is a function of the initial state and
+    of the ORDER of the power iterations alone - deterministic kernels, no gradient noise: the prefetching run must reproduce every
+    spectral-norm vector of the in-line run bit for bit (a skipped, repeated or reordered sequence would not)."""
+    log0, _, sd0 = _run(False, gen_lr=0.0, disc_lr=0.0)
+    log1, _, sd1 = _run(True, gen_lr=0.0, disc_lr=0.0)
+    _same_plan_sequences(log0, log1)
+    n = 0
+    for k in sd0:
+        if k.endswith(("._u", "._v")):
+            assert torch.equal(sd0[k], sd1[k]), k
+            n += 1
+        elif "original" in k or k.endswith((".weight", ".bias", "gamma")) and "bn" not in k:
+            assert torch.equal(sd0[k], sd1[k]), f"{k} moved at learning rate 0"
+    assert n > 100
+
+
+def test_prefetched_sequences_leave_the_trajectory_within_its_own_noise():
+    """Learning rates as shipped: two in-line runs differ by the float atomics of the bias gradients, amplified step by step (the
+    reference's own trajectory is chaotic the same way, tests/golden/training_steps_adv `noise.*`); the prefetching run must sit inside
+    a small multiple of that distance."""
+    log0, loss0, sd0 = _run(False)
+    _, loss0b, sd0b = _run(False)
+    log1, loss1, sd1 = _run(True)
+    _same_plan_sequences(log0, log1)
+    for i, (a, b, c) in enumerate(zip(loss0, loss0b, loss1)):
+        for u, v, w in zip(a, b, c):
+            noise = abs(u - v)
+            assert abs(u - w) <= 10.0 * noise + 1e-5 * max(abs(u), 1e-6), f"step {i}: {u} / {v} in line, {w} prefetched"
+    worst = 0.0
     for k in sd0:
         if not sd0[k].is_floating_point():
             assert torch.equal(sd0[k], sd1[k]), k
             continue
         scale = sd0[k].abs().max().item()
+        noise = (sd0[k] - sd0b[k]).abs().max().item()
         err = (sd0[k] - sd1[k]).abs().max().item()
-        # parameters: Adam's +- lr steps may flip on 1e-6-level gradient noise (bias-gradient atomics); buffers: 1e-4
-        tol = 2.5 * 5 * 2e-4 if "original" in k or k.endswith(("weight", "bias", "gamma")) else 1e-4 * scale + 1e-6
-        assert err <= tol, f"{k}: {err:.3e} (scale {scale:.3e})"
+        assert err <= 10.0 * noise + 1e-5 * scale + 1e-7, f"{k}: {err:.3e} prefetched vs {noise:.3e} between two in-line runs (scale {scale:.3e})"
+        worst = max(worst, err / max(scale, 1e-30))
+    print(f"prefetch vs in line, worst state difference {worst:.2e} of a tensor's max")
