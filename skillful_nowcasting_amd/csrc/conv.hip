@@ -724,6 +724,17 @@ static const bool g_stem4 = []() {
     const char* e = getenv("DGMR_STEM4");
     return !(e && e[0] == '0');
 }();
+// DGMR_CONV1X1=0: A/B switch for the streaming 1x1-conv kernel
+static const bool g_conv1x1 = []() {
+    const char* e = getenv("DGMR_CONV1X1");
+    return !(e && e[0] == '0');
+}();
+static bool conv1x1_ok(const dgmr_conv_args& p, int64_t M64) {
+    return g_conv1x1 && g_tune_variant < 0 && (g_precision == 1 || g_precision == 2) && p.w_split && p.KD == 1 && p.KH == 1 && p.KW == 1 &&
+           p.Cin % 8 == 0 && p.Cin >= 32 && p.Cout % 4 == 0 && p.w_cin == p.Cin && p.w_coff == 0 && p.epi_mode == DGMR_EPI_PLAIN && !p.upsample &&
+           !p.pool2 && !p.pre_a && !p.addend && !p.residual && !p.mask_src && !p.stats_out && (p.reserved1 & 4) && al16(p.x) &&
+           ((int64_t)p.D * p.H * p.W) % 256 == 0 && M64 / 256 >= 512;  // (enough workgroups to fill the chip twice; tiles inside one sample)
+}
 static bool stem4_ok(const dgmr_conv_args& p) {
     return g_stem4 && g_tune_variant < 0 && p.Cin == 4 && p.w_cin == 4 && p.w_coff == 0 && p.KH == 3 && p.KW == 3 &&
            ((p.KD == 1 && p.D == 1) || (p.KD == 3 && p.D >= 1)) && p.Cout % STEM_BN == 0 && p.H % STEM_TH == 0 && p.W % STEM_TW == 0 &&
@@ -823,6 +834,15 @@ extern "C" int dgmr_conv_fwd(const dgmr_conv_args* a, void* stream) {
         const dim3 grid((unsigned)(p.N * p.D * tiles_hw), (unsigned)(p.Cout / STEM_BN));
         if (p.KD == 3) hipLaunchKernelGGL(conv_stem4_kernel<3>, grid, dim3(256), 0, s, p, tiles_w, tiles_hw);
         else hipLaunchKernelGGL(conv_stem4_kernel<1>, grid, dim3(256), 0, s, p, tiles_w, tiles_hw);
+        DGMR_CHECK_LAUNCH();
+        return 0;
+    }
+    // 1x1 convs of the big maps, bf16 / bf16x3: streaming GEMM (conv1x1.h; needs pre-split weights like the window kernels)
+    if (conv1x1_ok(p, M64)) {
+        const uint32_t detail = 5u | ((p.KD == 1 && p.D > 1 ? 1u : 0u) << 11);
+        ProfScope ps(variant, flops, s, 1.0, detail);
+        const int rows = p.D * p.H * p.W;
+        if ((g_precision == 1 ? dgmr_tu::launch_conv1x1_ns3(p, M, rows, s) : dgmr_tu::launch_conv1x1_ns1(p, M, rows, s)) != 0) return -1;
         DGMR_CHECK_LAUNCH();
         return 0;
     }
@@ -1204,6 +1224,8 @@ static std::string prof_detail_name(int variant, uint32_t d) {
     } else if (kind == 2) {
         snprintf(b, sizeof b, "%s%s%s%s%s %s", kVariantNames[variant], (d >> 8) & 1 ? " splitk" : "", (d >> 9) & 1 ? " 1x1" : "",
                  (d >> 11) & 1 ? " 3d" : "", (d >> 14) & 1 ? " gru" : "", (d >> 12) & 1 ? "small(<1024wg)" : "big");
+    } else if (kind == 5) {
+        snprintf(b, sizeof b, "conv1x1 stream (%s class)", kVariantNames[variant]);
     } else if (kind == 4) {
         snprintf(b, sizeof b, "stem3x3 Cin=4 <f32 mfma 16x16x4>%s", (d >> 11) & 1 ? " 3d" : "");
     } else if (kind == 3) {

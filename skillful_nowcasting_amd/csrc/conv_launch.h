@@ -36,6 +36,10 @@ DGMR_TU_DECLARE(1)
 DGMR_TU_DECLARE(3)
 DGMR_TU_DECLARE(6)
 #undef DGMR_TU_DECLARE
+// streaming 1x1 conv (tu_1x1.hip, conv1x1.h): bf16 and bf16x3
+DGMR_HIDDEN int launch_conv1x1_ns1(const dgmr_conv_args& p, int M, int rows_per_sample, hipStream_t s);
+DGMR_HIDDEN int launch_conv1x1_ns3(const dgmr_conv_args& p, int M, int rows_per_sample, hipStream_t s);
+
 // wave-specialised window kernels (tu_ws.hip): one translation unit per (arithmetic, kernel mode: 0 plain, 1 phase, 2 pooled)
 #define DGMR_TU_DECLARE_WS(NS, MODE) \
     DGMR_HIDDEN int launch_window_ws_ns##NS##_m##MODE(const dgmr_conv_args& p, const WinPlan& wp, int grid, hipStream_t s);

@@ -206,9 +206,11 @@ def _split_planes(w: torch.Tensor, flipped: bool, coff: int = 0, cin: Optional[i
     """bf16 (hi, lo) planes of a 3x3 (or 3x3x3) conv weight — optionally of its input-channel slice [coff, coff+cin) — or of the
     flipped / transposed version used by the data gradient; cached until the parameter changes.  None when the LDS-window kernels
     cannot take this conv (mode f32, not 3x3[x3], channel count % 8)."""
-    if _PRECISION_CODE == 0 or w.dim() not in (4, 5) or any(k != 3 for k in w.shape[2:]):
+    ks = tuple(w.shape[2:])
+    one = all(k == 1 for k in ks)  # 1x1 (1x1x1): the streaming 1x1 kernel (conv1x1.h) takes the same plane layout, one tap
+    if _PRECISION_CODE == 0 or w.dim() not in (4, 5) or not (one or all(k == 3 for k in ks)):
         return None
-    taps = 9 if w.dim() == 4 else 27
+    taps = 1 if one else (9 if w.dim() == 4 else 27)
     cout, cin_total = w.shape[0], w.shape[1]
     if cin is None:
         cin = cin_total

@@ -529,3 +529,45 @@ def test_four_channel_first_conv_kernel_matches_implicit_gemm(n, d, h, w, cout, 
     tref = (torch.nn.functional.conv3d if is3d else torch.nn.functional.conv2d)(xr.double(), wt.double(), None, padding=1) * scale.double() \
         + bias.double().view(1, -1, *([1] * (x.dim() - 2)))
     assert (y.double() - tref).abs().max().item() / tref.abs().max().item() < 2e-6
+
+
+# The streaming 1x1-conv kernel (conv1x1.h) against the implicit-GEMM kernel (forcing a tile variant through dgmr_conv_tune switches the
+# special kernel off): forward and data gradient, same bf16 planes and products, another summation order.
+@pytest.mark.parametrize("n,h,w,cin,cout,relu", [(32, 64, 64, 96, 48, False), (128, 32, 32, 192, 96, True), (512, 16, 16, 384, 192, False),
+                                                 (160, 32, 32, 80, 200, True), (40, 64, 64, 48, 384, False)])
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 5e-3)])
+def test_streaming_1x1_conv_matches_implicit_gemm(n, h, w, cin, cout, relu, prec, tol):
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import ops
+    from skillful_nowcasting_amd._lib import call
+
+    torch.manual_seed(9)
+    x0 = torch.randn(n, cin, h, w, device=DEV).contiguous(memory_format=torch.channels_last)
+    w0 = (torch.randn(cout, cin, 1, 1, device=DEV) * 0.1).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(cout, device=DEV)
+    scale = torch.rand(1, device=DEV) + 0.5
+    gy = torch.randn(n, cout, h, w, device=DEV).contiguous(memory_format=torch.channels_last)
+    spec = ops.ConvSpec(pre_relu=relu)
+
+    def run():
+        x = x0.clone().requires_grad_(True)
+        y = ops.conv(x, w0, bias, scale, None, spec)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return y.detach(), x.grad
+
+    S.set_precision(prec)
+    try:
+        y, dx = run()
+        call("dgmr_conv_tune", 2 if cout % 96 == 0 else (0 if cout > 64 else 3), -1, -1, -1)
+        yr, dxr = run()
+    finally:
+        call("dgmr_conv_tune", -1, -1, -1, -1)
+        S.set_precision("f32")
+    for name, a, b in (("y", y, yr), ("dx", dx, dxr)):
+        assert not torch.isnan(a).any(), name
+        err = (a - b).abs().max().item() / b.abs().max().item()
+        assert err <= tol, f"{name}: {err:.2e}"
+    xr = torch.relu(x0) if relu else x0
+    ref = torch.nn.functional.conv2d(xr.double(), w0.double()) * scale.double() + bias.double().view(1, -1, 1, 1)
+    assert (y.double() - ref).abs().max().item() / ref.abs().max().item() <= (3e-4 if prec == "bf16x3" else 3e-2)
