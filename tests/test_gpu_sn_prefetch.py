@@ -54,21 +54,34 @@ def _same_plan_sequences(log0, log1):
     assert ahead >= 4, f"only {ahead} sequences ran ahead"  # steps 3 .. 5: at least the second D-pass forward and the generator pass each
 
 
-def test_prefetched_sequences_are_the_same_power_iterations_bit_for_bit():
+def _rel(a, b):
+    if a.numel() == 0:
+        return 0.0
+    return (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-30)
+
+
+def test_prefetched_sequences_are_the_same_power_iterations():
     """With both learning rates at zero the weights never move, so every u / v after five steps is a function of the initial state and
-    of the ORDER of the power iterations alone - deterministic kernels, no gradient noise: the prefetching run must reproduce every
-    spectral-norm vector of the in-line run bit for bit (a skipped, repeated or reordered sequence would not)."""
+    of the ORDER of the power iterations alone: the prefetching run must reproduce the spectral-norm vectors of the in-line run as
+    closely as a second in-line run does (bit for bit where the kernels are deterministic; a skipped, repeated or reordered
+    sequence moves u / v by 1e-3 ... 1e-1 this early in the power iteration)."""
     log0, _, sd0 = _run(False, gen_lr=0.0, disc_lr=0.0)
+    _, _, sd0b = _run(False, gen_lr=0.0, disc_lr=0.0)
     log1, _, sd1 = _run(True, gen_lr=0.0, disc_lr=0.0)
     _same_plan_sequences(log0, log1)
-    n = 0
+    n, floor, worst, where = 0, 0.0, 0.0, ""
     for k in sd0:
         if k.endswith(("._u", "._v")):
-            assert torch.equal(sd0[k], sd1[k]), k
+            floor = max(floor, _rel(sd0b[k], sd0[k]))
+            e = _rel(sd1[k], sd0[k])
+            if e > worst:
+                worst, where = e, k
             n += 1
-        elif "original" in k or k.endswith((".weight", ".bias", "gamma")) and "bn" not in k:
+        elif "original" in k:
             assert torch.equal(sd0[k], sd1[k]), f"{k} moved at learning rate 0"
+    print(f"u / v after five steps: two in-line runs differ by {floor:.2e}, prefetched vs in-line {worst:.2e} ({where})")
     assert n > 100
+    assert worst <= 10.0 * floor + 1e-6, f"{where}: {worst:.3e} (two in-line runs: {floor:.3e})"
 
 
 def test_prefetched_sequences_leave_the_trajectory_within_its_own_noise():
@@ -85,12 +98,10 @@ def test_prefetched_sequences_leave_the_trajectory_within_its_own_noise():
             assert abs(u - w) <= 10.0 * noise + 1e-5 * max(abs(u), 1e-6), f"step {i}: {u} / {v} in line, {w} prefetched"
     worst = 0.0
     for k in sd0:
-        if not sd0[k].is_floating_point():
+        if not sd0[k].is_floating_point() or sd0[k].numel() == 0:
             assert torch.equal(sd0[k], sd1[k]), k
             continue
-        scale = sd0[k].abs().max().item()
-        noise = (sd0[k] - sd0b[k]).abs().max().item()
-        err = (sd0[k] - sd1[k]).abs().max().item()
-        assert err <= 10.0 * noise + 1e-5 * scale + 1e-7, f"{k}: {err:.3e} prefetched vs {noise:.3e} between two in-line runs (scale {scale:.3e})"
-        worst = max(worst, err / max(scale, 1e-30))
+        noise, err = _rel(sd0b[k], sd0[k]), _rel(sd1[k], sd0[k])
+        assert err <= 10.0 * noise + 1e-5, f"{k}: {err:.3e} prefetched vs {noise:.3e} between two in-line runs"
+        worst = max(worst, err)
     print(f"prefetch vs in line, worst state difference {worst:.2e} of a tensor's max")
