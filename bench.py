@@ -279,13 +279,19 @@ def main():
         mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(dev),
                 "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)}
         seen = [None] * world
-        dist.all_gather_object(seen, mine)
+        try:  # (diagnostics only: nothing here may cost the bench line)
+            dist.all_gather_object(seen, mine)
+        except Exception as e:  # noqa: BLE001
+            seen = [mine, f"all_gather_object failed: {type(e).__name__}: {e}"]
         try:
             ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             ver = None
-        pg_info = {"backend": backend, "world_size_reported": dist.get_world_size(), "rccl_version": ver, "ranks_seen": seen,
-                   "grad_sync": dict(model.grad_sync.stats) if getattr(model, "grad_sync", None) is not None else None}
+        try:
+            gs = dict(model.grad_sync.stats) if getattr(model, "grad_sync", None) is not None else None
+        except Exception:
+            gs = None
+        pg_info = {"backend": backend, "world_size_reported": dist.get_world_size(), "rccl_version": ver, "ranks_seen": seen, "grad_sync": gs}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -956,6 +956,20 @@ static bool wgrad_uses_window(const dgmr_wgrad_args* a) {
 }
 // tiles of 64 pixels: 2 x 32, or 4 x 16 on 16-pixel-wide maps
 static int wgrad_window_tw_shift(const dgmr_wgrad_args* a) { return a->W % 32 == 0 ? 5 : 4; }
+// Upsampling convs: the weight gradient by output-pixel parity on the LOW-resolution map (wgrad_ws.h PHASE: 16 instead of 36 multiply
+// steps per input pixel).  DGMR_WGRAD_PHASES=1 switches it ON: written at the end of round 4 and not yet measured in the step.  Needs the
+// four-matrix-wave kernel (bf16 / bf16x3) and a low-resolution map the window kernel tiles.
+static const bool g_wgrad_phases = []() {
+    const char* e = getenv("DGMR_WGRAD_PHASES");
+    return e && e[0] == '1';
+}();
+static bool wgrad_by_phases(const dgmr_wgrad_args* a) {
+    if (!((g_wgrad_phases || g_tune_wgrad_window == 4) && a->upsample && a->KD == 1 && a->D == 1 && a->KH == 3 && a->KW == 3 && wgrad_ws() && g_tune_wgrad_window != 2 &&
+          (g_precision == 1 || g_precision == 2) && a->H % 2 == 0 && a->W % 2 == 0))
+        return false;
+    const int h = a->H / 2, w = a->W / 2;
+    return (w % 32 == 0 && h % 2 == 0) || (w == 16 && h % 4 == 0);
+}
 
 extern "C" int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a) {
     DGMR_CHECK_ARG(a && a->N > 0 && a->Cin > 0 && a->Cout > 0, "dgmr_conv_wgrad_plan: bad args");
@@ -969,7 +983,8 @@ extern "C" int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a) {
     // workgroups = 32-channel input chunks x output tiles x slabs.  Two are resident per CU: one full round (<= 512 workgroups)
     // measures better than 1.5 rounds (tail) and than many small slabs (partial-sum traffic); >= 2 tiles of 64 pixels per slab
     const int per_slab = ((a->Cin + 31) / 32) * (a->Cout % 96 == 0 ? a->Cout / 96 : (a->Cout + 63) / 64);
-    const int64_t tiles_per_group = (int64_t)(a->N / groups) * a->D * ((int64_t)a->H * a->W / 64);
+    const bool phases = wgrad_by_phases(a);  // tiles of the low-resolution map; every slab is four rows of `partial` (one per parity)
+    const int64_t tiles_per_group = (int64_t)(a->N / groups) * a->D * ((int64_t)a->H * a->W / (phases ? 256 : 64));
     int64_t per = 512 / ((int64_t)per_slab * groups);  // slabs per group
     per = std::min<int64_t>(per, tiles_per_group / 2);
     per = std::max<int64_t>(per, 1);
@@ -978,7 +993,7 @@ extern "C" int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a) {
     // +8 % in isolation - but in the training step the weight gradients share the chip with the other streams' kernels and the
     // larger partial sums cost what the fill gains: 999 vs 1000 - 1004 ms per step)
     if (wgrad_ws()) per = std::max<int64_t>(1, std::min<int64_t>(256 / ((int64_t)per_slab * groups), tiles_per_group / 2));
-    a->nsplit = (int)std::min<int64_t>(per * groups, 4096);
+    a->nsplit = (int)std::min<int64_t>(per * groups, 4096) * (phases ? 4 : 1);
     return 0;
 }
 
@@ -1008,6 +1023,23 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
                              ((a->KD == 3 ? 1u : 0u) << 8) | ((a->upsample ? 1u : 0u) << 9) | ((Ktot == a->Cin ? 1u : 0u) << 10);
     ProfScope ps(wclass, 2.0 * (double)M64 * (double)Ktot * (double)a->Cout, s, 1.0, wdetail);
     // 3x3 convs on maps with whole rows of 32 pixels, bf16 modes: LDS-window weight gradient (wgrad_win.h)
+    if (wgrad_uses_window(a) && wgrad_by_phases(a) && a->nsplit % (4 * groups) == 0) {
+        dgmr_wgrad_args q = p;
+        q.H = a->H / 2, q.W = a->W / 2, q.upsample = 0;
+        const int spg4 = a->nsplit / 4 / groups;
+        const int tw_shift = wgrad_window_tw_shift(&q);
+        const int tiles_w = q.W >> tw_shift, tiles_hw = (q.H / (64 >> tw_shift)) * tiles_w;
+        const int tiles_per_group = (a->N / groups) * tiles_hw;
+        const int tiles_per_split = (tiles_per_group + spg4 - 1) / spg4;
+        const bool b96 = a->Cout % 96 == 0;
+        const dim3 grid((a->Cin + 31) / 32, b96 ? a->Cout / 96 : (a->Cout + 63) / 64, a->nsplit / 4);
+        for (int ph = 0; ph < 4; ++ph) {  // (every parity holds a quarter of dY's pixels: the bias gradient adds up over the four launches)
+            DGMR_BY_NS(launch_wgrad_window, q, grid, tw_shift, tiles_w, tiles_hw, tiles_per_split, spg4, tiles_per_group,
+                       1 | ((g_debug_flags & 16) >> 3) | 4 | 8 | (ph << 16), s);
+            DGMR_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     if (wgrad_uses_window(a)) {
         const int tw_shift = wgrad_window_tw_shift(a);
         const int tiles_w = a->W >> tw_shift, tiles_hw = (a->H / (64 >> tw_shift)) * tiles_w;
@@ -1180,7 +1212,7 @@ extern "C" int dgmr_get_precision(void) { return g_precision; }
 
 extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window) {
     DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 7 && wgrad_window >= -1 &&
-                       wgrad_window <= 3,
+                       wgrad_window <= 4,
                    "dgmr_conv_tune: variant %d ksplit %d window %d wgrad_window %d", variant, ksplit, window, wgrad_window);
     g_tune_variant = variant;
     g_tune_ksplit = ksplit;

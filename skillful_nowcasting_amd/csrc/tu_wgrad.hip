@@ -19,14 +19,19 @@ int DGMR_TU_CAT(launch_wgrad_window_ns, DGMR_NS)(const dgmr_wgrad_args& p, dim3 
 #define DGMR_WGS(BI_, TWS_)                                                                                                      \
     do {                                                                                                                         \
         if constexpr (NS != 6) {                                                                                                 \
+            if (ws & 8) { /* one output-pixel parity of an upsampling conv (ws bits 16, 17), four matrix waves */                 \
+                hipLaunchKernelGGL((conv_wgrad_ws_kernel<BI_, NS, TWS_, 4, true>), dim3(grid.x * grid.y * grid.z), dim3(512), 0, s, p,     \
+                                   tiles_w, tiles_hw, tiles_per_split, splits_per_group, tiles_per_group, ws & 0xff, 0, (ws >> 16) & 3, 4); \
+                break;                                                                                                           \
+            }                                                                                                                    \
             if (ws & 4) {                                                                                                        \
                 hipLaunchKernelGGL((conv_wgrad_ws_kernel<BI_, NS, TWS_, 4>), dim3(grid.x * grid.y * grid.z), dim3(512), 0, s, p, tiles_w, \
-                                   tiles_hw, tiles_per_split, splits_per_group, tiles_per_group, ws & 0xff, ws >> 8);            \
+                                   tiles_hw, tiles_per_split, splits_per_group, tiles_per_group, ws & 0xff, (ws >> 8) & 0xff);   \
                 break;                                                                                                           \
             }                                                                                                                    \
         }                                                                                                                        \
         hipLaunchKernelGGL((conv_wgrad_ws_kernel<BI_, NS, TWS_, 3>), dim3(grid.x * grid.y * grid.z), dim3(448), 0, s, p, tiles_w,    \
-                           tiles_hw, tiles_per_split, splits_per_group, tiles_per_group, ws & 0xff, ws >> 8);                    \
+                           tiles_hw, tiles_per_split, splits_per_group, tiles_per_group, ws & 0xff, (ws >> 8) & 0xff);           \
     } while (0)
         if (b96) {
             if (tw_shift == 5) DGMR_WGS(96, 5);

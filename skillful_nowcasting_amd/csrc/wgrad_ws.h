@@ -67,10 +67,21 @@ __device__ __forceinline__ void ws_interleave() {
 // MW = 4: FOUR matrix waves, one per SIMD, 16 x 16 x 32 MFMAs: wave (ci half, co half) owns 16 input channels x BI / 2 output channels
 //         x all 9 taps = 9 x BI / 32 accumulators [16 co x 16 ci]; the LDS images are [16-channel block][pixel][16] (32-byte rows), so
 //         that the 8 pixel rows a 32-lane group of a transposing read touches are 256 contiguous bytes at any tap shift.
-template <int BI, int NS, int TWS, int MW = 3>
+// PHASE (MW = 4 only; round 4): the weight gradient of a conv behind a nearest-2x upsample, one output-pixel parity (py, px) per
+//         launch.  Output pixel (2r + py, 2c + px) reads the input pixels (r + py - 1 + a, c + px - 1 + b), a, b in {0, 1}, under the
+//         filter rows / columns that fold onto them (ky -> a = (ky + 1 - py) >> 1), so
+//             dW[ky][kx] = sum over the four parities of  G[a(ky)][b(kx)],   G[a][b] = sum_pixels dY(2r + py, 2c + px) x(r + py - 1 + a, ...)
+//         - four 2 x 2-tap gradients on the LOW-resolution map (p.H x p.W = the input's; dY is read with stride 2) instead of one
+//         3 x 3-tap gradient on the upsampled one: 16 instead of 36 multiply steps per input pixel, as forward and data gradient
+//         already run.  Every launch writes a complete 9-tap slab (each G into the taps it feeds); the four parities of a slab are
+//         consecutive rows of `partial` (slab_mul = 4), which the reduction sums like any other slabs.
+template <int BI, int NS, int TWS, int MW = 3, bool PHASE = false>
 __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr_wgrad_args p, const int tiles_w, const int tiles_hw,
                                                            const int tiles_per_split, const int splits_per_group,
-                                                           const int tiles_per_group, const int dbg, const int kd) {
+                                                           const int tiles_per_group, const int dbg, const int kd, const int ph = 0,
+                                                           const int slab_mul = 1) {
+    static_assert(!PHASE || MW == 4, "phase mode: four matrix waves");
+    const int ppy = PHASE ? ph >> 1 : 0, ppx = PHASE ? ph & 1 : 0;
     constexpr int NP = planes_of<NS>::value;
     constexpr int CK = 32, CB = BI / 32;
     constexpr int TW = 1 << TWS, TH = 64 >> TWS;      // 32 x 2 or 16 x 4 pixels
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
         const int xq = lt & 7;     // this thread's 4-channel quad of the 32-channel chunk: the same for all its X items
         const int xci = chunk * CK + xq * 4;
         const bool xc_ok = xci < p.Cin;
-        const int us = p.upsample ? 1 : 0;
+        const int us = (!PHASE && p.upsample) ? 1 : 0;
         const int Hs = p.H >> us, Ws = p.W >> us;
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         // per-thread constants: every item's element offset from its tile's origin (the tile origin is a multiple of the tile size, so
@@ -142,7 +153,8 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
             const int idx = lt + i * NL;
             const int pix = idx / YQ, q = idx - pix * YQ;  // (compile-time divisor)
             const int co = co0 + q * 4;
-            yrel[i] = (uint32_t)((pix >> TWS) * p.W + (pix & (TW - 1))) * p.Cout + min(co, p.Cout - 4);
+            yrel[i] = PHASE ? (uint32_t)((pix >> TWS) * 4 * p.W + (pix & (TW - 1)) * 2) * p.Cout + min(co, p.Cout - 4)  // dY: 2 p.H x 2 p.W, stride 2
+                            : (uint32_t)((pix >> TWS) * p.W + (pix & (TW - 1))) * p.Cout + min(co, p.Cout - 4);
             y_ok |= co < p.Cout ? 1u << i : 0u;
         }
         // position of the next tile to fetch (tiles are fetched in order: stepped, not divided) and how many lie beyond it
@@ -186,7 +198,8 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
                 sa[E] = *reinterpret_cast<const f32x4*>(p.pre_a + g);
                 sb[E] = *reinterpret_cast<const f32x4*>(p.pre_b + g);
             }
-            const float* yb = p.dy + (((size_t)cn * p.H + ch0) * p.W + cw0) * p.Cout;
+            const float* yb = PHASE ? p.dy + (((size_t)cn * 2 * p.H + 2 * ch0 + ppy) * 2 * p.W + 2 * cw0 + ppx) * p.Cout
+                                    : p.dy + (((size_t)cn * p.H + ch0) * p.W + cw0) * p.Cout;
 #pragma unroll
             for (int i = 0; i < YP; ++i) sy[E][i] = *reinterpret_cast<const f32x4*>(yb + yrel[i]);
             if (left > 0) {
@@ -272,9 +285,10 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
         if constexpr (MW == 4) {
             constexpr int CBH = BI / 32;  // 16-channel output blocks of this wave's half
             const int cih = wid & 1, coh = wid >> 1;
-            f32x4 acc[9][CBH];
+            constexpr int NT = PHASE ? 4 : 9;  // taps a wave accumulates
+            f32x4 acc[NT][CBH];
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int c = 0; c < CBH; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
             // a 32-pixel step of the reduction: operand lane l holds k = 8 (l >> 4) ... + 7 for row / column l & 15; the two transposing
@@ -287,10 +301,12 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
             auto compute = [&](int buf) {
                 const uint32_t* Xs = smem + buf * BUF + cih * (HPIX * 8) + px_lane * 8 + seg;
                 const uint32_t* Ys = smem + buf * BUF + NP * XPL + coh * CBH * (64 * 8) + py_lane * 8 + seg;
-                auto fetch_x = [&](int ks, int pl, bf16x8_t (&dst)[9]) {
+                auto fetch_x = [&](int ks, int pl, bf16x8_t (&dst)[NT]) {
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const int hp = ((TWS == 5 ? ks : 2 * ks) + t / 3) * HTW + t % 3;
+                    for (int t = 0; t < NT; ++t) {
+                        // halo row / column of tap t: the 3 x 3 taps, or (phase) the 2 x 2 window that starts at row ppy, column ppx
+                        const int hp = PHASE ? ((TWS == 5 ? ks : 2 * ks) + ppy + (t >> 1)) * HTW + ppx + (t & 1)
+                                             : ((TWS == 5 ? ks : 2 * ks) + t / 3) * HTW + t % 3;
                         dst[t] = tr_fragment(Xs + pl * XPL + hp * 8, 8 * 8);
                     }
                 };
@@ -298,23 +314,23 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
 #pragma unroll
                     for (int c = 0; c < CBH; ++c) dst[c] = tr_fragment(Ys + pl * YPL + c * (64 * 8) + ks * 32 * 8, 8 * 8);
                 };
-                auto mm = [&](const bf16x8_t (&y)[CBH], const bf16x8_t (&x)[9]) {
+                auto mm = [&](const bf16x8_t (&y)[CBH], const bf16x8_t (&x)[NT]) {
 #pragma unroll
-                    for (int t = 0; t < 9; ++t)
+                    for (int t = 0; t < NT; ++t)
 #pragma unroll
                         for (int c = 0; c < CBH; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[c], x[t], acc[t][c], 0, 0, 0);
                 };
-                constexpr int M = 9 * CBH, RX = 18, RY = CBH * 2;
+                constexpr int M = NT * CBH, RX = 2 * NT, RY = CBH * 2, RX0 = PHASE ? 4 : 6;
                 if constexpr (NP == 2) {  // (product order and fragment rotation as in the three-wave variant below)
-                    bf16x8_t y0[2][CBH], x0[9], x1[9], y1[CBH];
+                    bf16x8_t y0[2][CBH], x0[NT], x1[NT], y1[CBH];
                     fetch_y(0, 0, y0[0]), fetch_x(0, 1, x1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, RY + 6, 0);  // dY and the first filter row of x: the first MFMAs can start
+                    __builtin_amdgcn_sched_group_barrier(0x100, RY + RX0, 0);  // dY and the first filter row of x: the first MFMAs can start
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         const int e = ks & 1;
                         fetch_y(ks, 1, y1), fetch_x(ks, 0, x0);
                         mm(y0[e], x1);  // hi(dY) . lo(x)
-                        if (ks == 0) ws_interleave<RX - 6 + RX + RY, M, 0>();
+                        if (ks == 0) ws_interleave<RX - RX0 + RX + RY, M, 0>();
                         else ws_interleave<RX + RY, M, 0>();
                         if (ks < 1) fetch_x(ks + 1, 1, x1), fetch_y(ks + 1, 0, y0[e ^ 1]);
                         mm(y1, x0);  // lo(dY) . hi(x)
@@ -325,7 +341,7 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
                     }
                 } else {
                     static_assert(NP == 1, "four matrix waves: bf16 and bf16x3 only (bf16x6 needs 144 fragment registers)");
-                    bf16x8_t xf[2][9], yf[2][CBH];
+                    bf16x8_t xf[2][NT], yf[2][CBH];
                     fetch_y(0, 0, yf[0]), fetch_x(0, 0, xf[0]);
                     fetch_y(1, 0, yf[1]), fetch_x(1, 0, xf[1]);
                     mm(yf[0], xf[0]);
@@ -342,7 +358,7 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
             }
             // ---- partial[slab][co][tap*Cin + ci]: lane = input channel (16 per wave), 4 output channels per lane and block ----
             const int Ktot = 9 * p.KD * p.Cin, tap0 = (p.KD == 3 ? kd : 0) * 9;
-            float* out = p.partial + (size_t)slab * p.Cout * Ktot;
+            float* out = p.partial + ((size_t)slab * slab_mul + (PHASE ? ph : 0)) * p.Cout * Ktot;
             const int ci = chunk * CK + cih * 16 + (lane & 15);
             if (ci < p.Cin) {
 #pragma unroll
@@ -352,7 +368,17 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
                         const int co = co0 + (coh * CBH + c) * 16 + 4 * (lane >> 4) + r;
                         if (co >= p.Cout) continue;
 #pragma unroll
-                        for (int t = 0; t < 9; ++t) out[(size_t)co * Ktot + (tap0 + t) * p.Cin + ci] = acc[t][c][r];
+                        for (int t = 0; t < 9; ++t) {
+                            float v;
+                            if constexpr (PHASE) {  // filter tap (ky, kx) is fed by window tap (a, b) = ((ky + 1 - py) >> 1, (kx + 1 - px) >> 1)
+                                const int a = (t / 3 + 1 - ppy) >> 1, b = (t % 3 + 1 - ppx) >> 1;
+                                const float va0 = b ? acc[1][c][r] : acc[0][c][r], va1 = b ? acc[3][c][r] : acc[2][c][r];
+                                v = a ? va1 : va0;
+                            } else {
+                                v = acc[t][c][r];
+                            }
+                            out[(size_t)co * Ktot + (tap0 + t) * p.Cin + ci] = v;
+                        }
                     }
             }
         } else {

@@ -355,6 +355,52 @@ def test_upsampling_conv_weight_gradient_paths_agree(n, h, w, cin, cout, groups)
             assert err <= 1e-4, f"{what}: {name} gradient rel err {err:.2e}"
 
 
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 6e-3)])
+@pytest.mark.parametrize("n,h,w,cin,cout,groups", [(4, 16, 16, 64, 96, 2), (6, 32, 32, 96, 192, 3), (2, 64, 64, 40, 48, 1), (3, 32, 64, 96, 96, 1)])
+def test_upsampling_conv_weight_gradient_by_phases(n, h, w, cin, cout, groups, prec, tol):
+    """The same gradient with the wave-specialised kernel's PHASE mode (dgmr_conv_tune wgrad_window = 4): four 2 x 2-tap gradients on
+    the low-resolution map, one per output-pixel parity, each written into the filter taps it feeds - against the 3 x 3-tap gradient
+    on the upsampled map (same bf16 planes and products, another summation order) and against exact f32."""
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import ops
+    from skillful_nowcasting_amd._lib import call
+
+    torch.manual_seed(4)
+    mf = torch.channels_last
+    x = (torch.randn(n, cin, h, w) + 0.3).to(DEV).contiguous(memory_format=mf)
+    w0 = (torch.randn(cout, cin, 3, 3) * (cin * 9) ** -0.5).to(DEV).contiguous(memory_format=mf)
+    b0 = torch.randn(cout).to(DEV)
+    inv_sigma = (torch.rand(groups) + 0.5).to(DEV)
+    u = torch.nn.functional.normalize(torch.randn(groups, cout, device=DEV), dim=1)
+    v = torch.nn.functional.normalize(torch.randn(groups, cin * 9, device=DEV), dim=1)
+    gy = torch.randn(n, cout, 2 * h, 2 * w).to(DEV).contiguous(memory_format=mf)
+
+    def grads(mode, wgrad_window):
+        S.set_precision(mode)
+        call("dgmr_conv_tune", -1, -1, -1, wgrad_window)
+        try:
+            wt, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
+            xr = x.clone().requires_grad_(True)
+            sn = ops.SNCall(inv_sigma, u, v, groups)
+            y = ops.conv(xr, wt, b, inv_sigma, None, ops.ConvSpec(pre_relu=True, sn=sn, upsample=True))
+            y.backward(gy)
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            return [t.detach().clone() for t in (ops.grad_buffer(wt), ops.grad_buffer(b))]
+        finally:
+            call("dgmr_conv_tune", -1, -1, -1, -1)
+            S.set_precision("f32")
+
+    ref = grads("f32", -1)
+    direct = grads(prec, 3)
+    phases = grads(prec, 4)
+    for g, d, r, name in zip(phases, direct, ref, ("weight", "bias")):
+        assert not torch.isnan(g).any(), name
+        scale = float(r.double().abs().max())
+        assert float((g.double() - d.double()).abs().max()) / scale <= tol, f"{name}: phases vs the 3 x 3 kernel"
+        assert float((g.double() - r.double()).abs().max()) / scale <= (1e-4 if prec == "bf16x3" else 2e-2), f"{name}: phases vs exact f32"
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # the wave-specialised persistent window kernel (conv_win_ws.h, dgmr_conv_tune window = 7) and the 16-column tile
 # ------------------------------------------------------------------------------------------------------------------------------
