@@ -106,7 +106,9 @@ def test_prefetched_sequences_leave_the_trajectory_within_its_own_noise():
             # parameters: a gradient that is rounding noise (a conv bias in front of BatchNorm: exactly zero in exact arithmetic) becomes
             # a +- lr step under Adam - two in-line runs may agree on it bit for bit and a third may not; bounded by the steps themselves
             lr, updates = (2e-4, 10) if k.startswith("discriminator.") else (5e-5, 5)
-            assert (sd1[k].double() - sd0[k].double()).abs().max().item() <= 2.2 * lr * updates, k
+            # (one Adam step with betas (0, 0.999) is at most sqrt(t) lr <= 2.24 lr in the first five; two trajectories may take it in
+            #  opposite directions)
+            assert (sd1[k].double() - sd0[k].double()).abs().max().item() <= 2 * 2.24 * lr * updates, k
         else:
             assert err <= 10.0 * noise + 1e-5, f"{k}: {err:.3e} prefetched vs {noise:.3e} between two in-line runs"
             worst = max(worst, err)
