@@ -957,11 +957,12 @@ static bool wgrad_uses_window(const dgmr_wgrad_args* a) {
 // tiles of 64 pixels: 2 x 32, or 4 x 16 on 16-pixel-wide maps
 static int wgrad_window_tw_shift(const dgmr_wgrad_args* a) { return a->W % 32 == 0 ? 5 : 4; }
 // Upsampling convs: the weight gradient by output-pixel parity on the LOW-resolution map (wgrad_ws.h PHASE: 16 instead of 36 multiply
-// steps per input pixel).  DGMR_WGRAD_PHASES=1 switches it ON: written at the end of round 4 and not yet measured in the step.  Needs the
-// four-matrix-wave kernel (bf16 / bf16x3) and a low-resolution map the window kernel tiles.
+// steps per input pixel; measured 57.9 -> 44.5 ms for the step's four launches, 877.7 -> 864.7 ms per step, profiles/r04_step6_*).
+// DGMR_WGRAD_PHASES=0 switches it off (A/B).  Needs the four-matrix-wave kernel (bf16 / bf16x3) and a low-resolution map the window
+// kernel tiles.
 static const bool g_wgrad_phases = []() {
     const char* e = getenv("DGMR_WGRAD_PHASES");
-    return e && e[0] == '1';
+    return !(e && e[0] == '0');
 }();
 static bool wgrad_by_phases(const dgmr_wgrad_args* a) {
     if (!((g_wgrad_phases || g_tune_wgrad_window == 4) && a->upsample && a->KD == 1 && a->D == 1 && a->KH == 3 && a->KW == 3 && wgrad_ws() && g_tune_wgrad_window != 2 &&
