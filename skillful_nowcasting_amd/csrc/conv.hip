@@ -965,7 +965,8 @@ static const bool g_wgrad_phases = []() {
     return !(e && e[0] == '0');
 }();
 static bool wgrad_by_phases(const dgmr_wgrad_args* a) {
-    if (!((g_wgrad_phases || g_tune_wgrad_window == 4) && a->upsample && a->KD == 1 && a->D == 1 && a->KH == 3 && a->KW == 3 && wgrad_ws() && g_tune_wgrad_window != 2 &&
+    // (dgmr_conv_tune wgrad_window: -1 = the library's choice = phases unless switched off, 4 = phases, 1 / 2 / 3 = the named 3 x 3 kernel)
+    if (!((g_tune_wgrad_window == 4 || (g_tune_wgrad_window < 0 && g_wgrad_phases)) && a->upsample && a->KD == 1 && a->D == 1 && a->KH == 3 && a->KW == 3 &&
           (g_precision == 1 || g_precision == 2) && a->H % 2 == 0 && a->W % 2 == 0))
         return false;
     const int h = a->H / 2, w = a->W / 2;
