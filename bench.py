@@ -56,6 +56,10 @@ def parse():
                          "reference's arithmetic: >= 10 steps after 3 warm-ups, with its own roofline block), bf16x6 and plain bf16 "
                          "(a few steps each); auto = on for single-GPU runs")
     ap.add_argument("--also-f32-steps", type=int, default=10)
+    ap.add_argument("--detail", default="", help="side file for the full record (default gpurun_out/bench_detail.json, relative to the repo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: still create the RCCL process group (world 1), attach the gradient exchange with "
+                         "force_exchange so that every bucket goes through ncclAllReduce and the buffers through ncclBroadcast")
     return ap.parse_args()
 
 
@@ -96,7 +100,7 @@ def cpu_baseline_reference(kw, hw, T):
     THIS host: whole `DGMR.training_step` calls (dgmr/dgmr.py:137-218) at the bench's model configuration and batch 1, through the
     stand-ins of oracle/_stubs.py for the three packages the image lacks (pytorch_lightning's LightningModule -> nn.Module with
     manual_backward / optimizers / log_dict, torchvision, pytorch_msssim: none of them does arithmetic on this path).  One step AS
-    WRITTEN (torch.autograd.set_detect_anomaly(True), dgmr.py:130) is `value`; a second with anomaly detection off rides along.
+    WRITTEN (torch.autograd.set_detect_anomaly(True), dgmr.py:130) runs first; a second, warmed-up one with anomaly detection off is `value`.
     Returns None when oracle/_ref is absent."""
     ref_root = os.path.join(ROOT, "oracle", "_ref")
     if not os.path.isdir(os.path.join(ref_root, "dgmr")):
@@ -118,21 +122,22 @@ def cpu_baseline_reference(kw, hw, T):
     with torch.no_grad():
         model(x)  # warm-up: thread pool, oneDNN primitive caches (advances u / v like any forward)
     times = {}
-    for label, anomaly in (("anomaly_off", False), ("as_written_anomaly_on", True)):  # (the first step also pays the one-off warm-up costs)
+    # the step AS WRITTEN (anomaly detection on, dgmr.py:130) runs first and absorbs what is left of the one-off warm-up; the warmed-up
+    # step with anomaly detection off is the faster of the two and is `value` (the conservative baseline for any speed-up quoted)
+    for label, anomaly in (("as_written_anomaly_on", True), ("anomaly_off", False)):
         torch.autograd.set_detect_anomaly(anomaly)
         t0 = time.perf_counter()
         model.training_step((x, y), 0)
         times[label] = time.perf_counter() - t0
     torch.autograd.set_detect_anomaly(False)
-    t_step = times["as_written_anomaly_on"]
+    t_step = times["anomaly_off"]
     return {
         "value": (4 + T) / t_step, "unit": "radar frames/s", "cores": cores, "kind": "reference", "host_cpus": os.cpu_count(),
         "seconds_per_step": {k: round(v, 2) for k, v in times.items()},
-        "value_anomaly_off": (4 + T) / times["anomaly_off"],
-        "sample": f"the unmodified reference's DGMR.training_step (dgmr/dgmr.py:137-218; package staged by oracle/make_ref.py, "
-                  f"LightningModule stand-in from oracle/_stubs.py), torch-CPU fp32, batch 1, {cores} threads of {os.cpu_count()} host "
-                  f"CPUs: one step with anomaly detection off first ({times['anomaly_off']:.1f} s, absorbs "
-                  f"the one-off warm-up), then ONE step as written (anomaly detection on, dgmr.py:130) = {t_step:.1f} s = `value`; no extrapolation",
+        "value_as_written_anomaly_on": (4 + T) / times["as_written_anomaly_on"],
+        "sample": f"unmodified reference DGMR.training_step (dgmr/dgmr.py:137-218, staged by oracle/make_ref.py), torch-CPU fp32, batch 1, "
+                  f"{cores} of {os.cpu_count()} host threads: 1 step as written (anomaly detection on, {times['as_written_anomaly_on']:.1f} s), "
+                  f"then 1 warmed-up step with it off ({t_step:.1f} s) = value; no extrapolation",
     }
 
 
@@ -180,6 +185,95 @@ REFERENCE_MEASURED = {
              "what": "unmodified reference DGMR.training_step, torch-CPU fp32, 25.8-28.4 s/step",
              "where": "build container, Intel Xeon 2.10 GHz 8 cores (BASELINE.md); not this host"},
 }
+
+
+LINE_LIMIT = 6000  # bytes: the driver keeps an 8 KB tail of stdout; round 4's 52 KB line did not parse
+DTYPE_SHORT = {
+    "f32": "f32 (exact fp32 MFMA)",
+    "bf16x6": "bf16x6 (fp32 tensors, 3 bf16 planes, 6 MFMAs/product, fp32 accumulate)",
+    "mixed": "mixed (fp32 tensors + accumulate; bf16x3 = 2 bf16 planes, 3 MFMAs/product, 16-bit products; discriminator forward bf16x6)",
+    "bf16x3": "bf16x3 (fp32 tensors, 2 bf16 planes, 3 MFMAs/product: 16-bit products, fp32 accumulate)",
+    "bf16": "bf16 operands, fp32 accumulate",
+}
+
+
+def _r(v, sig=4):
+    """floats to `sig` significant digits (the line is a summary; full precision lives in the detail file)"""
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}")
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def _roof_compact(roof, top=8):
+    if not roof:
+        return None
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "mfma_executed_frac", "mfma_util",
+            "mfma_util_weighted", "valu_per_mfma", "launches_per_step", "avg_launch_us", "flops_per_launch")
+    out = {k: roof.get(k) for k in keep if k in roof}
+    if roof.get("pmc_source"):
+        out["pmc_source"] = roof["pmc_source"]
+    ws = roof.get("whole_step") or {}
+    out["whole_step"] = {"tflops": ws.get("tflops"), "frac": ws.get("frac")}
+    ack = roof.get("all_conv_kernels") or {}
+    out["all_conv_kernels"] = {k: ack.get(k) for k in ("tflops", "ms_per_step")}
+    rows = sorted(roof.get("per_kernel") or [], key=lambda r: -r["total_ms"])[:top]
+    out["top_rows"] = [[r["kernel"], r["launches"], r["total_ms"], r["tflops"]] for r in rows if r["launches"]]
+    out["top_rows_cols"] = "kernel class, launches, total_ms, TFLOP/s"
+    return out
+
+
+def compact_line(full, detail_path=None, limit=LINE_LIMIT):
+    """The ONE JSON line of the bench contract, bounded in size: headline, config, dominant-kernel roofline with the <= 8 biggest
+    class rows, the other arithmetic modes as one number each, the CPU baseline.  Everything else (`per_kernel_detail`, per-step
+    times, the PMC launch record) goes to the side file `detail_path`.  Optional blocks are dropped in a fixed order should the
+    line still exceed `limit` bytes."""
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "hbm") if k in full}
+    for k in ("replicas_in_sync",):
+        if k in full:
+            out[k] = full[k]
+    pg = full.get("process_group")
+    if pg:
+        out["process_group"] = {k: pg.get(k) for k in ("backend", "world_size_reported", "rccl_version", "forced_single_rank")}
+        gs = pg.get("grad_sync")
+        if isinstance(gs, dict):
+            out["process_group"]["grad_sync"] = {k: v for k, v in gs.items() if isinstance(v, (int, float, str, bool))}
+    if full.get("roofline"):
+        out["roofline"] = _roof_compact(full["roofline"])
+    if full.get("also"):
+        out["also"] = {}
+        for mode, leg in full["also"].items():
+            c = {"ms_per_step": leg.get("ms_per_step"), "radar_frames_per_s": leg.get("radar_frames_per_s"), "steps": leg.get("steps")}
+            rf = leg.get("roofline")
+            if rf:
+                c["roofline"] = {k: rf.get(k) for k in ("kernel", "achieved", "peak", "frac")}
+            out["also"][mode] = c
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "host_cpus", "seconds_per_step",
+                                                      "value_as_written_anomaly_on", "sample") if k in cb}
+    if detail_path:
+        out["detail"] = detail_path
+    out = _r(out)
+    line = json.dumps(out, separators=(",", ":"))
+    # bounded: drop optional blocks in a fixed order until the line fits
+    for path in (("roofline", "top_rows"), ("cpu_baseline", "sample"), ("process_group",), ("also",), ("hbm",), ("roofline", "all_conv_kernels")):
+        if len(line) <= limit:
+            break
+        d = out
+        for k in path[:-1]:
+            d = d.get(k) or {}
+        if path[-1] == "top_rows" and d.get("top_rows"):
+            d["top_rows"] = d["top_rows"][:4]
+        else:
+            d.pop(path[-1], None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) <= limit, f"bench line is {len(line)} bytes"
+    return line
 
 
 def time_steps(model, batch, first_idx, n, barrier):
@@ -230,8 +324,17 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # --force-dist without a launcher: a one-rank RCCL group on this GPU
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -246,8 +349,8 @@ def main():
         _lib.load().dgmr_conv_tune(*[int(v) for v in args.tune.split(",")])
     torch.manual_seed(0)
     model = S.DGMR(strict_reference_semantics=not args.fast, **kw).to(dev)
-    if world > 1:
-        model.attach_data_parallel()
+    if use_dist:
+        model.attach_data_parallel(force_exchange=args.force_dist)
     torch.manual_seed(1000 + rank)
     images = torch.rand(B, 4, 1, hw, hw).to(dev)
     future = torch.rand(B, T, 1, hw, hw).to(dev)
@@ -256,7 +359,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for i in range(args.warmup):
@@ -265,7 +368,7 @@ def main():
     step_host = list(time_steps.host)
     # data parallel: every rank must hold bit-identical parameters after the timed steps (same all-reduced gradients, same Adam)
     replicas_in_sync = None
-    if world > 1:
+    if use_dist:
         cs = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
         lo, hi = cs.clone(), cs.clone()
         if backend != "nccl":
@@ -274,7 +377,7 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_in_sync = bool((lo == hi).all().item())
     pg_info = None
-    if world > 1:
+    if use_dist:
         # who is in the job: every rank reports (rank, device index, device name, PCI bus id); RCCL's version as torch reports it
         mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(dev),
                 "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)}
@@ -291,8 +394,9 @@ def main():
             gs = dict(model.grad_sync.stats) if getattr(model, "grad_sync", None) is not None else None
         except Exception:
             gs = None
-        pg_info = {"backend": backend, "world_size_reported": dist.get_world_size(), "rccl_version": ver, "ranks_seen": seen, "grad_sync": gs}
-    if world > 1:
+        pg_info = {"backend": backend, "world_size_reported": dist.get_world_size(), "rccl_version": ver, "ranks_seen": seen, "grad_sync": gs,
+                   "forced_single_rank": bool(args.force_dist and world == 1)}
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -380,6 +484,8 @@ def main():
                 # `traffic` belongs to ONE named launch of the dominant kernel (pmc_launch: its own duration, flops and bytes);
                 # avg_launch_us / flops_per_launch above are the class averages over the step - two different things, both labelled
                 roof["traffic"] = pmc["traffic_bytes"]
+                roof["traffic_over_algorithmic"] = pmc.get("traffic_over_algorithmic")
+                roof["pmc_source"] = f"profiles/{os.path.basename(pmc_path)}: committed rocprofv3 --pmc passes on one launch of this kernel (not this run)"
                 roof["mfma_util"] = pmc.get("mfma_util")
                 roof["valu_per_mfma"] = pmc.get("valu_per_mfma")
                 roof["pmc_launch"] = {k: pmc.get(k) for k in ("kernel", "shape", "launch_us", "algorithmic_tflops", "mfma_executed_tflops",
@@ -390,6 +496,15 @@ def main():
                 roof["traffic_detail"]["source"] = (f"profiles/{os.path.basename(pmc_path)} (+ raw counters in profiles/*_pmc_*.csv): "
                                                     "PMC passes cannot run inside this process; the number is the committed "
                                                     "measurement of one representative launch of this kernel, not of this run")
+        # time-weighted matrix-pipe busy share over every 3x3 conv class (north star: >= 40 %), from the committed per-class PMC passes
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_classes.json")))
+        if cands and precision != "f32":
+            try:
+                pc = json.load(open(cands[-1]))
+                roof["mfma_util_weighted"] = pc.get("mfma_util_weighted")
+                roof["mfma_util_classes"] = {"source": f"profiles/{os.path.basename(cands[-1])}", "rows": pc.get("rows")}
+            except (OSError, ValueError):
+                pass
         return roof
 
     roofline = None
@@ -421,22 +536,22 @@ def main():
     if rank == 0:
         out = {
             "metric": "radar frames/sec (G+D step) 4->18 @256^2" if args.workload == "paper" else f"radar frames/sec (G+D step) [{args.workload}]",
-            "value": value, "unit": "radar frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "radar frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_median": ms_median, "step_ms": [round(v, 1) for v in step_ms], "step_host_ms__reserved_gb__device_allocs__retries": step_host,
             "hbm": {"max_allocated_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
                     "reserved_gb": round(torch.cuda.memory_reserved() / 2**30, 1),
                     "alloc_retries": torch.cuda.memory_stats().get("num_alloc_retries", 0)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE_TEXT[args.precision],
+            "dtype": DTYPE_SHORT[args.precision], "dtype_long": DTYPE_TEXT[args.precision],
             "data": "synthetic torch.rand frames, random-init weights",
-            "config": {"workload": f"DGMR.training_step {args.workload}: {kw}, H=W={hw}", "per_gpu_batch": B, "global_batch": world * B,
-                       "frames_per_sample": 4 + T, "parallelism": f"dp{world}",
-                       "semantics": "fast (state-only forwards skipped too)" if args.fast else
-                                    "strict: every observable effect of the reference step (losses, both Adam updates, u/v / BN / RNG "
-                                    "state incl. checkpoint-recompute and logging forwards); never-read gradients are not computed"},
+            "config": {"workload": f"DGMR.training_step {args.workload}: " + ", ".join(f"{k}={v}" for k, v in kw.items()) + f", H=W={hw}",
+                       "per_gpu_batch": B, "global_batch": world * B, "frames_per_sample": 4 + T, "parallelism": f"dp{world}",
+                       "semantics": "fast (state-only forwards skipped)" if args.fast else
+                                    "strict: every observable effect of the reference step (losses, both Adam updates, u/v, BN and RNG state)"},
         }
         if replicas_in_sync is not None:
             out["replicas_in_sync"] = replicas_in_sync  # parameter checksums agree bit for bit across the ranks after the timed steps
+        if pg_info is not None:
             out["process_group"] = pg_info
         if roofline:
             out["roofline"] = roofline
@@ -446,8 +561,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline_reference(kw, hw, T) or cpu_baseline(kw, hw, T)
             if args.workload in REFERENCE_MEASURED:
                 out["cpu_baseline"]["reference_measured"] = REFERENCE_MEASURED[args.workload]
-        print(json.dumps(out))
-    if world > 1:
+        # the full record (per_kernel_detail, per-step times, the PMC launch records) goes to a side file; stdout gets ONE bounded line
+        detail_path = args.detail or os.path.join("gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(os.path.join(ROOT, detail_path)) or ".", exist_ok=True)
+            with open(os.path.join(ROOT, detail_path), "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:  # (a read-only tree must not cost the bench line)
+            detail_path = f"not written: {e}"
+        sys.stdout.flush()
+        print(compact_line(out, detail_path), flush=True)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -86,9 +86,13 @@ class _Pass:
 
 
 class GradSync:
-    def __init__(self, model, process_group=None, chunk_mb: int = 64, overlap: bool = True):
+    def __init__(self, model, process_group=None, chunk_mb: int = 64, overlap: bool = True, force_exchange: bool = False):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_exchange: run every collective even in a one-rank group (all-reduce and broadcast over one rank are the identity, the
+        # scale is 1/1): the whole RCCL path - library load, communicator on device_id, comm-stream fan-in, work.wait() - executes on a
+        # single GPU and must leave the parameters bit-identical to the run without it (tests/test_gpu_rccl.py)
+        self.exchange = self.world > 1 or (bool(force_exchange) and dist.is_initialized())
         if dist.is_initialized() and process_group is None and "WORLD_SIZE" in os.environ:
             # the launcher's idea of the job and the process group's must agree (a rank that fell back to a private group would train alone)
             if int(os.environ["WORLD_SIZE"]) != self.world:
@@ -138,13 +142,13 @@ class GradSync:
         self._buf_flat = flat
 
     def broadcast_buffers(self, src: int = 0):
-        if self.world == 1 or self._buf_flat is None:
+        if not self.exchange or self._buf_flat is None:
             return
         dist.broadcast(self._buf_flat, src=src, group=self.pg)
 
     def broadcast_parameters(self, src: int = 0):
         """One coalesced broadcast per network (two collectives instead of one per tensor)."""
-        if self.world == 1:
+        if not self.exchange:
             return
         with torch.no_grad():
             for fg in (self.gen, self.disc):
@@ -184,7 +188,7 @@ class GradSync:
 
     def begin(self, which: str):
         """Call right before the backward pass that fills network `which`'s gradients ('d' or 'g')."""
-        if self.world == 1:
+        if not self.exchange:
             return
         from . import ops
 
@@ -205,7 +209,10 @@ class GradSync:
         ops.set_grad_touch_hook(None)
         self._active = None
         for work in self._launched.values():
-            work.wait()
+            try:
+                work.wait()
+            except Exception:  # noqa: BLE001 - the backward pass already failed; its error is the one to surface
+                pass
         self._launched = {}
 
     def _touch(self, p):
@@ -265,7 +272,7 @@ class GradSync:
         """All-reduce (mean) the gradient buffer of network `which` ('g' or 'd'): launch whatever has not been launched during the
         backward pass, wait for every bucket, scale by 1/world.  Call after the backward pass (and after the weight-gradient
         streams have been joined), before ``optimizer.step()``."""
-        if self.world == 1:
+        if not self.exchange:
             return
         from . import ops
 
@@ -293,25 +300,30 @@ class GradSync:
             self._record(fg, ps)
 
     def _record(self, fg: FlatGrads, ps: _Pass):
-        ps.recorded = list(self._touches)
+        recorded = list(self._touches)
         nb = self._nbuckets(fg)
         last = [-1] * nb
         by_id = {id(p): p for p in fg.params}
-        for i, pid in enumerate(ps.recorded):
+        for i, pid in enumerate(recorded):
             for b in self._buckets_of(fg, by_id[pid]):
                 last[b] = i
-        ps.last_touch = last  # -1: a bucket nothing writes (dead parameters only): launchable from the start
-        ps.order = sorted(range(nb), key=lambda b: last[b])
-        # the launch order IS the pairing of the collectives across ranks: it must be the same list everywhere
-        if self.world > 1:
+        order = sorted(range(nb), key=lambda b: last[b])
+        # the launch order IS the pairing of the collectives across ranks: it must be the same list everywhere.  Checked on LOCAL
+        # values; the pass state is committed only on success - a caller that catches the error and goes on keeps exchanging
+        # un-overlapped, back to front, which pairs by bucket index on every rank
+        if self.exchange:
             h = 0
-            for b in ps.order:
+            for b in order:
                 h = (h * 1000003 + b + 1) % 2147483629
             t = torch.tensor([h, -h], dtype=torch.int64, device=fg.flat.device if fg.flat.is_cuda else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
             if int(t[0]) != h or int(t[1]) != -h:
+                self.overlap = False
                 raise RuntimeError("the ranks recorded different gradient-bucket launch orders: the backward passes are not the same "
-                                   "static graph on every rank; run with overlap=False")
+                                   "static graph on every rank; overlap has been switched off for this GradSync")
+        ps.recorded = recorded
+        ps.last_touch = last  # -1: a bucket nothing writes (dead parameters only): launchable from the start
+        ps.order = order
 
     def _verify_exchange(self, fg: FlatGrads):
         """check_exchange: the reduced bucket must equal the sum over ranks of what each rank held when it launched the bucket (fp32

@@ -356,12 +356,12 @@ class DGMR(
         out = self._generate(images.float(), k, grad=False)
         return out.view(k, images.shape[0], *out.shape[1:])
 
-    def attach_data_parallel(self, process_group=None, chunk_mb: int = 64, overlap: bool = True):
+    def attach_data_parallel(self, process_group=None, chunk_mb: int = 64, overlap: bool = True, force_exchange: bool = False):
         """One-process-per-GPU data parallelism: flat gradient buffers, RCCL all-reduce of 64 MB buckets launched while the backward
         pass is still running (`overlap`), buffers broadcast from rank 0 once per step."""
         from .ddp import GradSync
 
-        self.grad_sync = GradSync(self, process_group, chunk_mb, overlap)
+        self.grad_sync = GradSync(self, process_group, chunk_mb, overlap, force_exchange)
         g_opt, d_opt = self.optimizers()
         g_opt.flat_grads = self.grad_sync.gen
         d_opt.flat_grads = self.grad_sync.disc

@@ -448,8 +448,11 @@ class ConvFn(Function):
             raise RuntimeError("conv: pool_out combines with pre_relu / a pooled-resolution residual only")
         is3d = x.dim() == 5
         pd = 2 if is3d else 1
-        if h % 2 or wd % 2 or (is3d and d < 2):
-            raise RuntimeError(f"conv: pool_out needs even maps (got {d}x{h}x{wd})")
+        if h < 2 or wd < 2 or (is3d and d < 2):
+            raise RuntimeError(f"conv: pool_out needs maps of at least one pooling window (got {d}x{h}x{wd})")
+        # odd maps floor like nn.AvgPool2d / AvgPool3d (the last row / column / plane is dropped: 6 -> 3 -> 1 for 96x96 inputs); only the
+        # fused 4x4 stride-2 pass needs whole spatial windows - odd maps take the conv + pooling-kernel branch below (dgmr_pool_bwd zero-fills)
+        even = h % 2 == 0 and wd % 2 == 0  # (an odd DEPTH stays on the fused path: dgmr_pool_depth2 drops the last plane)
         oshape = (n, cout, d // pd, h // 2, wd // 2) if is3d else (n, cout, h // 2, wd // 2)
         if residual is not None:
             residual = to_cl(residual)
@@ -458,7 +461,7 @@ class ConvFn(Function):
         groups = spec.groups
         y = empty_cl(oshape, x)
         done = NotImplemented
-        w_pool = _pool2_fwd_planes(w) if (kd, kh, kw) in ((1, 3, 3), (3, 3, 3)) else None
+        w_pool = _pool2_fwd_planes(w) if (even and (kd, kh, kw) in ((1, 3, 3), (3, 3, 3))) else None
         if w_pool is not None:
             sp = empty_cl((n, cout, d, h // 2, wd // 2), x) if is3d else y
             done = _launch_conv(x, _p(w), bias, scale, sp, n, d, h, wd, cin, cout, kd, kh, kw, pre_relu=spec.pre_relu,

@@ -22,6 +22,7 @@ class FusedAdam(torch.optim.Optimizer):
             return
         super().zero_grad(set_to_none=set_to_none)
 
+    RING = 4  # pinned descriptor tables in flight (see _step_multi)
     multi_tensor = True  # every tensor of a parameter group in ONE launch (dgmr_adam_multi); False: one dgmr_adam launch per tensor
 
     @torch.no_grad()
@@ -69,10 +70,24 @@ class FusedAdam(torch.optim.Optimizer):
         if chunk is None:
             chunk = self.__dict__["_chunk"] = int(load().dgmr_adam_chunk())
         n = len(todo)
-        host = self.__dict__.get("_desc_host")
-        if host is None or host.numel() < n * ADAM_DESC_DTYPE.itemsize:
-            host = self.__dict__["_desc_host"] = torch.empty(n * ADAM_DESC_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
-            self.__dict__["_desc_dev"] = torch.empty(n * ADAM_DESC_DTYPE.itemsize, dtype=torch.uint8, device=todo[0][0].device)
+        # The upload is asynchronous and the step never synchronises the host: a pinned table must not be rewritten before the copy
+        # that reads it has executed (two step() calls per training step, several parameter groups per call).  A ring of pinned
+        # tables, each with the event of its last copy; a slot is reused only after that event.
+        nbytes = n * ADAM_DESC_DTYPE.itemsize
+        ring = self.__dict__.setdefault("_desc_ring", [])
+        turn = self.__dict__["_desc_turn"] = self.__dict__.get("_desc_turn", -1) + 1
+        if len(ring) < self.RING:
+            ring.append(None)
+        slot = turn % len(ring)
+        ent = ring[slot]
+        if ent is None or ent[0].numel() < nbytes:
+            if ent is not None:
+                ent[2].synchronize()
+            ent = ring[slot] = (torch.empty(nbytes, dtype=torch.uint8).pin_memory(),
+                                torch.empty(nbytes, dtype=torch.uint8, device=todo[0][0].device), torch.cuda.Event())
+        else:
+            ent[2].synchronize()  # (long done in practice: RING - 1 other uploads lie in between)
+        host, dev, done = ent
         tab = np.frombuffer(host.numpy(), dtype=ADAM_DESC_DTYPE, count=n)
         block = 0
         for i, (p, g, st) in enumerate(todo):
@@ -81,6 +96,6 @@ class FusedAdam(torch.optim.Optimizer):
             tab[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), numel, block,
                       np.float32(lr / (1.0 - b1 ** step)), np.float32(math.sqrt(1.0 - b2 ** step)), 0)
             block += (numel + chunk - 1) // chunk
-        dev = self.__dict__["_desc_dev"]
-        dev[:n * ADAM_DESC_DTYPE.itemsize].copy_(host[:n * ADAM_DESC_DTYPE.itemsize], non_blocking=True)
+        dev[:nbytes].copy_(host[:nbytes], non_blocking=True)
+        done.record()
         ops.call("dgmr_adam_multi", dev.data_ptr(), n, block, float(b1), float(b2), float(eps), ops._stream())

@@ -540,6 +540,48 @@ def test_conv_with_pooled_output_matches_conv_then_pool(n, d, h, w, cin, cout, r
         assert err <= (tol if name == "y" else 1e-5), f"{name}: {err:.2e}"
 
 
+# Odd maps: DBlock's fused tail must floor like nn.AvgPool2d / AvgPool3d (96x96 inputs reach a 3x3 map: 6 -> 3 -> 1), forward and backward,
+# against torch's own conv + avg_pool on the device (the fused tail raised on odd maps).
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16x3", 2e-4)])
+@pytest.mark.parametrize("n,d,h,w,cin,cout", [(6, 1, 3, 3, 96, 96), (4, 1, 5, 7, 48, 96), (3, 1, 33, 33, 48, 48), (2, 3, 5, 5, 48, 48), (2, 5, 9, 6, 48, 48)])
+def test_pooled_conv_floors_odd_maps_like_avgpool(n, d, h, w, cin, cout, prec, tol):
+    import torch.nn.functional as F
+
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import ops
+
+    torch.manual_seed(11)
+    is3d = d > 1
+    mf = torch.channels_last_3d if is3d else torch.channels_last
+    xs = (n, cin, d, h, w) if is3d else (n, cin, h, w)
+    ws = (cout, cin, 3, 3, 3) if is3d else (cout, cin, 3, 3)
+    os_ = (n, cout, d // 2, h // 2, w // 2) if is3d else (n, cout, h // 2, w // 2)
+    x0 = torch.randn(xs, device=DEV).contiguous(memory_format=mf)
+    w0 = (torch.randn(ws, device=DEV) * 0.05).contiguous(memory_format=mf)
+    b0 = torch.randn(cout, device=DEV)
+    r0 = torch.randn(os_, device=DEV).contiguous(memory_format=mf)
+    gy = torch.randn(os_, device=DEV).contiguous(memory_format=mf)
+    scale = torch.ones(1, device=DEV)
+    x, wt, b, r = (t.clone().requires_grad_(True) for t in (x0, w0, b0, r0))
+    for t in (wt, b):
+        t.grad = torch.zeros_like(t)
+    S.set_precision(prec)
+    try:
+        y = ops.conv(x, wt, b, scale, r, ops.ConvSpec(pre_relu=True, pool_out=True))
+        y.backward(gy)
+        torch.cuda.synchronize()
+    finally:
+        S.set_precision("f32")
+    xr, wr, br, rr = (t.double().clone().requires_grad_(True) for t in (x0, w0, b0, r0))
+    conv = (F.conv3d if is3d else F.conv2d)(F.relu(xr), wr, br, padding=1)
+    yr = (F.avg_pool3d if is3d else F.avg_pool2d)(conv, 2) + rr
+    yr.backward(gy.double())
+    assert tuple(y.shape) == tuple(yr.shape)
+    for name, g, ref in (("y", y.detach(), yr.detach()), ("dx", x.grad, xr.grad), ("dw", wt.grad, wr.grad), ("db", b.grad, br.grad), ("dres", r.grad, rr.grad)):
+        err = (g.double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+        assert err <= tol, f"{name}: {err:.2e}"
+
+
 # The four-channel first-conv kernel (conv_stem4.h: exact fp32 on v_mfma_f32_16x16x4_f32, weights in registers) against the exact-f32
 # implicit-GEMM kernel (forcing a tile variant through dgmr_conv_tune switches the special kernel off).
 @pytest.mark.parametrize("n,d,h,w,cout,relu", [(6, 1, 64, 64, 96, False), (5, 1, 128, 128, 48, True), (2, 6, 64, 64, 48, False),

@@ -211,3 +211,37 @@ def test_temporal_discriminator_backward_stages():
     bad += [k for k, e in rows if k.endswith(".dout") and not l2s[k] <= 3e-3]
     bad += [k for k, e in rows if k.startswith("grad ") and not l2s[k] <= 3e-2]
     assert not bad, f"beyond the bounds: {bad}\n{table}"
+
+
+def test_discriminators_on_96x96_inputs_floor_odd_maps_like_the_reference():
+    """96x96 frames reach DBlocks with 3x3 maps (spatial: 96 -> 48 -> 24 -> 12 -> 6 -> 3 -> 1; temporal: 6 frames -> 3 -> 1): the fused
+    DBlock tail must floor like nn.AvgPool2d / AvgPool3d (dgmr/common.py:186-189), forward and backward, as the oracle does."""
+    import skillful_nowcasting_amd as S
+    from oracle import dgmr_oracle as O
+
+    torch.manual_seed(5)
+    disc = S.Discriminator(input_channels=1)
+    sd = {k: v.detach().clone() for k, v in disc.state_dict().items()}
+    disc = disc.cuda().train()
+    x = torch.rand(2, 6, 1, 96, 96)
+    for prec, tol in (("f32", 1e-3), ("mixed", 1e-3)):
+        disc.load_state_dict(sd)
+        S.set_precision(prec)
+        try:
+            torch.manual_seed(9)
+            xg = x.cuda().requires_grad_(True)
+            out = disc(xg)
+            out.sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            S.set_precision("f32")
+        torch.manual_seed(9)
+        idxs = torch.randint(0, 6, (8,)).tolist()
+        xr = x.clone().requires_grad_(True)
+        ref = O.discriminator({k: v.clone() for k, v in sd.items()}, "", xr, idxs, True)
+        ref.sum().backward()
+        assert out.shape == ref.shape == (2, 2, 1)
+        err = (out.detach().cpu() - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
+        assert err <= tol, f"{prec}: discriminator forward on odd maps {err:.2e}"
+        gerr = (xg.grad.cpu() - xr.grad).abs().max().item() / xr.grad.abs().max().item()
+        assert gerr <= 5e-3, f"{prec}: input gradient on odd maps {gerr:.2e}"

@@ -320,3 +320,38 @@ def test_fused_adam_multi_tensor_equals_per_tensor_launches():
         sa, sb = oa.state[a], ob.state[b]
         assert sa["step"] == sb["step"] and torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
     assert oa.state[pa[3]]["step"] == 3
+
+
+@pytest.mark.gpu
+def test_fused_adam_descriptor_tables_survive_a_gpu_backlog():
+    """The training step never synchronises the host and calls step() several times per step: with a queue of device work in front, the
+    host fills the NEXT descriptor table while earlier uploads have not executed yet (one pinned table, rewritten in place,
+    let earlier launches see later descriptors).  Two parameter groups, twelve steps with ~0.3 s of device work queued ahead and no
+    synchronisation in between, against per-tensor launches: bit-identical."""
+    from skillful_nowcasting_amd.optim import FusedAdam
+
+    shapes = [(5,), (4097,), (16, 8, 3, 3), (20000,), (1,), (129, 65)]
+
+    def make():
+        torch.manual_seed(21)
+        ps = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+        return [dict(params=ps[:3], lr=1e-3), dict(params=ps[3:], lr=5e-3)], ps
+
+    (ga, pa), (gb, pb) = make(), make()
+    oa, ob = FusedAdam(ga, lr=1e-3, betas=(0.0, 0.999)), FusedAdam(gb, lr=1e-3, betas=(0.0, 0.999))
+    oa.multi_tensor, ob.multi_tensor = True, False
+    torch.manual_seed(22)
+    grads = [[torch.randn(s, device="cuda") * (10.0 ** (k % 3 - 1)) for s in shapes] for k in range(12)]
+    big = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    for opt, ps in ((oa, pa), (ob, pb)):
+        for _ in range(40):  # a backlog: the host runs far ahead of the device from here on
+            big = torch.mm(big, big).clamp_(-1, 1)
+        for k in range(12):
+            for p, g in zip(ps, grads[k]):
+                p.grad = g
+            opt.step()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.equal(a, b), i
+        assert torch.equal(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]), i
