@@ -82,7 +82,7 @@ SHAPES = [
 ]
 
 
-def bench(fn, iters=10):
+def bench(fn, iters=int(os.environ.get("CONV_BENCH_ITERS", "10"))):
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -184,7 +184,8 @@ def main():
 
             ms2 = bench(wg)
             line += f" | wgrad ns={ns:4d} {ms2*1e3:9.1f} us {flops/ms2/1e9:7.1f} TF"
-            if up and wsp is not None and ks == (1, 3, 3):  # weight gradient through the 9 pair-summed planes (1x1 problem)
+            skip_old = os.environ.get("CONV_BENCH_SKIP_OLD") == "1"  # PMC runs: only the paths the product takes
+            if up and wsp is not None and ks == (1, 3, 3) and not skip_old:  # weight gradient through the 9 pair-summed planes (1x1 problem)
                 z9 = torch.empty(n * (h // 2) * (w // 2) * 9 * cout, device=dev)
                 wz = WgradArgs()
                 wz.x, wz.dy = x.data_ptr(), z9.data_ptr()
@@ -222,7 +223,7 @@ def main():
                     call("dgmr_pool_fwd", hi.data_ptr(), None, dx.data_ptr(), n, d, h, w, cin, 1, 1.0, x.data_ptr(),
                          a.data_ptr() if bn else None, b.data_ptr() if bn else None, n, ops._stream())
 
-                ms3 = bench(dg_old)
+                ms3 = 0.0 if skip_old else bench(dg_old)
                 dx_old = dx.clone()
                 dx.zero_()
 
@@ -233,7 +234,7 @@ def main():
                     assert r is not NotImplemented
 
                 ms4 = bench(dg_new)
-                diff = (dx - dx_old).abs().max().item() / dx_old.abs().max().item()
+                diff = (dx - dx_old).abs().max().item() / max(dx_old.abs().max().item(), 1e-30)
                 line += f" | dgrad conv+pool {ms3*1e3:9.1f} us, pooled pass {ms4*1e3:9.1f} us {flops/ms4/1e9:7.1f} TF diff {diff:.1e}"
             if not up:
                 dx = torch.empty_like(x)
