@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGMR_ABI_VERSION 10
+#define DGMR_ABI_VERSION 11
 
 int dgmr_abi_version(void);
 const char* dgmr_last_error(void);
@@ -217,6 +217,14 @@ typedef struct dgmr_wgrad_args {
     int32_t groups;      /* >= 1, divides N and nsplit: consecutive N/groups samples form a group (one spectral-norm call:
                             forecast step / frame); a slab never straddles two groups */
     float* bias_grad;    /* NULL, or [Cout]: += column sums of dy (the conv's bias gradient) in the same pass */
+    /* -- ABI 11 -- deterministic bias gradient: a workspace of `bias_rows` rows of Cout floats (bias_rows as filled in by
+       dgmr_conv_wgrad_plan).  With it every slab's column sums land in a row of their own (or, for the kernels whose workgroups meet
+       in a channel, a fixed-order column-sum pass over dy fills the rows) and ONE thread per channel adds the rows up in order:
+       bias_grad is bit-identical from run to run.  NULL: the slabs' sums meet in float atomics (any order).  Required when
+       dgmr_set_deterministic(1) is in force and bias_grad != NULL. */
+    float* bias_partial;
+    int32_t bias_rows;
+    int32_t bias_stride; /* set by the library (0 / Cout); ignored on input */
 } dgmr_wgrad_args;
 
 /* Weight-gradient partial sums: partial[s] = dy[slab s]^T * im2col(pre(x))[slab s]. */
@@ -228,7 +236,11 @@ int dgmr_conv_wgrad_nsplit(int M, int Cout, int K, int groups);
 int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a);
 
 /* With P_q = sum of group q's slabs:  g[Cout*K] = sum_q scale[q] * P_q  (scale == NULL: 1);  dot[q] += <P_q, w>  (dot == NULL:
- * skipped; otherwise [groups], zeroed by the caller / the previous finalize).  groups <= 128. */
+ * skipped; otherwise [groups], zeroed by the caller / the previous finalize).  groups <= 128.
+ * ABI 11: `dot` holds dgmr_wgrad_dot_floats(groups) floats - `groups` normally; in deterministic mode groups * (1 + 1024): the
+ * workgroups leave their partial dots in rows of their own behind the first `groups` floats and one thread per group adds them up in
+ * order (otherwise they meet in float atomics). */
+int dgmr_wgrad_dot_floats(int groups);
 int dgmr_wgrad_reduce(const float* partial, int nsplit, int groups, int64_t numel, const float* w, const float* scale, float* g,
                       float* dot, void* stream);
 /* Same for a weight gradient computed on an input-channel slice: partial is [nsplit][Cout][taps][cin_slice]; element
@@ -347,7 +359,7 @@ int dgmr_pool_depth2(const float* x, const float* addend, float* y, int N, int D
  * several discriminator calls, each with its own random frame draw (discriminators.py:199), batched into one. */
 int dgmr_frames_s2d(const float* frames, const int32_t* idx, float* out, int B, int T, int C, int H, int W, int F, int pool,
                     int frame_major, int idx_group, void* stream);
-int dgmr_frames_s2d_bwd(const float* dout, const int32_t* idx, float* dframes /* accumulated */, int B, int T, int C, int H,
+int dgmr_frames_s2d_bwd(const float* dout, const int32_t* idx, float* dframes /* written, every element (ABI 11: gather form, no atomics) */, int B, int T, int C, int H,
                         int W, int F, int pool, int frame_major, int idx_group, void* stream);
 /* channels-last [B][h][w][4C] -> frames[b][t][c][2h][2w] (PixelShuffle(2)) and its backward. */
 int dgmr_d2s_frames(const float* x, float* frames, int B, int T, int t, int C, int h, int w, void* stream);
@@ -378,6 +390,22 @@ int dgmr_gru_blend_bwd(const float* dout, const float* pu, const float* h, const
 /* y = x * s[0] * host_scale   (s is a device scalar: an upstream gradient) */
 int dgmr_scale_by_dev(const float* x, const float* s, float host_scale, float* y, int64_t n, void* stream);
 /* y = alpha*a + beta*b (b may be NULL) */
+/* ------------------------------------------------------------------------------------------------
+ * (ABI 11) Deterministic mode.  on != 0: every cross-workgroup sum of the step is formed in a fixed order - bias gradients through
+ * dgmr_wgrad_args.bias_partial, <P_q, W> through the rows behind `dot`, per-channel statistics (dgmr_bn_stats, dgmr_bn_bwd_reduce,
+ * dgmr_colsum, dgmr_bn_partial_reduce, dgmr_grid_cell_loss) through per-workgroup partial rows in the caller's `sums` / `tmp` / `acc`
+ * buffer, which then holds dgmr_reduce_doubles(G, R, C) doubles instead of G*2*C.  Two identical runs then give bit-identical
+ * parameters and buffers (tests/test_gpu_determinism.py).  Off: those sums meet in float / double atomics. */
+int dgmr_set_deterministic(int on);
+int dgmr_get_deterministic(void);
+/* doubles the caller provides (zeroed) as `sums` / `tmp` / `acc` of a [G][R][C] per-channel reduction: G*2*C, or, in deterministic
+ * mode, (1 + nb) * G*2*C with nb = the number of row blocks the library will launch (<= 512, capped so that the buffer stays below 32 MB) */
+int64_t dgmr_reduce_doubles(int G, int64_t R, int C);
+/* (ABI 11) count += number of non-finite values (NaN, +-Inf) among x[0..n): the opt-in stand-in for the reference's
+ * torch.autograd.set_detect_anomaly(True) (dgmr/dgmr.py:130) - parameter gradients are written by kernels here, so autograd's anomaly
+ * mode cannot see them.  count: one int32 on the device, accumulated (zero it first). */
+int dgmr_nonfinite_count(const float* x, int64_t n, int32_t* count, void* stream);
+
 int dgmr_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream);
 /* dst[i][:] = src[:] for i < repeat, rows of n floats (n % 4 == 0): einops 'b c h w -> (repeat b) c h w' at b == 1
  * (generators.py:146-148) */
@@ -426,6 +454,8 @@ int dgmr_hinge_disc(const float* s_real, const float* s_gen, float* loss, float*
 /* loss = mult * sum_i |mean_k pred_k[i] - y[i]| * w[i];  pred_k = preds + k*pred_stride;  w = weights (explicit, [n]) or, when
  * weights == NULL, the reference's default weight_fn max(y[i]+1, cap) (dgmr/dgmr.py:20-33) evaluated in the kernel.
  * acc: one double, zero on entry, left zero.  dweight[i] (optional) = sign(.)*w/K, the per-prediction gradient / mult. */
+/* (ABI 11) doubles behind `acc` (zeroed by the caller): 1, or in deterministic mode 1 + the number of workgroups of the launch */
+int64_t dgmr_grid_cell_acc_doubles(int64_t n);
 int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_stride, const float* target, const float* weights, float cap,
                         double* acc, float* loss, float mult, float* dweight, int64_t n, void* stream);
 

@@ -8,7 +8,7 @@ from .common import ContextConditioningStack, LatentConditioningStack
 from .dgmr import DGMR
 from .discriminators import Discriminator, SpatialDiscriminator, TemporalDiscriminator
 from .generators import Generator, Sampler
-from .ops import get_precision, set_precision
+from .ops import deterministic, get_precision, set_deterministic, set_precision
 
 
 
@@ -31,5 +31,5 @@ def install_as(name: str = "dgmr"):
     return me
 
 
-__all__ = ["DGMR", "Generator", "Sampler", "Discriminator", "SpatialDiscriminator", "TemporalDiscriminator",
+__all__ = ["deterministic", "set_deterministic", "DGMR", "Generator", "Sampler", "Discriminator", "SpatialDiscriminator", "TemporalDiscriminator",
            "ContextConditioningStack", "LatentConditioningStack", "set_precision", "get_precision", "install_as"]

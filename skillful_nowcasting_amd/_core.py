@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 import torch
 from torch.autograd import Function
 
-from ._lib import ConvArgs, WgradArgs, call
+from ._lib import DETERMINISTIC_DEFAULT, ConvArgs, WgradArgs, call
 
 _WEIGHTS_EPOCH = 0  # bumped by the optimiser after every in-place parameter update (flip cache key)
 
@@ -35,6 +35,56 @@ def _p(t):
     if t is None or isinstance(t, int):
         return t
     return t.data_ptr()
+
+
+# ---- deterministic mode (dgmr_set_deterministic, include/dgmr_hip.h ABI 11) -----------------------------------------------------------
+# Every cross-workgroup sum of the step in a fixed order: two identical runs give bit-identical parameters and buffers.  The library
+# needs rows of scratch for it, which the caller owns like every other buffer: the helpers below size them.
+_DETERMINISTIC = DETERMINISTIC_DEFAULT  # (the library is put into the same mode when it is loaded, _lib.load)
+
+
+def set_deterministic(on: bool = True):
+    global _DETERMINISTIC
+    call("dgmr_set_deterministic", int(bool(on)))
+    _DETERMINISTIC = bool(on)
+
+
+def deterministic() -> bool:
+    return _DETERMINISTIC
+
+
+def sums_buffer(groups: int, rows: int, c: int, device, row_blocks: bool = True) -> torch.Tensor:
+    """`sums` / `tmp` of a per-channel reduction over [groups][rows][c]: groups * 2 * c doubles, zeroed; in deterministic mode followed
+    by the library's per-workgroup rows (dgmr_reduce_doubles; row_blocks=False: dgmr_bn_partial_reduce needs none)."""
+    n = groups * 2 * c
+    if not (_DETERMINISTIC and row_blocks):
+        return torch.zeros(n, device=device, dtype=torch.float64)
+    from ._lib import load
+
+    buf = torch.empty(int(load().dgmr_reduce_doubles(groups, rows, c)), device=device, dtype=torch.float64)
+    buf[:n].zero_()
+    return buf
+
+
+def dot_buffer(groups: int, device) -> torch.Tensor:
+    """<P_q, W> accumulators of dgmr_wgrad_reduce: `groups` floats, zeroed (+ the workgroups' rows in deterministic mode)."""
+    if not _DETERMINISTIC:
+        return torch.zeros(groups, device=device, dtype=torch.float32)
+    from ._lib import load
+
+    buf = torch.empty(int(load().dgmr_wgrad_dot_floats(groups)), device=device, dtype=torch.float32)
+    buf[:groups].zero_()
+    return buf
+
+
+def bias_rows(wa, device) -> Optional[torch.Tensor]:
+    """After dgmr_conv_wgrad_plan: the row workspace of the deterministic bias gradient (dgmr_wgrad_args.bias_partial); the caller keeps
+    the returned tensor alive until the launch has been issued (stream-ordered allocator: that is enough)."""
+    if not (_DETERMINISTIC and wa.bias_grad):
+        return None
+    rows = torch.empty(int(wa.bias_rows) * int(wa.Cout), device=device, dtype=torch.float32)
+    wa.bias_partial = rows.data_ptr()
+    return rows
 
 
 _SPLITK_WS = {}
@@ -244,8 +294,9 @@ def bn_prepare(x: torch.Tensor, gamma, beta, running_mean, running_var, num_batc
     mean = torch.empty(groups, c, device=dev)
     rstd = torch.empty(groups, c, device=dev)
     if train:
-        sums = torch.zeros(groups * 2 * c, device=dev, dtype=torch.float64)
-        if partials is not None and partials.shape[0] % groups == 0 and partials.shape[2] == c:
+        from_partials = partials is not None and partials.shape[0] % groups == 0 and partials.shape[2] == c
+        sums = sums_buffer(groups, r, c, dev, row_blocks=not from_partials)
+        if from_partials:
             # the conv that produced x already summed y and y^2 per pixel tile in its epilogue (`want_stats`): x is not read again
             call("dgmr_bn_partial_reduce", _p(partials), _p(sums), groups, partials.shape[0] // groups, c, _stream())
         else:

@@ -11,7 +11,8 @@ import torch
 from torch.autograd import Function
 
 from ._lib import ConvArgs, WgradArgs, call
-from ._core import BNState, SNCall, _copy, _dims, _p, _stream, bn_prepare, empty_cl, grad_buffer, require_hip, to_cl
+from ._core import (BNState, SNCall, _copy, _dims, _p, _stream, bn_prepare, dot_buffer, empty_cl, grad_buffer, require_hip, sums_buffer,
+                    to_cl)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -107,7 +108,7 @@ class BatchNorm1dFn(Function):
         n, c = x.shape
         dy = dy.contiguous()
         gq = st.groups
-        sums = torch.zeros(gq * 2 * c, device=x.device, dtype=torch.float64)
+        sums = sums_buffer(gq, n // gq, c, x.device)
         call("dgmr_bn_bwd_reduce", _p(dy), _p(x), _p(mean), _p(rstd), _p(sums), gq, n // gq, c, _stream())
         dx = torch.empty_like(x)
         dgam = grad_buffer(st.gamma) if st.gamma.requires_grad else None
@@ -151,7 +152,7 @@ class SNLinear1Fn(Function):
             b = grad_buffer(bias)
             call("dgmr_axpby", _p(b), _p(gb), _p(b), 1.0, 1.0, 1, st)
         if w.requires_grad:
-            dot = torch.zeros(gq, device=dev, dtype=torch.float32)
+            dot = dot_buffer(gq, dev)
             g2 = torch.empty(c, device=dev, dtype=torch.float32)
             call("dgmr_wgrad_reduce", _p(g), gq, gq, c, _p(w), _p(inv_sigma), _p(g2), _p(dot), st)
             call("dgmr_sn_wgrad_finalize", _p(g2), _p(grad_buffer(w)), _p(dot), _p(inv_sigma), _p(sn_u), _p(sn_v), 1, c, 1, gq, 1, st)
@@ -191,7 +192,7 @@ class MeanFn(Function):
         x = x.contiguous()
         n = x.numel()
         out = torch.empty((), device=x.device, dtype=torch.float32)
-        tmp = torch.empty(2, device=x.device, dtype=torch.float64)
+        tmp = sums_buffer(1, n, 1, x.device)
         call("dgmr_colsum", _p(x), _p(out), _p(tmp), n, 1, 0, _stream())
         call("dgmr_axpby", _p(out), None, _p(out), sign / n, 0.0, 1, _stream())
         ctx.n, ctx.sign, ctx.shape = n, sign, x.shape
@@ -220,7 +221,9 @@ class GridCellFn(Function):
         n = targets.numel()
         mult = float(targets.size(3) * targets.size(4)) / float(targets.size(1))
         loss = torch.empty((), device=preds.device, dtype=torch.float32)
-        acc = torch.zeros(1, device=preds.device, dtype=torch.float64)
+        from ._lib import load
+
+        acc = torch.zeros(int(load().dgmr_grid_cell_acc_doubles(n)), device=preds.device, dtype=torch.float64)
         dweight = torch.empty_like(targets)
         call("dgmr_grid_cell_loss", _p(preds), k, n, _p(targets), _p(weights), float(cap), _p(acc), _p(loss), mult, _p(dweight), n,
              _stream())

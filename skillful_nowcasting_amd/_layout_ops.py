@@ -12,7 +12,7 @@ import torch
 from torch.autograd import Function
 
 from ._lib import ConvArgs, WgradArgs, call
-from ._core import _copy, _dims, _p, _stream, empty_cl, require_hip, to_cl
+from ._core import _copy, _dims, _p, _stream, empty_cl, require_hip, sums_buffer, to_cl
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -81,7 +81,7 @@ class FramesS2DFn(Function):
     def backward(ctx, dout):
         b, t, c, h, w, f, pool, fm, idx_group = ctx.geom
         dout = to_cl(dout)
-        dfr = torch.zeros(b, t, c, h, w, device=dout.device, dtype=torch.float32)
+        dfr = torch.empty(b, t, c, h, w, device=dout.device, dtype=torch.float32)  # (the kernel writes every element)
         call("dgmr_frames_s2d_bwd", _p(dout), _p(ctx.idx), _p(dfr), b, t, c, h, w, f, pool, fm, idx_group, _stream())
         return dfr, None, None, None, None, None
 
@@ -185,7 +185,7 @@ class RepeatBatchFn(Function):
         dout = to_cl(dout)
         n = dout.numel() // ctx.repeat
         dx = empty_cl((dout.shape[0] // ctx.repeat,) + tuple(dout.shape[1:]), dout)
-        tmp = torch.empty(2 * n, device=dout.device, dtype=torch.float64)
+        tmp = sums_buffer(1, ctx.repeat, n, dout.device)
         call("dgmr_colsum", _p(dout), _p(dx), _p(tmp), ctx.repeat, n, 0, _stream())
         return dx, None
 
@@ -335,7 +335,7 @@ class SumGroupsFn(Function):
         x = x.contiguous()
         n = x.shape[0] // groups
         out = torch.empty(n, 1, device=x.device, dtype=torch.float32)
-        tmp = torch.empty(2 * n, device=x.device, dtype=torch.float64)
+        tmp = sums_buffer(1, groups, n, x.device)
         call("dgmr_colsum", _p(x), _p(out), _p(tmp), groups, n, 0, _stream())
         ctx.groups, ctx.n = groups, n
         return out

@@ -11,9 +11,11 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdgmr_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 P = c_void_p  # every device pointer and the stream travel as void*
+# deterministic mode (fixed-order cross-workgroup sums: bit-identical runs) is the default; DGMR_DETERMINISTIC=0 switches it off (A/B)
+DETERMINISTIC_DEFAULT = os.environ.get("DGMR_DETERMINISTIC", "1") != "0"
 
 
 class ConvArgs(Structure):
@@ -40,6 +42,7 @@ class WgradArgs(Structure):
         ("N", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
         ("KD", c_int32), ("KH", c_int32), ("KW", c_int32), ("upsample", c_int32), ("pre_relu", c_int32),
         ("pre_group", c_int32), ("nsplit", c_int32), ("groups", c_int32), ("bias_grad", P),
+        ("bias_partial", P), ("bias_rows", c_int32), ("bias_stride", c_int32),  # ABI 11: deterministic bias gradient
     ]
 
 
@@ -136,6 +139,10 @@ SIGNATURES = {
     "dgmr_split_weights": [P, P, L, i, i, i, i, L, P],
     "dgmr_conv_gates2_supported": [POINTER(ConvArgs)],
     "dgmr_set_precision": [i],
+    "dgmr_set_deterministic": [i],
+    "dgmr_get_deterministic": [],
+    "dgmr_wgrad_dot_floats": [i],
+    "dgmr_nonfinite_count": [P, L, P, P],
     "dgmr_debug_flags": [i],
     "dgmr_get_precision": [],
     "dgmr_profile_enable": [i],
@@ -146,6 +153,8 @@ SIGNATURES = {
     "dgmr_profile_collect_detail": [P, i],
 }
 del i, f, L
+# buffer sizes: these return int64_t
+SIGNATURES_I64 = {"dgmr_reduce_doubles": [c_int, c_int64, c_int], "dgmr_grid_cell_acc_doubles": [c_int64]}
 
 _lib = None
 
@@ -174,6 +183,11 @@ def load():
         fn.argtypes = argtypes
     lib.dgmr_profile_variant_name.restype = c_char_p
     lib.dgmr_profile_variant_name.argtypes = [c_int]
+    for name, argtypes in SIGNATURES_I64.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int64
+        fn.argtypes = argtypes
+    lib.dgmr_set_deterministic(int(DETERMINISTIC_DEFAULT))
     _lib = lib
     return lib
 

@@ -10,6 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void dgmr_set_error(const char* fmt, ...);
+extern int g_deterministic;  // dgmr_set_deterministic (ops.hip): fixed-order cross-workgroup sums
 
 #define DGMR_CHECK_ARG(cond, ...)        \
     do {                                 \

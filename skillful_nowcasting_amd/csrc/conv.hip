@@ -485,7 +485,7 @@ constexpr int WG_MAX_GROUPS = 128;
 template <int MAXG, bool VEC4 = true>
 __global__ __launch_bounds__(256, 2) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int groups, size_t numel,
                                     const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ g,
-                                    float* __restrict__ dot, int taps, int cs, int ct, int coff) {
+                                    float* __restrict__ dot, int taps, int cs, int ct, int coff, int dot_rows) {
     __shared__ float red[MAXG][4];
     const int spg = nsplit / groups;
     const size_t rowlen = (size_t)taps * cs;
@@ -556,8 +556,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_reduce_kernel(const float* __res
             }
         }
         __syncthreads();
-        if ((int)threadIdx.x < groups) atomicAdd(dot + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+        if ((int)threadIdx.x < groups) {
+            const float v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+            // deterministic mode: this workgroup's row behind the first `groups` floats of dot (wgrad_dot_finish_kernel adds the rows in order)
+            if (dot_rows) dot[(size_t)(1 + blockIdx.x) * groups + threadIdx.x] = v;
+            else atomicAdd(dot + threadIdx.x, v);
+        }
     }
+}
+
+// dot[q] += sum over workgroup rows b of dot[(1 + b) * groups + q], in order
+__global__ void wgrad_dot_finish_kernel(float* __restrict__ dot, int groups, int nb) {
+    const int q = threadIdx.x;
+    if (q >= groups) return;
+    float a = 0.f;
+    for (int b = 0; b < nb; ++b) a += dot[(size_t)(1 + b) * groups + q];
+    dot[q] += a;
 }
 
 // gw (+)= g - sum_grp dot[grp] * inv_sigma[grp]^2 * u[grp][co] * v[grp][perm(k)]   (g already carries the 1/sigma factors)
@@ -944,6 +958,40 @@ extern "C" int dgmr_conv_wgrad_nsplit(int M, int Cout, int K, int groups) {
     return (int)(per * groups);
 }
 
+// ---- deterministic bias gradient (dgmr_wgrad_args.bias_partial) ----
+// rows[b][c] = sum of dy[r][c] over the b-th of `nrows` contiguous row ranges: fixed order inside a thread (stride RL), then over the
+// RL row lanes in lane order.  For the weight-gradient kernels whose workgroups meet in a channel (wgrad_win.h, the im2col kernels).
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ dy, float* __restrict__ rows, int64_t M, int Cout, int nrows) {
+    __shared__ f32x4 part[256];
+    const int Cq = Cout / 4;
+    const int64_t per = (M + nrows - 1) / nrows;
+    const int64_t r0 = blockIdx.x * per, r1 = min(M, r0 + per);
+    for (int cb = 0; cb < Cq; cb += 256) {
+        const int Wd = min(256, Cq - cb), RL = 256 / Wd;
+        const int q = cb + (int)threadIdx.x % Wd, rl = threadIdx.x / Wd;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (rl < RL)
+            for (int64_t r = r0 + rl; r < r1; r += RL) a += *reinterpret_cast<const f32x4*>(dy + (size_t)r * Cout + q * 4);
+        part[threadIdx.x] = a;
+        __syncthreads();
+        if ((int)threadIdx.x < Wd) {
+            f32x4 t = part[threadIdx.x];
+            for (int k = 1; k < RL; ++k) t += part[threadIdx.x + k * Wd];
+            *reinterpret_cast<f32x4*>(rows + (size_t)blockIdx.x * Cout + q * 4) = t;
+        }
+        __syncthreads();
+    }
+}
+// bias_grad[c] += rows[0][c] + rows[1][c] + ... (in that order)
+__global__ void bias_rows_finish_kernel(const float* __restrict__ rows, int nrows, int Cout, float* __restrict__ bias_grad) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cout) return;
+    float a = 0.f;
+    for (int r = 0; r < nrows; ++r) a += rows[(size_t)r * Cout + c];
+    bias_grad[c] += a;
+}
+static inline int colsum_rows_for(int64_t M) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, M / 512)); }
+
 // the LDS-window weight gradient (wgrad_win.h) applies to 3x3 convs on 2-D maps made of whole rows of 32 (or 16) pixels, bf16 modes
 // which of the two window kernels: the wave-specialised one (wgrad_ws.h; dgmr_conv_tune wgrad_window 2: three matrix waves, 3 = automatic:
 // four matrix waves in bf16 / bf16x3, three in bf16x6) or the one-role kernel of round 2 (wgrad_win.h; 1)
@@ -980,6 +1028,7 @@ extern "C" int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a) {
     const int64_t M = (int64_t)a->N * a->D * a->H * a->W;
     if (!wgrad_uses_window(a)) {
         a->nsplit = dgmr_conv_wgrad_nsplit((int)M, a->Cout, a->KD * a->KH * a->KW * a->Cin, groups);
+        a->bias_rows = std::max(a->nsplit, colsum_rows_for(M));
         return 0;
     }
     // workgroups = 32-channel input chunks x output tiles x slabs.  Two are resident per CU: one full round (<= 512 workgroups)
@@ -996,6 +1045,7 @@ extern "C" int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a) {
     // larger partial sums cost what the fill gains: 999 vs 1000 - 1004 ms per step)
     if (wgrad_ws()) per = std::max<int64_t>(1, std::min<int64_t>(256 / ((int64_t)per_slab * groups), tiles_per_group / 2));
     a->nsplit = (int)std::min<int64_t>(per * groups, 4096) * (phases ? 4 : 1);
+    a->bias_rows = std::max(a->nsplit, colsum_rows_for(M));  // rows of dgmr_wgrad_args.bias_partial (deterministic bias gradient)
     return 0;
 }
 
@@ -1014,6 +1064,22 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
                    (long long)M64, a->Cin);
     dgmr_wgrad_args p = *a;
     if (p.pre_group < 1) p.pre_group = 1;
+    p.bias_stride = 0;
+    // deterministic bias gradient: rows of bias_partial instead of float atomics on bias_grad (dgmr_hip.h, ABI 11)
+    const bool bias_rows_mode = a->bias_grad && a->bias_partial;
+    DGMR_CHECK_ARG(!(g_deterministic && a->bias_grad) || bias_rows_mode, "dgmr_conv_wgrad: deterministic mode needs bias_partial for the bias gradient");
+    DGMR_CHECK_ARG(!bias_rows_mode || a->bias_rows >= std::max(a->nsplit, colsum_rows_for(M64)),
+                   "dgmr_conv_wgrad: bias_rows=%d (dgmr_conv_wgrad_plan fills it in)", a->bias_rows);
+    hipStream_t s_ = (hipStream_t)stream;
+    auto bias_rows_begin = [&](int rows) { (void)hipMemsetAsync(a->bias_partial, 0, sizeof(float) * (size_t)rows * a->Cout, s_); };
+    auto bias_rows_finish = [&](int rows) {
+        hipLaunchKernelGGL(bias_rows_finish_kernel, dim3((a->Cout + 255) / 256), dim3(256), 0, s_, a->bias_partial, rows, a->Cout, a->bias_grad);
+    };
+    auto bias_by_colsum = [&]() {  // kernels whose workgroups meet in a channel: a fixed-order column-sum pass over dy instead
+        const int rows = colsum_rows_for(M64);
+        hipLaunchKernelGGL(colsum_rows_kernel, dim3(rows), dim3(256), 0, s_, a->dy, a->bias_partial, M64, a->Cout, rows);
+        bias_rows_finish(rows);
+    };
     const int M = (int)M64, Ktot = a->KD * a->KH * a->KW * a->Cin;
     const int spg = a->nsplit / groups, rows_per_group = M / groups;
     int rows = (rows_per_group + spg - 1) / spg;
@@ -1035,11 +1101,14 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
         const int tiles_per_split = (tiles_per_group + spg4 - 1) / spg4;
         const bool b96 = a->Cout % 96 == 0;
         const dim3 grid((a->Cin + 31) / 32, b96 ? a->Cout / 96 : (a->Cout + 63) / 64, a->nsplit / 4);
+        if (bias_rows_mode) bias_rows_begin(a->nsplit);
         for (int ph = 0; ph < 4; ++ph) {  // (every parity holds a quarter of dY's pixels: the bias gradient adds up over the four launches)
+            if (bias_rows_mode) q.bias_grad = a->bias_partial + (size_t)ph * (a->nsplit / 4) * a->Cout, q.bias_stride = a->Cout;
             DGMR_BY_NS(launch_wgrad_window, q, grid, tw_shift, tiles_w, tiles_hw, tiles_per_split, spg4, tiles_per_group,
                        1 | ((g_debug_flags & 16) >> 3) | 4 | 8 | (ph << 16), s);
             DGMR_CHECK_LAUNCH();
         }
+        if (bias_rows_mode) bias_rows_finish(a->nsplit);
         return 0;
     }
     if (wgrad_uses_window(a)) {
@@ -1049,15 +1118,22 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
         const int tiles_per_split = (tiles_per_group + spg - 1) / spg;
         const bool b96 = a->Cout % 96 == 0;
         const dim3 grid((a->Cin + 31) / 32, b96 ? a->Cout / 96 : (a->Cout + 63) / 64, a->nsplit);
+        const bool rows_in_kernel = bias_rows_mode && wgrad_ws();  // (the wave-specialised kernel: one writer per slab and channel)
+        if (rows_in_kernel) bias_rows_begin(a->nsplit);
         for (int kd = 0; kd < a->KD; ++kd) {  // (3-D: one launch per depth tap; the bias gradient rides in the centre one, which skips no plane)
             dgmr_wgrad_args q = p;
             if (a->KD == 3 && kd != 1) q.bias_grad = nullptr;
+            else if (rows_in_kernel) q.bias_grad = a->bias_partial, q.bias_stride = a->Cout;
+            else if (bias_rows_mode) q.bias_grad = nullptr;
             DGMR_BY_NS(launch_wgrad_window, q, grid, tw_shift, tiles_w, tiles_hw, tiles_per_split, spg, tiles_per_group,
                        wgrad_ws() ? (1 | ((g_debug_flags & 16) >> 3) | (g_tune_wgrad_window != 2 && g_precision != 3 ? 4 : 0) | (kd << 8)) : 0, s);
             DGMR_CHECK_LAUNCH();
         }
+        if (rows_in_kernel) bias_rows_finish(a->nsplit);
+        else if (bias_rows_mode) bias_by_colsum();
         return 0;
     }
+    if (bias_rows_mode) p.bias_grad = nullptr;
     if (g_precision != 0) {
         // output-channel tile: 32 / 64 / 96 (96, 192, 288 channels: no idle MFMA rows) / 128
         const int bi = a->Cout <= 32 ? 32 : (a->Cout <= 64 ? 64 : ((a->Cout % 96 == 0 && a->Cout % 128 != 0) ? 96 : 128));
@@ -1073,9 +1149,12 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), dim3(kt, (a->Cout + 127) / 128, a->nsplit), dim3(256), 0, s, p,
                            M, Ktot, rows, spg, rows_per_group);
     }
+    if (bias_rows_mode) bias_by_colsum();
     DGMR_CHECK_LAUNCH();
     return 0;
 }
+
+extern "C" int dgmr_wgrad_dot_floats(int groups) { return g_deterministic ? std::max(groups, 1) * (1 + 1024) : std::max(groups, 1); }
 
 extern "C" int dgmr_wgrad_reduce(const float* partial, int nsplit, int groups, int64_t numel, const float* w, const float* scale,
                                  float* g, float* dot, void* stream) {
@@ -1087,10 +1166,12 @@ extern "C" int dgmr_wgrad_reduce(const float* partial, int nsplit, int groups, i
     const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 1024);
     if (groups <= 32)
         hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups,
-                           (size_t)numel, w, scale, g, dot, 1, 1, 1, 0);
+                           (size_t)numel, w, scale, g, dot, 1, 1, 1, 0, (dot && g_deterministic) ? 1 : 0);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel<WG_MAX_GROUPS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups,
-                           (size_t)numel, w, scale, g, dot, 1, 1, 1, 0);
+                           (size_t)numel, w, scale, g, dot, 1, 1, 1, 0, (dot && g_deterministic) ? 1 : 0);
+    if (dot && g_deterministic)
+        hipLaunchKernelGGL(wgrad_dot_finish_kernel, dim3(1), dim3(WG_MAX_GROUPS), 0, (hipStream_t)stream, dot, groups, blocks);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
@@ -1108,10 +1189,12 @@ extern "C" int dgmr_wgrad_reduce_slice(const float* partial, int nsplit, int gro
     // cs == ct would short-circuit the index map: force the mapped path whenever this is a true slice
     if (groups <= 32)
         hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups,
-                           (size_t)numel, w, scale, g, dot, taps, cin_slice, cin_total, coff);
+                           (size_t)numel, w, scale, g, dot, taps, cin_slice, cin_total, coff, (dot && g_deterministic) ? 1 : 0);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel<WG_MAX_GROUPS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups,
-                           (size_t)numel, w, scale, g, dot, taps, cin_slice, cin_total, coff);
+                           (size_t)numel, w, scale, g, dot, taps, cin_slice, cin_total, coff, (dot && g_deterministic) ? 1 : 0);
+    if (dot && g_deterministic)
+        hipLaunchKernelGGL(wgrad_dot_finish_kernel, dim3(1), dim3(WG_MAX_GROUPS), 0, (hipStream_t)stream, dot, groups, blocks);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

@@ -21,6 +21,12 @@ void dgmr_set_error(const char* fmt, ...) {
 }
 extern "C" const char* dgmr_last_error(void) { return g_err; }
 extern "C" int dgmr_abi_version(void) { return DGMR_ABI_VERSION; }
+int g_deterministic = 0;
+extern "C" int dgmr_set_deterministic(int on) {
+    g_deterministic = on ? 1 : 0;
+    return 0;
+}
+extern "C" int dgmr_get_deterministic(void) { return g_deterministic; }
 
 namespace {
 
@@ -394,7 +400,7 @@ __global__ void zero_kernel(float* p, int n) {
 // (mean^2 / var ~ 1e4), and float partial sums (6e-8 x 1e4 = 6e-4 on rstd) put a 1e-3 ... 1e-2 error on every gradient behind the
 // head (found by tests/test_gpu_stages.py::test_temporal_discriminator_backward_stages).  These kernels are HBM-bound either way.
 template <class F>
-__device__ __forceinline__ void chan_reduce2(F f, int64_t R, int C, double* __restrict__ out /* [G][2][C] */) {
+__device__ __forceinline__ void chan_reduce2(F f, int64_t R, int C, double* __restrict__ out /* [G][2][C] */, int det = 0) {
     __shared__ double l0[256], l1[256];
     const int g = blockIdx.y;
     const int64_t rows_per_block = (R + gridDim.x - 1) / gridDim.x;
@@ -415,21 +421,54 @@ __device__ __forceinline__ void chan_reduce2(F f, int64_t R, int C, double* __re
                 a0 += l0[threadIdx.x + k * Wd];
                 a1 += l1[threadIdx.x + k * Wd];
             }
-            atomicAdd(out + ((size_t)g * 2 + 0) * C + c, a0);
-            atomicAdd(out + ((size_t)g * 2 + 1) * C + c, a1);
+            if (det) {  // deterministic mode: row 1 + blockIdx.x of the caller's buffer; reduce_rows_finish_kernel adds the rows up in order
+                double* row = out + (size_t)(1 + blockIdx.x) * gridDim.y * 2 * C;
+                row[((size_t)g * 2 + 0) * C + c] = a0;
+                row[((size_t)g * 2 + 1) * C + c] = a1;
+            } else {
+                atomicAdd(out + ((size_t)g * 2 + 0) * C + c, a0);
+                atomicAdd(out + ((size_t)g * 2 + 1) * C + c, a1);
+            }
         }
         __syncthreads();
     }
 }
 
-__global__ void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int64_t R, int C) {
+// out[j] += sum over rows b = 0 .. nb-1 of out[(1 + b) * n + j], in that order (deterministic mode of the per-channel reductions)
+__global__ void reduce_rows_finish_kernel(double* __restrict__ out, int nb, int64_t n) {
+    GRID_STRIDE(j, n) {
+        double a = 0.0;
+        for (int b = 0; b < nb; ++b) a += out[(size_t)(1 + b) * n + j];
+        out[j] += a;
+    }
+}
+
+__global__ void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int64_t R, int C, int det) {
     chan_reduce2(
         [&](int64_t i, int, int, double& s0, double& s1) {
             const double v = (double)x[i];
             s0 += v;
             s1 = fma(v, v, s1);
         },
-        R, C, sums);
+        R, C, sums, det);
+}
+
+// deterministic bn_partial_reduce: one workgroup per (32 columns, group); 8 row lanes sum rows r = lane (mod 8) in order, then in lane order
+__global__ __launch_bounds__(256) void bn_partial_reduce_det_kernel(const float* __restrict__ partials, double* __restrict__ sums, int64_t R, int C2) {
+    __shared__ double part[8][32];
+    const int g = blockIdx.y, col = threadIdx.x & 31, lane = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + col;
+    double a = 0.0;
+    if (j < C2)
+        for (int64_t r = lane; r < R; r += 8) a += (double)partials[((size_t)g * R + r) * C2 + j];
+    part[lane][col] = a;
+    __syncthreads();
+    if (lane == 0 && j < C2) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][col];
+        sums[(size_t)g * C2 + j] += t;
+    }
 }
 
 // sums[g][k][c] += sum_r partials[(g*R + r)][k][c]: blockIdx.y = g, blockIdx.z = slice of the rows; one thread per (k, c)
@@ -454,7 +493,7 @@ __global__ void bn_bwd_center_kernel(double* __restrict__ sums, const float* __r
 }
 
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
-                                     const float* __restrict__ rstd, double* __restrict__ sums, int64_t R, int C) {
+                                     const float* __restrict__ rstd, double* __restrict__ sums, int64_t R, int C, int det) {
     chan_reduce2(
         [&](int64_t i, int g, int c, double& s0, double& s1) {
             const float gv = gy[i];
@@ -462,11 +501,11 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* 
             s0 += (double)gv;
             s1 = fma((double)gv, (double)xh, s1);
         },
-        R, C, sums);
+        R, C, sums, det);
 }
 
-__global__ void colsum_kernel(const float* __restrict__ x, double* __restrict__ sums, int64_t R, int C) {
-    chan_reduce2([&](int64_t i, int, int, double& s0, double&) { s0 += (double)x[i]; }, R, C, sums);
+__global__ void colsum_kernel(const float* __restrict__ x, double* __restrict__ sums, int64_t R, int C, int det) {
+    chan_reduce2([&](int64_t i, int, int, double& s0, double&) { s0 += (double)x[i]; }, R, C, sums, det);
 }
 
 // out[c] (+)= sum_r x[r][c] for FEW rows and MANY columns (one thread per 4 columns; colsum_kernel is for the opposite shape)
@@ -759,32 +798,38 @@ __global__ void frames_s2d_kernel(const float* __restrict__ fr, const int32_t* _
     }
 }
 
+// Gradient of frames_s2d as a GATHER over the pixels of dframes: every element sums the (at most F) selected frames that read it, in
+// frame order - no atomics, no zero-fill, bit-identical from run to run (the scatter form added duplicates of a randomly drawn
+// frame index in whatever order the workgroups arrived: three draws of one frame among the spatial discriminator's eight happen in
+// ~10 % of the steps).  dframes is WRITTEN, every element.
 __global__ void frames_s2d_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx, float* __restrict__ dfr,
                                       int B, int T, int C, int H, int W, int F, int p, int frame_major, int idx_group) {
     const int Ho = H / (2 * p), Wo = W / (2 * p), Co = 4 * C;
-    const int64_t total = (int64_t)B * F * Ho * Wo * Co;
+    const int64_t total = (int64_t)B * T * C * H * W;
     const float inv = 1.f / (float)(p * p);
     GRID_STRIDE(i, total) {
-        const int co = i % Co;
-        int64_t t = i / Co;
-        const int wo = t % Wo;
-        t /= Wo;
-        const int ho = t % Ho;
-        t /= Ho;
-        int b, f;
-        if (frame_major) {
-            b = t % B;
-            f = t / B;
-        } else {
-            f = t % F;
-            b = t / F;
+        const int x = i % W;
+        int64_t t = i / W;
+        const int y = t % H;
+        t /= H;
+        const int c = t % C;
+        t /= C;
+        const int tf = t % T;
+        const int b = t / T;
+        const int xo = x / p, yo = y / p;  // pixel of the (pooled) frame
+        const int wo = xo >> 1, dx = xo & 1, ho = yo >> 1, dy = yo & 1;
+        float g = 0.f;
+        if (ho < Ho && wo < Wo) {
+            const int co = (c << 2) | (dy << 1) | dx;
+            const int f_lo = idx ? 0 : tf, f_hi = idx ? F : min(tf + 1, F);  // no index list: frame f reads frame f
+            for (int f = f_lo; f < f_hi; ++f) {
+                const int src = idx ? idx[(b / idx_group) * F + f] : f;
+                if (src != tf) continue;
+                const int64_t n = frame_major ? (int64_t)f * B + b : (int64_t)b * F + f;
+                g += dout[((n * Ho + ho) * Wo + wo) * Co + co] * inv;
+            }
         }
-        const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
-        const int tf = idx ? idx[(b / idx_group) * F + f] : f;
-        float* dst = dfr + (((size_t)b * T + tf) * C + c) * H * W;
-        const float g = dout[i] * inv;
-        for (int py = 0; py < p; ++py)
-            for (int px = 0; px < p; ++px) atomicAdd(dst + (size_t)((2 * ho + dy) * p + py) * W + (2 * wo + dx) * p + px, g);
+        dfr[i] = g;
     }
 }
 
@@ -880,6 +925,15 @@ __global__ void gru_blend_bwd_kernel(const f32x4* __restrict__ dout, const f32x4
         dh[i] = b;
         dpc[i] = d;
     }
+}
+
+// count += number of NaN / Inf among x (exponent field all ones); integer atomics: order-independent
+__global__ void nonfinite_count_kernel(const float* __restrict__ x, int64_t n, int32_t* __restrict__ count) {
+    int bad = 0;
+    GRID_STRIDE(i, n) bad += ((__float_as_uint(x[i]) & 0x7f800000u) == 0x7f800000u) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
 }
 
 __global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, float alpha,
@@ -1084,7 +1138,7 @@ __global__ void hinge_disc_kernel(const float* __restrict__ s_real, const float*
 
 __global__ void grid_cell_kernel(const float* __restrict__ preds, int K, int64_t stride, const float* __restrict__ target,
                                  const float* __restrict__ weights, float cap, double* __restrict__ acc, float* __restrict__ dweight,
-                                 int64_t n) {
+                                 int64_t n, int det) {
     __shared__ float red[32];
     float s = 0.f;
     const float invK = 1.f / (float)K;
@@ -1099,10 +1153,14 @@ __global__ void grid_cell_kernel(const float* __restrict__ preds, int K, int64_t
         if (dweight) dweight[i] = (d > 0.f ? w : (d < 0.f ? -w : 0.f)) * invK;
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(acc, (double)s);
+    if (threadIdx.x == 0) {
+        if (det) acc[1 + blockIdx.x] = (double)s;  // deterministic mode: grid_cell_finish_kernel adds the workgroups' sums in order
+        else atomicAdd(acc, (double)s);
+    }
 }
 
-__global__ void grid_cell_finish_kernel(double* __restrict__ acc, float* __restrict__ loss, float mult) {
+__global__ void grid_cell_finish_kernel(double* __restrict__ acc, float* __restrict__ loss, float mult, int nb) {
+    for (int b = 0; b < nb; ++b) acc[0] += acc[1 + b];
     loss[0] = (float)(acc[0] * (double)mult);
     acc[0] = 0.0;
 }
@@ -1219,9 +1277,30 @@ static inline dim3 reduce_grid(int G, int64_t R) {
     return dim3((unsigned)bx, (unsigned)G);
 }
 
+// deterministic mode: row blocks of a [G][R][C] reduction = reduce_grid's, capped so that the (1 + nb) G 2 C doubles of the caller's buffer
+// stay below 32 MB
+static inline int det_blocks(int G, int64_t R, int C) {
+    const int64_t n = (int64_t)G * 2 * C;
+    const int64_t cap = std::max<int64_t>(1, (32ll << 20) / (n * 8));
+    return (int)std::min<int64_t>(reduce_grid(G, R).x, cap);
+}
+extern "C" int64_t dgmr_reduce_doubles(int G, int64_t R, int C) {
+    const int64_t n = (int64_t)std::max(G, 1) * 2 * C;
+    return g_deterministic ? (1 + (int64_t)det_blocks(std::max(G, 1), R, C)) * n : n;
+}
+static inline dim3 reduce_grid_mode(int G, int64_t R, int C) {
+    return g_deterministic ? dim3((unsigned)det_blocks(G, R, C), (unsigned)G) : reduce_grid(G, R);
+}
+static inline void reduce_finish(double* sums, int G, int64_t R, int C, hipStream_t s) {
+    if (!g_deterministic) return;
+    const int64_t n = (int64_t)G * 2 * C;
+    hipLaunchKernelGGL(reduce_rows_finish_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, sums, det_blocks(G, R, C), n);
+}
+
 extern "C" int dgmr_bn_stats(const float* x, double* sums, int G, int64_t R, int C, void* stream) {
     DGMR_CHECK_ARG(x && sums && G > 0 && R > 0 && C > 0, "dgmr_bn_stats: bad args");
-    hipLaunchKernelGGL(bn_stats_kernel, reduce_grid(G, R), dim3(256), 0, ST, x, sums, R, C);
+    hipLaunchKernelGGL(bn_stats_kernel, reduce_grid_mode(G, R, C), dim3(256), 0, ST, x, sums, R, C, g_deterministic);
+    reduce_finish(sums, G, R, C, ST);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
@@ -1229,6 +1308,11 @@ extern "C" int dgmr_bn_stats(const float* x, double* sums, int G, int64_t R, int
 extern "C" int dgmr_bn_partial_reduce(const float* partials, double* sums, int G, int64_t rows_per_group, int C, void* stream) {
     DGMR_CHECK_ARG(partials && sums && G > 0 && rows_per_group > 0 && C > 0, "dgmr_bn_partial_reduce: bad args");
     const int C2 = 2 * C;
+    if (g_deterministic) {
+        hipLaunchKernelGGL(bn_partial_reduce_det_kernel, dim3((C2 + 31) / 32, G), dim3(256), 0, ST, partials, sums, rows_per_group, C2);
+        DGMR_CHECK_LAUNCH();
+        return 0;
+    }
     int zs = (int)std::min<int64_t>(64, (rows_per_group + 31) / 32);  // >= 32 rows per slice
     hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((C2 + 255) / 256, G, zs), dim3(256), 0, ST, partials, sums, rows_per_group, C2);
     DGMR_CHECK_LAUNCH();
@@ -1256,7 +1340,8 @@ extern "C" int dgmr_bn_finalize(const double* sums, const float* gamma, const fl
 extern "C" int dgmr_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* rstd, double* sums, int G,
                                   int64_t R, int C, void* stream) {
     DGMR_CHECK_ARG(gy && x && mean && rstd && sums, "dgmr_bn_bwd_reduce: null pointer");
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, reduce_grid(G, R), dim3(256), 0, ST, gy, x, mean, rstd, sums, R, C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, reduce_grid_mode(G, R, C), dim3(256), 0, ST, gy, x, mean, rstd, sums, R, C, g_deterministic);
+    reduce_finish(sums, G, R, C, ST);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
@@ -1294,8 +1379,9 @@ extern "C" int dgmr_colsum(const float* x, float* out, double* tmp, int64_t R, i
         DGMR_CHECK_LAUNCH();
         return 0;
     }
-    (void)hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C, ST);
-    hipLaunchKernelGGL(colsum_kernel, reduce_grid(1, R), dim3(256), 0, ST, x, tmp, R, C);
+    (void)hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C, ST);  // (deterministic mode: tmp holds dgmr_reduce_doubles(1, R, C) doubles)
+    hipLaunchKernelGGL(colsum_kernel, reduce_grid_mode(1, R, C), dim3(256), 0, ST, x, tmp, R, C, g_deterministic);
+    reduce_finish(tmp, 1, R, C, ST);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, tmp, out, C, accumulate);
     DGMR_CHECK_LAUNCH();
     return 0;
@@ -1688,7 +1774,7 @@ extern "C" int dgmr_frames_s2d_bwd(const float* dout, const int32_t* idx, float*
     if (idx_group < 1) idx_group = B;
     DGMR_CHECK_ARG(dout && dframes, "dgmr_frames_s2d_bwd: null pointer");
     const int p = pool ? 2 : 1;
-    const int64_t total = (int64_t)B * F * (H / (2 * p)) * (W / (2 * p)) * 4 * C;
+    const int64_t total = (int64_t)B * T * C * H * W;
     hipLaunchKernelGGL(frames_s2d_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ST, dout, idx, dframes, B, T, C, H, W, F,
                        p, frame_major, idx_group);
     DGMR_CHECK_LAUNCH();
@@ -1748,6 +1834,13 @@ extern "C" int dgmr_gru_blend_bwd(const float* dout, const float* pu, const floa
     CHECK_N4(n);
     hipLaunchKernelGGL(gru_blend_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(EW_THREADS), 0, ST, (const f32x4*)dout, (const f32x4*)pu,
                        (const f32x4*)h, (const f32x4*)pc, (f32x4*)dpu, (f32x4*)dh, (f32x4*)dpc, n / 4);
+    DGMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dgmr_nonfinite_count(const float* x, int64_t n, int32_t* count, void* stream) {
+    DGMR_CHECK_ARG(x && count && n > 0, "dgmr_nonfinite_count: bad args");
+    hipLaunchKernelGGL(nonfinite_count_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, x, n, count);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
@@ -1846,12 +1939,14 @@ extern "C" int dgmr_hinge_disc(const float* s_real, const float* s_gen, float* l
     return 0;
 }
 
+extern "C" int64_t dgmr_grid_cell_acc_doubles(int64_t n) { return g_deterministic ? 1 + (int64_t)ew_blocks(n) : 1; }
+
 extern "C" int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_stride, const float* target, const float* weights, float cap,
                                    double* acc, float* loss, float mult, float* dweight, int64_t n, void* stream) {
     DGMR_CHECK_ARG(preds && target && acc && loss && K > 0 && n > 0, "dgmr_grid_cell_loss: bad args");
     hipLaunchKernelGGL(grid_cell_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, preds, K, pred_stride, target, weights, cap,
-                       acc, dweight, n);
-    hipLaunchKernelGGL(grid_cell_finish_kernel, dim3(1), dim3(1), 0, ST, acc, loss, mult);
+                       acc, dweight, n, g_deterministic);
+    hipLaunchKernelGGL(grid_cell_finish_kernel, dim3(1), dim3(1), 0, ST, acc, loss, mult, g_deterministic ? ew_blocks(n) : 0);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

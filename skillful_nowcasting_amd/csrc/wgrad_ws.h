@@ -487,7 +487,8 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
                     }
             }
         }
-        if (want_bias) {  // (deterministic within the workgroup; across workgroups one float atomic per channel, as in wgrad_win.h)
+        if (want_bias) {  // (deterministic within the workgroup; across workgroups one float atomic per channel - or, with
+                          //  dgmr_wgrad_args.bias_partial, a row of its own per slab that dgmr_conv_wgrad adds up in order)
             __syncthreads();  // the loaders have written their sums: slot i of thread lt covers channel quad (lt + i NL) mod YQ
             if (tid < BI && co0 + tid < p.Cout) {
                 const int q = tid >> 2, comp = tid & 3;
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
 #pragma unroll
                 for (int i = 0; i < BSN; ++i)
                     for (int l = ((q - i * NL) % YQ + YQ) % YQ; l < NL; l += YQ) total += red[(i * NL + l) * 4 + comp];
-                atomicAdd(p.bias_grad + co0 + tid, total);
+                atomicAdd(p.bias_grad + (size_t)slab * p.bias_stride + co0 + tid, total);  // (bias_stride = Cout: a row per slab, ONE writer per element)
             }
         }
     }

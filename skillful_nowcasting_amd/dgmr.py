@@ -184,7 +184,13 @@ class DGMR(
         # Important: This property activates manual optimization.
         self.automatic_optimization = False
         # NB the reference also flips torch.autograd.set_detect_anomaly(True) globally here (dgmr.py:130); that is a
-        # debugging aid which changes no value, so it is left to the caller.
+        # debugging aid which changes no value, so it is left to the caller.  Autograd's anomaly mode cannot see the parameter
+        # gradients here (kernels write them): `detect_anomaly` is the stand-in - after every backward pass the losses and every
+        # parameter gradient of the network just differentiated are scanned for NaN / Inf on the device (dgmr_nonfinite_count) and
+        # the first offender is named.  It synchronises the host once per backward pass: opt-in (or DGMR_DETECT_ANOMALY=1).
+        import os
+
+        self.detect_anomaly = os.environ.get("DGMR_DETECT_ANOMALY", "0") == "1"
 
     def forward(self, x):
         return self.generator(x)
@@ -292,6 +298,9 @@ class DGMR(
                 if self.grad_sync is not None:
                     self.grad_sync.abort()  # (no stale touch hook for whatever runs backward next)
                 raise
+            if self.detect_anomaly:
+                ops.join_side_streams()
+                self._check_finite("the discriminator pass", [discriminator_loss], self.discriminator)
             d_step_pending = True
         ######################
         # Optimize Generator #
@@ -313,6 +322,9 @@ class DGMR(
                 if self.grad_sync is not None:
                     self.grad_sync.abort()
                 raise
+            if self.detect_anomaly:
+                ops.join_side_streams()
+                self._check_finite("the generator pass", [generator_loss, grid_cell_reg], self.generator)
             if self.grad_sync is not None:
                 self.grad_sync.sync("g")
             g_opt.step()
@@ -368,6 +380,24 @@ class DGMR(
         self.grad_sync.broadcast_parameters()
         self.grad_sync.broadcast_buffers()
         return self.grad_sync
+
+    def _check_finite(self, what: str, losses, module):
+        """detect_anomaly: raise if a loss or a parameter gradient of `module` holds NaN / Inf (the reference's
+        torch.autograd.set_detect_anomaly(True), dgmr.py:130, raises from inside backward; here the scan follows it)."""
+        dev = losses[0].device
+        count = torch.zeros(1, device=dev, dtype=torch.int32)
+        flat = self.grad_sync.flat_for("g" if module is self.generator else "d").flat if self.grad_sync is not None else None
+        tensors = [l.detach().reshape(-1).float().contiguous() for l in losses]
+        tensors += [flat] if flat is not None else [p.grad for p in module.parameters() if p.grad is not None]
+        for t in tensors:
+            ops.call("dgmr_nonfinite_count", t.data_ptr(), t.numel(), count.data_ptr(), ops._stream())
+        if int(count.item()) == 0:
+            return
+        for name, p in module.named_parameters():  # slow path: name the first offender
+            if p.grad is not None and not bool(torch.isfinite(p.grad).all()):
+                raise RuntimeError(f"detect_anomaly: non-finite gradient in {what}: parameter '{name}' "
+                                   f"({int((~torch.isfinite(p.grad)).sum())} of {p.grad.numel()} elements)")
+        raise RuntimeError(f"detect_anomaly: non-finite loss in {what}: {[float(l) for l in losses]}")
 
     def configure_optimizers(self):
         """Two Adam optimisers, lr 5e-5 / 2e-4, betas (0.0, 0.999) by default (dgmr/dgmr.py:292-300)."""

@@ -26,8 +26,8 @@ from ._lib import ConvArgs, WgradArgs, call
 
 from . import _core, _streams
 from ._core import (BNState, CallLayout, SNCall, SPLITK_WS_BYTES, _copy, _dims, _p, _scratch, _splitk_ws, _stream, bn_prepare,  # noqa: F401
-                    bump_weights_epoch, call_slots, empty_cl, grad_buffer, require_hip, require_weight_layout, set_grad_touch_hook, to_cl,
-                    weights_epoch)
+                    bias_rows, bump_weights_epoch, call_slots, deterministic, dot_buffer, empty_cl, grad_buffer, require_hip,
+                    require_weight_layout, set_deterministic, set_grad_touch_hook, sums_buffer, to_cl, weights_epoch)
 from ._head_ops import (AttentionFn, AxpbyFn, BatchNorm1dFn, GridCellFn, HingeDiscFn, MeanFn, ReluSumHWFn, SNLinear1Fn, adam_update,  # noqa: F401
                         attention, axpby, relu_sum_hw)
 from ._layout_ops import (CatChannelsFn, D2SFramesFn, FramesS2DFn, FramesToBatchFn, PoolAddFn, RepeatBatchFn, StackBatchFn,  # noqa: F401
@@ -507,7 +507,7 @@ class ConvFn(Function):
         # ---- bias: column sums of dy ride along in the weight-gradient kernel; standalone only when W is frozen ----
         want_bias = bias is not None and bias.requires_grad
         if want_bias and not w.requires_grad:
-            tmp = torch.empty(2 * cout, device=dev, dtype=torch.float64)
+            tmp = sums_buffer(1, m, cout, dev)
             call("dgmr_colsum", _p(dy), _p(grad_buffer(bias)), _p(tmp), m, cout, 1, st)
         # ---- weight (and scale) ----
         groups = spec.groups
@@ -545,7 +545,9 @@ class ConvFn(Function):
                 ns = wa.nsplit
                 partial = torch.empty(ns * cout * k, device=dev, dtype=torch.float32)
                 wa.partial = _p(partial)
+                rows_ws = bias_rows(wa, dev)  # deterministic mode: the slabs' bias sums in rows of their own (kept alive past the launch)
                 call("dgmr_conv_wgrad", ctypes.byref(wa), st)
+                del rows_ws
                 if z9_bias is not None:
                     grad_buffer(bias).add_(z9_bias.view(cout, 9)[:, 4])
                 gw = grad_buffer(w)
@@ -555,7 +557,7 @@ class ConvFn(Function):
                     call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), None, None, None, None, cout, cin, taps, 1, 1, st)
                 else:
                     # g = sum_q P_q / sigma_q ; dot[q] = <P_q, W>   (P_q: raw weight gradient over the rows of call q)
-                    dot = torch.zeros(groups, device=dev, dtype=torch.float32)
+                    dot = dot_buffer(groups, dev)
                     call("dgmr_wgrad_reduce", _p(partial), ns, groups, cout * k, _p(w), _p(scale), _p(g), _p(dot), st)
                     if spec.sn is not None:
                         call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), _p(sn_u), _p(sn_v), cout, cin, taps, groups, 1, st)
@@ -605,8 +607,9 @@ class ConvFn(Function):
             else:
                 c = cin
                 r = x.numel() // (c * bn.groups)
-                sums = torch.zeros(bn.groups * 2 * c, device=dev, dtype=torch.float64)
-                if g_sums is not None and g_sums.shape[0] % bn.groups == 0:
+                from_partials = g_sums is not None and g_sums.shape[0] % bn.groups == 0
+                sums = sums_buffer(bn.groups, r, c, dev, row_blocks=not from_partials)
+                if from_partials:
                     call("dgmr_bn_partial_reduce", _p(g_sums), _p(sums), bn.groups, g_sums.shape[0] // bn.groups, c, st)
                     call("dgmr_bn_bwd_center", _p(sums), _p(bn_mean), _p(bn_rstd), bn.groups, c, st)
                 else:
@@ -683,10 +686,10 @@ class HeadFn(Function):
                 call("dgmr_wgrad_reduce", _p(w_part), nblk, 1, 4 * c, None, None, _p(g), None, st)
                 call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), None, None, None, None, 4, c, 1, 1, 1, st)
             else:
-                dot = torch.zeros(groups, device=dev, dtype=torch.float32)
+                dot = dot_buffer(groups, dev)
                 call("dgmr_wgrad_reduce", _p(w_part), nblk, groups, 4 * c, _p(w), _p(scale), _p(g), _p(dot), st)
                 call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), _p(dot), _p(scale), _p(sn_u), _p(sn_v), 4, c, 1, groups, 1, st)
-        sums = torch.zeros(groups * 2 * c, device=dev, dtype=torch.float64)
+        sums = sums_buffer(groups, nblk // groups, c, dev, row_blocks=False)
         call("dgmr_bn_partial_reduce", _p(bn_part), _p(sums), groups, nblk // groups, c, st)
         call("dgmr_bn_bwd_center", _p(sums), _p(bn_mean), _p(bn_rstd), groups, c, st)
         dx = empty_cl(x.shape, dy)
@@ -955,11 +958,11 @@ class ConvGRUFn(Function):
                 want_bias = bias is not None and bias.requires_grad
                 if not w.requires_grad:
                     if want_bias:
-                        tmpd = torch.empty(2 * ch, device=dev, dtype=torch.float64)
+                        tmpd = sums_buffer(1, m, ch, dev)
                         call("dgmr_colsum", _p(dp), _p(grad_buffer(bias)), _p(tmpd), m, ch, 1, st)
                     continue
                 g = torch.empty(ch * taps * ct, device=dev, dtype=torch.float32)
-                dot = torch.zeros(g_, device=dev, dtype=torch.float32)
+                dot = dot_buffer(g_, dev)
                 # x half: T*B maps, or (shared x) the T per-step sums against T copies of the one map; h half: always T*B maps
                 x_half = (x_rep, dsum[ki], TD, cx, 0) if x_shared else (x_all, dp, tb, cx, 0)
                 for src, dy, nimg, cin, coff in (x_half, (hsrc, dp, tb, ch, cx)):
@@ -974,7 +977,9 @@ class ConvGRUFn(Function):
                     ns = wa.nsplit
                     partial = torch.empty(ns * ch * k, device=dev, dtype=torch.float32)
                     wa.partial = _p(partial)
+                    rows_ws = bias_rows(wa, dev)
                     call("dgmr_conv_wgrad", ctypes.byref(wa), st)
+                    del rows_ws
                     call("dgmr_wgrad_reduce_slice", _p(partial), ns, g_, ch, taps, cin, ct, coff, _p(w), _p(inv_s), _p(g), _p(dot), st)
                 call("dgmr_sn_wgrad_finalize", _p(g), _p(grad_buffer(w)), _p(dot), _p(inv_s), _p(u_), _p(v_), ch, ct, taps, g_, 1, st)
 

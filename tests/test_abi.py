@@ -46,7 +46,7 @@ def test_ctypes_table_matches_header(lib):
     from skillful_nowcasting_amd import _lib
 
     declared = set(_declared_functions())
-    bound = set(_lib.SIGNATURES) | {"dgmr_abi_version", "dgmr_last_error", "dgmr_profile_variant_name"}
+    bound = set(_lib.SIGNATURES) | set(_lib.SIGNATURES_I64) | {"dgmr_abi_version", "dgmr_last_error", "dgmr_profile_variant_name"}
     assert declared == bound, f"header-only: {sorted(declared - bound)}  binding-only: {sorted(bound - declared)}"
     assert lib.dgmr_abi_version() == _lib.ABI_VERSION
 

@@ -213,9 +213,10 @@ def test_temporal_discriminator_backward_stages():
     assert not bad, f"beyond the bounds: {bad}\n{table}"
 
 
-def test_discriminators_on_96x96_inputs_floor_odd_maps_like_the_reference():
-    """96x96 frames reach DBlocks with 3x3 maps (spatial: 96 -> 48 -> 24 -> 12 -> 6 -> 3 -> 1; temporal: 6 frames -> 3 -> 1): the fused
-    DBlock tail must floor like nn.AvgPool2d / AvgPool3d (dgmr/common.py:186-189), forward and backward, as the oracle does."""
+def test_discriminators_on_160x160_inputs_floor_odd_maps_like_the_reference():
+    """160x160 frames reach DBlocks with 5x5 maps (spatial: 160 -> 80 -> 40 -> 20 -> 10 -> 5 -> 2 -> 1; temporal: 6 frames -> 3 -> 1, maps
+    40 -> 20 -> 10 -> 5 -> 2): the fused DBlock tail must floor like nn.AvgPool2d / AvgPool3d (dgmr/common.py:186-189), forward and
+    backward, as the oracle does (96x96 is too small for the reference itself: its fifth D-block would pool a 1x1 map)."""
     import skillful_nowcasting_amd as S
     from oracle import dgmr_oracle as O
 
@@ -223,7 +224,7 @@ def test_discriminators_on_96x96_inputs_floor_odd_maps_like_the_reference():
     disc = S.Discriminator(input_channels=1)
     sd = {k: v.detach().clone() for k, v in disc.state_dict().items()}
     disc = disc.cuda().train()
-    x = torch.rand(2, 6, 1, 96, 96)
+    x = torch.rand(2, 6, 1, 160, 160)
     for prec, tol in (("f32", 1e-3), ("mixed", 1e-3)):
         disc.load_state_dict(sd)
         S.set_precision(prec)

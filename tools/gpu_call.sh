@@ -3,7 +3,7 @@
 #   bash tools/gpu_call.sh <tag> [steps...]      steps, in the order given:
 #     tests:<pytest -k expression or file list>   selected -m gpu tests           -> pytest_<n>.log
 #     alltests                                    the whole -m gpu suite          -> pytest_all.log
-#     bench:<bench.py args>                       one bench line + detail file    -> bench_<n>.json / bench_<n>_detail.json
+#     bench:[VAR=v ...] <bench.py args>           one bench line + detail file (leading VAR=v words: environment)    -> bench_<n>.json / bench_<n>_detail.json
 #     prof:<bench.py args>                        rocprofv3 --kernel-trace --stats of a 1-step run (summaries only are kept)
 #     pmc                                         tools/r5_pmc.sh (counters for every conv class)
 #     convbench:<conv_bench.py args>              kernel micro-benchmarks         -> convbench_<n>.log
@@ -30,7 +30,9 @@ for STEP in "$@"; do
       timeout 1500 python -m pytest tests -m gpu -q ${PYTEST_FLAGS:-} > "$OUT/pytest_all.log" 2>&1; echo "[$n] alltests rc=$?"
       grep -E "^FAILED|^ERROR|passed|failed" "$OUT/pytest_all.log" | cut -c1-260 | head -20 ;;
     bench)
-      timeout 900 python bench.py $ARG --detail "gpurun_out/$TAG/bench_${n}_detail.json" > "$OUT/bench_$n.json" 2> "$OUT/bench_$n.err"; echo "[$n] bench rc=$?"
+      ENVV=""  # leading VAR=value words of the argument go to the environment (A/B switches)
+      while [[ "${ARG%% *}" == *=* && "${ARG%% *}" != --* ]]; do ENVV="$ENVV ${ARG%% *}"; ARG="${ARG#* }"; done
+      timeout 900 env $ENVV python bench.py $ARG --detail "gpurun_out/$TAG/bench_${n}_detail.json" > "$OUT/bench_$n.json" 2> "$OUT/bench_$n.err"; echo "[$n] bench rc=$?"
       tail -c 3500 "$OUT/bench_$n.json"; echo; tail -3 "$OUT/bench_$n.err" ;;
     prof)
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof$n" -o trace -- \
@@ -44,7 +46,7 @@ for STEP in "$@"; do
         && python tools/trace_gaps.py "$KT" "$OUT/prof_keep_$n/kernel_gaps.txt" 20 $LAST_MS
       rm -rf "$OUT/prof$n"; head -25 "$OUT/prof_keep_$n/kernel_stats_last_step.csv" | cut -c1-160 ;;
     pmc)
-      bash tools/r5_pmc.sh "$TAG/pmc" ;;
+      SKIP_STEP=${ARG:-0} bash tools/r5_pmc.sh "$TAG/pmc" ;;
     convbench)
       timeout 600 python tools/conv_bench.py $ARG > "$OUT/convbench_$n.log" 2>&1; echo "[$n] convbench rc=$?"; cut -c1-300 "$OUT/convbench_$n.log" ;;
     py)

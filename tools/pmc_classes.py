@@ -69,7 +69,8 @@ def main():
                          "whole training step of bench.py, paper config, per-GPU batch 16, `mixed`; dispatches run serialised under the "
                          "counter pass, so co-running weight-gradient launches do not dilute each other)"}
     fams = {}
-    tot_gui = sum(r.get("GRBM_GUI_ACTIVE", 0.0) for r in step)
+    # shares by kernel-trace DURATION: GRBM_GUI_ACTIVE of tiny launches also counts dispatch overhead under the counter pass
+    tot_gui = sum(r.get("total_ms", 0.0) for r in step)
     rows = []
     for r in step:
         fam = family(r["kernel"])
@@ -84,7 +85,7 @@ def main():
         f["ms"] += r.get("total_ms", 0.0)
         d = derive(r)
         d["family"] = fam
-        d["share_of_gpu_cycles"] = round(r.get("GRBM_GUI_ACTIVE", 0.0) / tot_gui, 4) if tot_gui else None
+        d["share_of_gpu_cycles"] = round(r.get("total_ms", 0.0) / tot_gui, 4) if tot_gui else None
         rows.append(d)
     if step:
         win = [f for k, f in fams.items() if k.startswith("3x3 window")]
@@ -96,7 +97,7 @@ def main():
             out["mfma_util_weighted_fwd_dgrad_only"] = round(fw["busy"] / (128.0 * fw["gui"]), 4)
         out["families"] = {k: {"mfma_busy": round(f["busy"] / (128.0 * f["gui"]), 4) if f["gui"] else None,
                                "valu_per_mfma": round(f["valu"] / f["mfma"], 2) if f["mfma"] else None, "dispatches": f["dispatches"],
-                               "share_of_gpu_cycles": round(f["gui"] / tot_gui, 4), "total_ms_under_counters": round(f["ms"], 1)}
+                               "share_of_gpu_cycles": round(f["ms"] / tot_gui, 4), "total_ms_under_counters": round(f["ms"], 1)}
                            for k, f in sorted(fams.items(), key=lambda kv: -kv[1]["gui"])}
         rows.sort(key=lambda d: -(d["share_of_gpu_cycles"] or 0))
         out["rows"] = [{k: d[k] for k in ("kernel", "grid", "dispatches", "total_ms", "mfma_busy", "valu_per_mfma", "share_of_gpu_cycles") if k in d}

@@ -22,12 +22,12 @@ if [ "${SKIP_STEP:-0}" != "1" ]; then
   [ -n "$F" ] && python "$ROOT/tools/pmc_agg.py" "$F" "$OUT/step_pmc_by_kernel.csv" $K
   rm -rf "$OUT/step"
 fi
-SHAPES=("full g4.first" "full g3.first" "full up_g4.last" "full up_g4.first" "full up_g3.first" "gru3.h-step B96" "gru4.h-step B96" "gru2.h-step B96" "tempD.d1.last 3d")
+SHAPES=("full g4.first" "full g3.first" "full up_g4.last" "full up_g4.first" "full up_g3.first" "gru3.h-step B96" "gru4.h-step B96" "gru2.h-step B96")
 i=0
 for CTRS in "$SETA" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   CONV_BENCH_SKIP_OLD=1 CONV_BENCH_ITERS=3 timeout 400 rocprofv3 --kernel-trace --pmc $CTRS -f csv -d "$OUT/m$i" -o pmc -- \
-      python "$ROOT/tools/conv_bench.py" --prec=bf16x3 --bwd --groups=108 --phases-only "${SHAPES[@]}" > "$OUT/modes_pass$i.log" 2>&1
+      python "$ROOT/tools/conv_bench.py" --prec=bf16x3 --bwd --groups=96 --phases-only "${SHAPES[@]}" > "$OUT/modes_pass$i.log" 2>&1
   echo "modes pass $i rc=$?"
   F=$(find "$OUT/m$i" -name '*counter_collection.csv' | head -1); K=$(find "$OUT/m$i" -name '*kernel_trace.csv' | head -1)
   [ -n "$F" ] && python "$ROOT/tools/pmc_agg.py" "$F" "$OUT/modes_pmc_pass$i.csv" $K conv wgrad
