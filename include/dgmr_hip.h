@@ -220,8 +220,8 @@ typedef struct dgmr_wgrad_args {
     /* -- ABI 11 -- deterministic bias gradient: a workspace of `bias_rows` rows of Cout floats (bias_rows as filled in by
        dgmr_conv_wgrad_plan).  With it every slab's column sums land in a row of their own (or, for the kernels whose workgroups meet
        in a channel, a fixed-order column-sum pass over dy fills the rows) and ONE thread per channel adds the rows up in order:
-       bias_grad is bit-identical from run to run.  NULL: the slabs' sums meet in float atomics (any order).  Required when
-       dgmr_set_deterministic(1) is in force and bias_grad != NULL. */
+       bias_grad is bit-identical from run to run.  NULL: the slabs' sums meet in float atomics (any order), whatever
+       dgmr_set_deterministic says - the rows are the caller's to provide. */
     float* bias_partial;
     int32_t bias_rows;
     int32_t bias_stride; /* set by the library (0 / Cout); ignored on input */

@@ -1067,7 +1067,7 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
     p.bias_stride = 0;
     // deterministic bias gradient: rows of bias_partial instead of float atomics on bias_grad (dgmr_hip.h, ABI 11)
     const bool bias_rows_mode = a->bias_grad && a->bias_partial;
-    DGMR_CHECK_ARG(!(g_deterministic && a->bias_grad) || bias_rows_mode, "dgmr_conv_wgrad: deterministic mode needs bias_partial for the bias gradient");
+    // (deterministic mode without bias_partial: the float-atomic path - the caller's choice; the package always passes the rows)
     DGMR_CHECK_ARG(!bias_rows_mode || a->bias_rows >= std::max(a->nsplit, colsum_rows_for(M64)),
                    "dgmr_conv_wgrad: bias_rows=%d (dgmr_conv_wgrad_plan fills it in)", a->bias_rows);
     hipStream_t s_ = (hipStream_t)stream;
@@ -1133,12 +1133,19 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
         else if (bias_rows_mode) bias_by_colsum();
         return 0;
     }
-    if (bias_rows_mode) p.bias_grad = nullptr;
+    if (bias_rows_mode && g_precision != 0) {
+        // conv_wgrad_bf16_kernel: ONE thread per (slab, channel) adds the slab's column sum - into a row of its own per slab (blockIdx.z)
+        bias_rows_begin(a->nsplit);
+        p.bias_grad = a->bias_partial, p.bias_stride = a->Cout;
+    } else if (bias_rows_mode) {
+        p.bias_grad = nullptr;  // conv_wgrad_kernel (exact f32): several threads of a workgroup meet in a channel - column-sum pass instead
+    }
     if (g_precision != 0) {
         // output-channel tile: 32 / 64 / 96 (96, 192, 288 channels: no idle MFMA rows) / 128
         const int bi = a->Cout <= 32 ? 32 : (a->Cout <= 64 ? 64 : ((a->Cout % 96 == 0 && a->Cout % 128 != 0) ? 96 : 128));
         const dim3 grid(kt, (a->Cout + bi - 1) / bi, a->nsplit);
         DGMR_BY_NS(launch_wgrad_gemm, p, bi, grid, M, Ktot, rows, spg, rows_per_group, s);
+        if (bias_rows_mode) bias_rows_finish(a->nsplit);
     } else if (a->Cout <= 32) {
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), dim3(kt, (a->Cout + 31) / 32, a->nsplit), dim3(256), 0, s, p, M,
                            Ktot, rows, spg, rows_per_group);
@@ -1149,7 +1156,7 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), dim3(kt, (a->Cout + 127) / 128, a->nsplit), dim3(256), 0, s, p,
                            M, Ktot, rows, spg, rows_per_group);
     }
-    if (bias_rows_mode) bias_by_colsum();
+    if (bias_rows_mode && g_precision == 0) bias_by_colsum();
     DGMR_CHECK_LAUNCH();
     return 0;
 }

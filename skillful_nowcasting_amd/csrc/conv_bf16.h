@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const dgmr_wgra
             v += __shfl_xor(v, 1, 64);
             v += __shfl_xor(v, 2, 64);
             v += __shfl_xor(v, 4, 64);
-            if (mg == 0 && y_on) atomicAdd(p.bias_grad + co + c, v);
+            if (mg == 0 && y_on) atomicAdd(p.bias_grad + (size_t)blockIdx.z * p.bias_stride + co + c, v);  // (bias_stride = Cout: a row per slab, one writer)
         }
     }
 }

@@ -42,9 +42,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 // ------------------------------------------------------------------------------------------------
 // spectral norm
 // ------------------------------------------------------------------------------------------------
-// t[i] = sum_k w[i][k] * v[perm(k)]; scratch[0] += (u_for_dot ? u[i]*t[i] : t[i]^2)
-__global__ void sn_rows_kernel(const float* __restrict__ w, const float* __restrict__ v, const float* __restrict__ u_for_dot,
-                               float* __restrict__ t, float* __restrict__ scratch, int K, int Cin, int taps) {
+// t[i] = sum_k w[i][k] * v[perm(k)].  (Round 5: the norms / dots over t that used to meet in float atomics on `scratch` are recomputed
+// by their consumers in a fixed order - the first, traced forward of a module went through these kernels and was the last source of
+// run-to-run differences; `scratch` stays in the signatures and is left untouched.)
+__global__ void sn_rows_kernel(const float* __restrict__ w, const float* __restrict__ v, float* __restrict__ t, int K, int Cin, int taps) {
     __shared__ float red[32];
     const int i = blockIdx.x;
     const float* wr = w + (size_t)i * K;
@@ -56,10 +57,14 @@ __global__ void sn_rows_kernel(const float* __restrict__ w, const float* __restr
         for (int j = 0; j < 4; ++j) s = fmaf(wv[j], v[(size_t)(ci + j) * taps + tp], s);
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) {
-        t[i] = s;
-        atomicAdd(scratch, u_for_dot ? u_for_dot[i] * s : s * s);
-    }
+    if (threadIdx.x == 0) t[i] = s;
+}
+
+// sum_i a[i] * b[i] over n values, the same fixed order in every workgroup that calls it (strided per thread, then block_sum)
+__device__ __forceinline__ float sn_dot_fixed(const float* __restrict__ a, const float* __restrict__ b, int n, float* red) {
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) q = fmaf(a[i], b[i], q);
+    return block_sum(q, red);
 }
 
 // s[k] = sum_i w[i][k] * t[i] / max(||t||, eps); block 0 also writes u = t / max(||t||, eps); scratch[1] += s^2
@@ -68,7 +73,7 @@ __global__ void sn_cols_kernel(const float* __restrict__ w, const float* __restr
                                float eps) {
     __shared__ float part[4][64];
     __shared__ float red[32];
-    const float inv = 1.f / fmaxf(sqrtf(scratch[0]), eps);
+    const float inv = 1.f / fmaxf(sqrtf(sn_dot_fixed(t, t, Cout, red)), eps);
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + c;
     float s = 0.f;
@@ -76,14 +81,7 @@ __global__ void sn_cols_kernel(const float* __restrict__ w, const float* __restr
         for (int i = rg; i < Cout; i += 4) s = fmaf(w[(size_t)i * K + k], t[i] * inv, s);
     part[rg][c] = s;
     __syncthreads();
-    float sq = 0.f;
-    if (rg == 0 && k < K) {
-        s = part[0][c] + part[1][c] + part[2][c] + part[3][c];
-        s_out[k] = s;
-        sq = s * s;
-    }
-    sq = block_sum(sq, red);
-    if (threadIdx.x == 0) atomicAdd(scratch + 1, sq);
+    if (rg == 0 && k < K) s_out[k] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < Cout; i += blockDim.x) {
             const float ui = t[i] * inv;
@@ -96,7 +94,8 @@ __global__ void sn_cols_kernel(const float* __restrict__ w, const float* __restr
 __global__ void sn_finish_train_kernel(const float* __restrict__ s, float* __restrict__ v, float* __restrict__ v_save,
                                        float* __restrict__ inv_sigma, const float* __restrict__ scratch, int K, int Cin, int taps,
                                        float eps) {
-    const float n2 = scratch[1];
+    __shared__ float red[32];
+    const float n2 = sn_dot_fixed(s, s, K, red);  // ||s||^2, recomputed by every workgroup in the same order
     const float d = fmaxf(sqrtf(n2), eps);
     const float inv = 1.f / d;
     GRID_STRIDE(k, K) {
@@ -111,14 +110,16 @@ __global__ void sn_finish_train_kernel(const float* __restrict__ s, float* __res
 
 __global__ void sn_finish_eval_kernel(const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ u_save,
                                       float* __restrict__ v_save, float* __restrict__ inv_sigma,
-                                      const float* __restrict__ scratch, int Cout, int K) {
+                                      const float* __restrict__ t, int Cout, int K) {
+    __shared__ float red[32];
+    const float sigma = sn_dot_fixed(u, t, Cout, red);  // u^T W v
     GRID_STRIDE(i, (int64_t)Cout + K) {
         if (i < Cout) {
             if (u_save) u_save[i] = u[i];
         } else if (v_save)
             v_save[i - Cout] = v[i - Cout];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) inv_sigma[0] = 1.f / scratch[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv_sigma[0] = 1.f / sigma;
 }
 
 
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(1024) void sn_gram_chain_kernel(const float* __rest
     float* red = sh + 2 * Cout;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     {
-        const float inv = 1.f / fmaxf(sqrtf(scratch[0]), eps);
+        const float inv = 1.f / fmaxf(sqrtf(sn_dot_fixed(t0, t0, Cout, red)), eps);  // (was scratch[0]: float atomics of sn_rows_kernel)
         for (int i = threadIdx.x; i < Cout; i += blockDim.x) ucur[i] = t0[i] * inv;
     }
     __syncthreads();
@@ -1220,14 +1221,14 @@ extern "C" int dgmr_spectral_sigma(const float* w, float* u, float* v, float* u_
     float* t = tmp;
     float* s = tmp + Cout;
     if (train) {
-        hipLaunchKernelGGL(sn_rows_kernel, dim3(Cout), dim3(256), 0, ST, w, v, (const float*)nullptr, t, scratch, K, Cin, taps);
+        hipLaunchKernelGGL(sn_rows_kernel, dim3(Cout), dim3(256), 0, ST, w, v, t, K, Cin, taps);
         hipLaunchKernelGGL(sn_cols_kernel, dim3((K + 63) / 64), dim3(256), 0, ST, w, t, s, u, u_save, scratch, Cout, K, eps);
         hipLaunchKernelGGL(sn_finish_train_kernel, dim3(std::min((K + 255) / 256, 64)), dim3(256), 0, ST, s, v, v_save, inv_sigma,
                            scratch, K, Cin, taps, eps);
     } else {
-        hipLaunchKernelGGL(sn_rows_kernel, dim3(Cout), dim3(256), 0, ST, w, v, (const float*)u, t, scratch, K, Cin, taps);
+        hipLaunchKernelGGL(sn_rows_kernel, dim3(Cout), dim3(256), 0, ST, w, v, t, K, Cin, taps);
         hipLaunchKernelGGL(sn_finish_eval_kernel, dim3(std::min((Cout + K + 255) / 256, 64)), dim3(256), 0, ST, u, v, u_save, v_save,
-                           inv_sigma, scratch, Cout, K);
+                           inv_sigma, t, Cout, K);
     }
     hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, ST, scratch, 4);
     DGMR_CHECK_LAUNCH();
@@ -1245,7 +1246,7 @@ extern "C" int dgmr_spectral_sigma_seq(const float* w, const float* gram, float*
     const int K = Cin * taps;
     float* t0 = tmp;           // [Cout]
     float* dnorm = tmp + Cout; // [T]
-    hipLaunchKernelGGL(sn_rows_kernel, dim3(Cout), dim3(256), 0, ST, w, v, (const float*)nullptr, t0, scratch, K, Cin, taps);
+    hipLaunchKernelGGL(sn_rows_kernel, dim3(Cout), dim3(256), 0, ST, w, v, t0, K, Cin, taps);
     const int threads = Cout >= 512 ? 1024 : (Cout >= 128 ? 512 : 256);
     hipLaunchKernelGGL(sn_gram_chain_kernel, dim3(1), dim3(threads), (2 * Cout + 32) * sizeof(float), ST, gram, t0, scratch, u,
                        u_hist, dnorm, inv_sigma, Cout, T, eps);
