@@ -565,13 +565,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_reduce_kernel(const float* __res
     }
 }
 
-// dot[q] += sum over workgroup rows b of dot[(1 + b) * groups + q], in order
-__global__ void wgrad_dot_finish_kernel(float* __restrict__ dot, int groups, int nb) {
-    const int q = threadIdx.x;
-    if (q >= groups) return;
+// dot[q] += sum over workgroup rows b of dot[(1 + b) * groups + q] in a FIXED order: eight lanes per group take rows b = lane (mod 8)
+// in increasing order, then the eight partial sums are added in lane order (1024 rows as 128 dependent adds instead of 1024)
+__global__ __launch_bounds__(1024) void wgrad_dot_finish_kernel(float* __restrict__ dot, int groups, int nb) {
+    __shared__ float part[8][WG_MAX_GROUPS];
+    const int q = threadIdx.x & (WG_MAX_GROUPS - 1), l = threadIdx.x / WG_MAX_GROUPS;
     float a = 0.f;
-    for (int b = 0; b < nb; ++b) a += dot[(size_t)(1 + b) * groups + q];
-    dot[q] += a;
+    if (q < groups) {
+        int b = l;
+        for (; b + 56 < nb; b += 64) {  // eight independent loads in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = dot[(size_t)(1 + b + 8 * k) * groups + q];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += v[k];
+        }
+        for (; b < nb; b += 8) a += dot[(size_t)(1 + b) * groups + q];
+    }
+    part[l][q] = a;
+    __syncthreads();
+    if (l == 0 && q < groups) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][q];
+        dot[q] += t;
+    }
 }
 
 // gw (+)= g - sum_grp dot[grp] * inv_sigma[grp]^2 * u[grp][co] * v[grp][perm(k)]   (g already carries the 1/sigma factors)
@@ -982,13 +1000,27 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
         __syncthreads();
     }
 }
-// bias_grad[c] += rows[0][c] + rows[1][c] + ... (in that order)
-__global__ void bias_rows_finish_kernel(const float* __restrict__ rows, int nrows, int Cout, float* __restrict__ bias_grad) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cout) return;
+// bias_grad[c] += sum of rows[r][c] in a fixed order: four lanes per channel take rows r = lane (mod 4) in increasing order, then the
+// four partial sums are added in lane order
+__global__ __launch_bounds__(256) void bias_rows_finish_kernel(const float* __restrict__ rows, int nrows, int Cout, float* __restrict__ bias_grad) {
+    __shared__ float part[4][64];
+    const int col = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + col;
     float a = 0.f;
-    for (int r = 0; r < nrows; ++r) a += rows[(size_t)r * Cout + c];
-    bias_grad[c] += a;
+    if (c < Cout) {
+        int r = l;
+        for (; r + 28 < nrows; r += 32) {  // eight independent loads in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = rows[(size_t)(r + 4 * k) * Cout + c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += v[k];
+        }
+        for (; r < nrows; r += 4) a += rows[(size_t)r * Cout + c];
+    }
+    part[l][col] = a;
+    __syncthreads();
+    if (l == 0 && c < Cout) bias_grad[c] += (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 static inline int colsum_rows_for(int64_t M) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, M / 512)); }
 
@@ -1073,7 +1105,7 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
     hipStream_t s_ = (hipStream_t)stream;
     auto bias_rows_begin = [&](int rows) { (void)hipMemsetAsync(a->bias_partial, 0, sizeof(float) * (size_t)rows * a->Cout, s_); };
     auto bias_rows_finish = [&](int rows) {
-        hipLaunchKernelGGL(bias_rows_finish_kernel, dim3((a->Cout + 255) / 256), dim3(256), 0, s_, a->bias_partial, rows, a->Cout, a->bias_grad);
+        hipLaunchKernelGGL(bias_rows_finish_kernel, dim3((a->Cout + 63) / 64), dim3(256), 0, s_, a->bias_partial, rows, a->Cout, a->bias_grad);
     };
     auto bias_by_colsum = [&]() {  // kernels whose workgroups meet in a channel: a fixed-order column-sum pass over dy instead
         const int rows = colsum_rows_for(M64);
@@ -1178,7 +1210,7 @@ extern "C" int dgmr_wgrad_reduce(const float* partial, int nsplit, int groups, i
         hipLaunchKernelGGL(wgrad_reduce_kernel<WG_MAX_GROUPS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups,
                            (size_t)numel, w, scale, g, dot, 1, 1, 1, 0, (dot && g_deterministic) ? 1 : 0);
     if (dot && g_deterministic)
-        hipLaunchKernelGGL(wgrad_dot_finish_kernel, dim3(1), dim3(WG_MAX_GROUPS), 0, (hipStream_t)stream, dot, groups, blocks);
+        hipLaunchKernelGGL(wgrad_dot_finish_kernel, dim3(1), dim3(8 * WG_MAX_GROUPS), 0, (hipStream_t)stream, dot, groups, blocks);
     DGMR_CHECK_LAUNCH();
     return 0;
 }
@@ -1201,7 +1233,7 @@ extern "C" int dgmr_wgrad_reduce_slice(const float* partial, int nsplit, int gro
         hipLaunchKernelGGL(wgrad_reduce_kernel<WG_MAX_GROUPS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, nsplit, groups,
                            (size_t)numel, w, scale, g, dot, taps, cin_slice, cin_total, coff, (dot && g_deterministic) ? 1 : 0);
     if (dot && g_deterministic)
-        hipLaunchKernelGGL(wgrad_dot_finish_kernel, dim3(1), dim3(WG_MAX_GROUPS), 0, (hipStream_t)stream, dot, groups, blocks);
+        hipLaunchKernelGGL(wgrad_dot_finish_kernel, dim3(1), dim3(8 * WG_MAX_GROUPS), 0, (hipStream_t)stream, dot, groups, blocks);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

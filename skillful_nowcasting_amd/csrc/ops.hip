@@ -1160,8 +1160,22 @@ __global__ void grid_cell_kernel(const float* __restrict__ preds, int K, int64_t
     }
 }
 
-__global__ void grid_cell_finish_kernel(double* __restrict__ acc, float* __restrict__ loss, float mult, int nb) {
-    for (int b = 0; b < nb; ++b) acc[0] += acc[1 + b];
+__global__ __launch_bounds__(256) void grid_cell_finish_kernel(double* __restrict__ acc, float* __restrict__ loss, float mult, int nb) {
+    // deterministic mode: the workgroups' sums acc[1 .. nb] in a fixed order - thread t takes rows b = t (mod 256) in increasing order,
+    // thread 0 adds the 256 partial sums in thread order
+    __shared__ double part[256];
+    if (nb > 0) {
+        double a = 0.0;
+        for (int b = threadIdx.x; b < nb; b += 256) a += acc[1 + b];
+        part[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int k = 0; k < 256; ++k) t += part[k];
+            acc[0] += t;
+        }
+    }
+    if (threadIdx.x != 0) return;
     loss[0] = (float)(acc[0] * (double)mult);
     acc[0] = 0.0;
 }
@@ -1947,7 +1961,7 @@ extern "C" int dgmr_grid_cell_loss(const float* preds, int K, int64_t pred_strid
     DGMR_CHECK_ARG(preds && target && acc && loss && K > 0 && n > 0, "dgmr_grid_cell_loss: bad args");
     hipLaunchKernelGGL(grid_cell_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, preds, K, pred_stride, target, weights, cap,
                        acc, dweight, n, g_deterministic);
-    hipLaunchKernelGGL(grid_cell_finish_kernel, dim3(1), dim3(1), 0, ST, acc, loss, mult, g_deterministic ? ew_blocks(n) : 0);
+    hipLaunchKernelGGL(grid_cell_finish_kernel, dim3(1), dim3(256), 0, ST, acc, loss, mult, g_deterministic ? ew_blocks(n) : 0);
     DGMR_CHECK_LAUNCH();
     return 0;
 }

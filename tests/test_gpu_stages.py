@@ -224,7 +224,9 @@ def test_discriminators_on_160x160_inputs_floor_odd_maps_like_the_reference():
     disc = S.Discriminator(input_channels=1)
     sd = {k: v.detach().clone() for k, v in disc.state_dict().items()}
     disc = disc.cuda().train()
-    x = torch.rand(2, 6, 1, 160, 160)
+    # eight samples: the heads' BatchNorm1d over a batch of two maps every feature to +-1 and its input gradient to rounding noise
+    x = torch.rand(8, 6, 1, 160, 160)
+    wgt = torch.randn(8, 2, 1)
     for prec, tol in (("f32", 1e-3), ("mixed", 1e-3)):
         disc.load_state_dict(sd)
         S.set_precision(prec)
@@ -232,7 +234,7 @@ def test_discriminators_on_160x160_inputs_floor_odd_maps_like_the_reference():
             torch.manual_seed(9)
             xg = x.cuda().requires_grad_(True)
             out = disc(xg)
-            out.sum().backward()
+            (out * wgt.cuda()).sum().backward()
             torch.cuda.synchronize()
         finally:
             S.set_precision("f32")
@@ -240,9 +242,11 @@ def test_discriminators_on_160x160_inputs_floor_odd_maps_like_the_reference():
         idxs = torch.randint(0, 6, (8,)).tolist()
         xr = x.clone().requires_grad_(True)
         ref = O.discriminator({k: v.clone() for k, v in sd.items()}, "", xr, idxs, True)
-        ref.sum().backward()
-        assert out.shape == ref.shape == (2, 2, 1)
+        (ref * wgt).sum().backward()
+        assert out.shape == ref.shape == (8, 2, 1)
         err = (out.detach().cpu() - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
         assert err <= tol, f"{prec}: discriminator forward on odd maps {err:.2e}"
         gerr = (xg.grad.cpu() - xr.grad).abs().max().item() / xr.grad.abs().max().item()
-        assert gerr <= 5e-3, f"{prec}: input gradient on odd maps {gerr:.2e}"
+        cos = torch.nn.functional.cosine_similarity(xg.grad.cpu().double().reshape(-1), xr.grad.double().reshape(-1), dim=0).item()
+        # (relu kinks are not aligned here: a handful of flipped units on 2x2 / 1x1 maps move single gradient entries; direction and scale must agree)
+        assert cos >= 0.999 and gerr <= 5e-2, f"{prec}: input gradient on odd maps: max err {gerr:.2e}, cosine {cos:.5f}"
