@@ -58,6 +58,7 @@ def join_side_streams():
     """The current stream waits for everything issued on the weight-gradient streams and on the branch stream (no host
     synchronisation): parameter gradients are written by the kernels, not handed to autograd, so its own end-of-backward stream
     synchronisation does not cover them."""
+    flush_deferred()
     cur = torch.cuda.current_stream()
     for idx, st in _BRANCH_STREAMS.items():
         if cur.device.index == idx:
@@ -70,6 +71,7 @@ def join_side_streams():
 
 
 def _join_side_streams():
+    flush_deferred()  # (end of a backward pass: nothing may stay behind)
     if _DEFER_JOIN[0]:
         return
     for key, main in list(_SIDE_PENDING.items()):
@@ -83,14 +85,47 @@ def _join_side_streams():
     _SIDE_KEEP.clear()  # everything the main stream does from here on is ordered behind the side work
 
 
+# Deferred weight gradients (DGMR_WGRAD_DEFER=1, inside `with defer_wgrads():` = the generator's backward pass): instead of starting
+# beside the fat data-gradient convs of the G-blocks (both compute-bound: they take CUs from each other, the main chain measured
+# ~14 % slower), the weight gradients of a sampler level are held back until the level's ConvGRU starts its backward-through-time
+# chain - small, latency-bound launches that leave most of the chip idle - and are flushed onto the side stream there
+# (ops.ConvGRUFn.backward calls flush_deferred()).  Whatever is still held when a join happens is flushed first.
+_DEFER_ON = __import__("os").environ.get("DGMR_WGRAD_DEFER", "0") != "0"
+_DEFER_OPEN = [0]
+_DEFERRED = []
+
+
+class defer_wgrads:
+    def __enter__(self):
+        _DEFER_OPEN[0] += 1
+
+    def __exit__(self, *exc):
+        _DEFER_OPEN[0] -= 1
+        if not _DEFER_OPEN[0]:
+            flush_deferred()
+
+
+def flush_deferred():
+    if not _DEFERRED:
+        return
+    todo = list(_DEFERRED)
+    _DEFERRED.clear()
+    for dev, fn, tensors, lane in todo:
+        _on_side_stream(dev, fn, tensors, lane, _now=True)
+
+
 _SIDE_LANES = int(__import__("os").environ.get("DGMR_WGRAD_LANES", "1"))  # more lanes measured no gain (1051-1060 ms for 1, 2, 3)
 _side_rr = [0]
 
 
-def _on_side_stream(dev, fn, tensors, lane=None):
+def _on_side_stream(dev, fn, tensors, lane=None, _now=False):
     """Run fn() (kernel launches through _stream()) on one of the device's side streams, ordered after everything issued so far on
     the current stream; `tensors`: what fn reads that the caller may free right after (kept alive for the side stream's work).
     lane: a fixed stream for work that shares a scratch buffer (the pair-sum planes: lane 0); None: round robin."""
+    if _DEFER_ON and _DEFER_OPEN[0] and not _now:
+        _DEFERRED.append((dev, fn, tensors, lane))  # (the closure and `tensors` keep every operand alive until the flush)
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+        return
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if lane is None:
         _side_rr[0] = (_side_rr[0] + 1) % _SIDE_LANES

@@ -317,7 +317,8 @@ class DGMR(
             if self.grad_sync is not None:
                 self.grad_sync.begin("g")
             try:
-                self.manual_backward(generator_loss)
+                with ops.defer_wgrads():  # (no-op unless DGMR_WGRAD_DEFER=1: weight gradients beside the ConvGRU backward chains)
+                    self.manual_backward(generator_loss)
             except BaseException:
                 if self.grad_sync is not None:
                     self.grad_sync.abort()

@@ -33,7 +33,8 @@ from ._head_ops import (AttentionFn, AxpbyFn, BatchNorm1dFn, GridCellFn, HingeDi
 from ._layout_ops import (CatChannelsFn, D2SFramesFn, FramesS2DFn, FramesToBatchFn, PoolAddFn, RepeatBatchFn, StackBatchFn,  # noqa: F401
                           SumGroupsFn, TimeToChannelsFn, UnstackBatchFn, avg_pool_add, cat_channels, d2s_frames, frames_s2d,
                           frames_to_batch, repeat_batch, stack_batch, sum_groups, time_to_channels, unstack_batch)
-from ._streams import _on_side_stream, branch_stream, defer_side_join, join_side_streams, side_streams  # noqa: F401
+from ._streams import (_on_side_stream, branch_stream, defer_side_join, defer_wgrads, flush_deferred, join_side_streams,  # noqa: F401
+                       side_streams)
 
 
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x6": 3}
@@ -890,6 +891,7 @@ class ConvGRUFn(Function):
         gr, gu, gc = ctx.groups
         dout_all = to_cl(dout_all)
         dev = dout_all.device
+        flush_deferred()  # (DGMR_WGRAD_DEFER: the held-back weight gradients of this level's G-blocks start beside the recurrent chain)
         st = _stream()
         tb = T * b
         n_step = b * ch * hh * ww

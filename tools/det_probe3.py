@@ -39,8 +39,20 @@ def run():
     return rec
 
 
-runs = [run() for _ in range(3)]
-for (na, a), (nb, b) in ((("a", runs[0]), ("b", runs[1])), (("b", runs[1]), ("c", runs[2]))):
+contender = None
+if os.environ.get("PROBE_CONTEND") == "1":  # a second process keeps the GPU busy (what two DDP ranks on one GPU do to each other)
+    import subprocess
+
+    contender = subprocess.Popen([sys.executable, "-c", "import torch,time\na=torch.randn(4096,4096,device='cuda')\nt=time.time()\n"
+                                  "while time.time()-t<float(%r):\n    b=a@a\n    b=torch.relu(b)*1e-3\n    torch.cuda.synchronize()" % os.environ.get("PROBE_CONTEND_S", "60")])
+    import time
+
+    time.sleep(8)
+N = int(os.environ.get("PROBE_RUNS", "3"))
+runs = [run() for _ in range(N)]
+if contender is not None:
+    contender.kill()
+for (na, a), (nb, b) in [((f"run0", runs[0]), (f"run{i}", runs[i])) for i in range(1, N)]:
     print(f"--- {na} vs {nb}: {len(a)} recorded outputs")
     shown = 0
     for (ka, ta), (kb, tb) in zip(a, b):
