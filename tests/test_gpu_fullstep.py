@@ -238,6 +238,7 @@ def test_training_step_paper_config_vs_oracle(initial, oracle_step, precision, t
     # mixed (products carry 16 significant bits: gradients differ from fp32 by ~1e-5, so more of Adam's first steps flip): 165 of 230,
     # worst 1.5e-2 (a spectral-norm u of the conditioning stack) - every buffer must still be within 5e-2
     # (exact f32: 211 and 207 of 230 in two runs of round 4 - the count itself moves with the float atomics of the bias gradients)
-    assert n_tight >= (0.65 if precision == "mixed" else 0.85) * n_buf, f"only {n_tight} of {n_buf} buffers within 1e-3 of the float64 oracle"
+    # (round 5: deterministic mode - the counts no longer move from run to run: 207 of 230 in f32, 165 of 230 in mixed)
+    assert n_tight >= (0.70 if precision == "mixed" else 0.88) * n_buf, f"only {n_tight} of {n_buf} buffers within 1e-3 of the float64 oracle"
     assert worst[0] <= 5e-2, f"buffer {worst[1]} is {worst[0]:.2e} of its max away from the float64 oracle"
     assert not bad, f"{len(bad)} buffers beyond max({floor:g}, {factor:g} x fp32 band) after the step: {sorted(bad, key=lambda t: -t[1])[:8]}"

@@ -222,7 +222,10 @@ def test_hip_training_steps_adv_match_reference(precision, grad_tol):
     #  atomics of the bias gradients are enough to move it across 10 x after three steps; 15 x)
     # (direction bound of the tensors the reference does not reproduce itself: conditioning_stack.d1.first_conv_3x3, band 0.21, measured
     #  cosine 0.8999 ... 0.98 from run to run in exact f32 - 0.85)
-    _check_grads(grads, rec, grad_tol, *{"f32": (3.0, 0.85), "bf16x6": (6.0, 0.85)}.get(precision, (15.0, 0.5)))
+    # (round 5, deterministic mode: the run-to-run spread is gone and the bounds are back at round 3's - measured on the final tree,
+    #  profiles/r05_final_pytest_gpu.log: worst err / band 2.53 (f32), 1.79 (bf16x6), 8.13 (bf16x3), 8.09 (mixed); worst cosine of the
+    #  tensors the reference does not reproduce itself 0.952 (f32), 0.948 (bf16x6), 0.903 (bf16x3), 0.906 (mixed))
+    _check_grads(grads, rec, grad_tol, *{"f32": (3.0, 0.9), "bf16x6": (6.0, 0.9)}.get(precision, (10.0, 0.85)))
     _check_post(sd0, model.state_dict(), rec, keys, kw, steps)
 
 
