@@ -520,7 +520,10 @@ int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window);
  * only the launch duration is meaningful (how much of a launch is operand staging / matrix work / epilogue).  Bit 3 (8) = the
  * window kernels use their lane-per-channel epilogue instead of the 16-byte one (A/B: results are bit-identical); 64 / 128 = every
  * wave sleeps ~3.4 / ~6.8 us after issuing its last store (how long does a finished wave wait for its stores anyway?); 16 = the
- * wave-specialised weight-gradient kernel without its matrix work (the loaders' time alone). */
+ * wave-specialised weight-gradient kernel without its matrix work (the loaders' time alone); 256 (round 5) = phase launches of the
+ * upsampling convs with one workgroup per ROW parity that computes both column parities from one staged halo, instead of one
+ * workgroup per output-pixel parity (conv_win_glds.h PAIR; same results bit for bit - tests/test_gpu_kernels.py; measured no faster,
+ * so it is not the default: DGMR_PHASE_PAIR=1 switches it on for a whole process). */
 int dgmr_debug_flags(int flags);
 
 #ifdef __cplusplus

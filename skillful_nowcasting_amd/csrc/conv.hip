@@ -638,6 +638,15 @@ static const bool g_ws_auto = []() {
     return e && e[0] == '1';
 }();
 
+// DGMR_PHASE_PAIR=1 (or dgmr_debug_flags 256): phase launches with one workgroup per ROW parity (conv_win_glds.h PAIR).  Off by default:
+// measured in isolation (tools/conv_bench.py, profiles/r05_phase_pair_*.log) 4 % / 3 % SLOWER on the two biggest upsampling convs
+// (up_g4.first 8.79 vs 8.43 ms, up_g3.first 7.00 vs 6.78 ms) and 2.5 % faster on up_g2.first - half the halo staging per MFMA, but a
+// 128-pixel tile with one block row per wave reads 1.33 LDS fragments per MFMA where the 256-pixel tile reads 0.83
+static const bool g_phase_pair = []() {
+    const char* e = getenv("DGMR_PHASE_PAIR");
+    return e && e[0] == '1';
+}();
+
 // Which LDS-window 3x3 kernel (if any) takes a conv, and with which tiling: shared by the launch and by dgmr_conv_stats_rows.
 static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     const int64_t M64 = (int64_t)p.N * p.D * p.H * p.W;
@@ -675,6 +684,7 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
     // blocks, 32-bit element offsets, and enough taps per item to hide the previous item's epilogue behind (ws_ups)
     w->ws = false;
     w->ws_ups = 1;
+    w->pair = false;
     if (glds_ok && g_precision != 3 && p.KD == 1 && p.D == 1 && !p.upsample && p.epi_mode == DGMR_EPI_PLAIN && (p.reserved1 & 4) &&
         !p.addend && !(p.residual && p.mask_src) && (w->bnw == 96 || w->bnw == 128) && M64 * (int64_t)C < (1ll << 32) &&
         !(p.reserved1 & (64 | 128)) && (g_tune_window == 7 || g_tune_window < 0)) {
@@ -692,7 +702,11 @@ static bool window_plan(const dgmr_conv_args& p, WinPlan* w) {
             w->ws_ups = ups;
         }
     }
-    w->big = !w->ws && !small8 && w->bnw != 128 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 && g_precision != 3 &&  // (bf16x6: 102 KB of LDS)
+    // phase mode, 96 / 128 output columns, bf16 / bf16x3: both column parities of a row parity from ONE staged halo (conv_win_glds.h
+    // PAIR; 128-pixel tiles).  DGMR_PHASE_PAIR=0: the four-workgroups-per-tile scheme (A/B)
+    w->pair = !w->ws && p.reserved0 == 1 && glds_ok && g_precision != 3 && (g_phase_pair || (g_debug_flags & 256)) && g_tune_window < 0 && C % 96 == 0 && !small8 && p.KD == 1;
+    if (w->pair) w->bnw = 96;  // (384 / 768 columns too: the 128-column tile with two accumulator sets spills, 96 sits at 217 registers)
+    w->big = !w->ws && !w->pair && !small8 && w->bnw != 128 && p.KD == 1 && p.H % (256 >> w->tw_shift) == 0 && g_precision != 3 &&  // (bf16x6: 102 KB of LDS)
              (g_tune_window == 2 || (g_tune_window < 0 && big_wgs >= 2048));
     w->glds = glds_ok || w->big;
     const int TWv = 1 << w->tw_shift, THv = ((w->big ? 256 : 128) >> w->tw_shift) >> w->g_shift;
@@ -1346,7 +1360,7 @@ extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_win
 }
 
 extern "C" int dgmr_debug_flags(int flags) {
-    DGMR_CHECK_ARG(flags >= 0 && flags <= 255 && !(flags & 4), "dgmr_debug_flags: %d", flags);
+    DGMR_CHECK_ARG(flags >= 0 && flags <= 511 && !(flags & 4), "dgmr_debug_flags: %d", flags);  // (256: phase launches one workgroup per ROW parity - tests, A/B)
     g_debug_flags = flags;
     return 0;
 }

@@ -16,6 +16,7 @@ struct WinPlan {
     bool big, glds;  // 256-pixel tiles; LDS-DMA kernel (has the fused output statistics)
     bool ws;         // the wave-specialised persistent kernel (conv_win_ws.h): 128-pixel tiles, one workgroup per CU
     int ws_ups;      // its epilogue units per tap (1 | 2)
+    bool pair;       // phase mode: one workgroup per ROW parity computes both column parities from one halo (conv_win_glds.h PAIR)
 };
 
 namespace dgmr_tu {

@@ -96,8 +96,13 @@ __host__ __device__ constexpr int halo_row_stride(int halo_cols) { return halo_c
 // nine times per chunk (PMC: 37 % of the wave cycles parked, matrix pipe 50 % busy).
 // M16: the wave's tile is made of 16 x 16 blocks (v_mfma_f32_16x16x32_bf16: one instruction per 32-channel chunk and block) instead
 // of 32 x 32 ones: 48 output channels are three blocks - the 64-column tile spent a quarter of its matrix work on padding.
-template <int BN, int WM, int WN, int NS, int BM = 128, bool PRIV = false, bool M16 = false>
-__global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || (M16 && BN >= 96)) ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift,
+// PAIR (round 5, phase mode only): ONE workgroup computes BOTH column parities (px = 0, 1) of a row parity py from one staged halo - two
+// accumulator sets, eight taps per 32-channel chunk instead of four.  The four-workgroups-per-tile scheme staged (fetched, BatchNorm +
+// relu'd, split, LDS-stored) every halo four times for four taps each: 9.1 VALU instructions per MFMA against 5.0 in the plain mode,
+// matrix pipe 29 - 33 % busy (PMC, profiles/r05_pmc_classes.json).  128-pixel tiles: the doubled accumulators take the registers the
+// 256-pixel tile's second block row had.
+template <int BN, int WM, int WN, int NS, int BM = 128, bool PRIV = false, bool M16 = false, bool PAIR = false>
+__global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || (M16 && BN >= 96) || PAIR) ? 2 : 3) void conv3x3_glds_kernel(const dgmr_conv_args p, const int tw_shift,
                                                                                           const int tiles_w, const int tiles_hw,
                                                                                           const int g_shift) {
     constexpr int CK = 32;
@@ -118,6 +123,8 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
     constexpr int WSLICE = NP * TN * 32 * ROW;                        // dwords of one wave's private slice of a stage
     constexpr int BSTAGE = PRIV ? 4 * WSLICE : NP * BN * ROW;         // dwords of one stage
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BUNITS % 64 == 0, "bad tile");
+    static_assert(!PAIR || (BM == 128 && !PRIV), "PAIR tile");
+    constexpr int NACC = PAIR ? 2 : 1;
 
     __shared__ __attribute__((aligned(16))) uint32_t smem[NP * AMAX * ROW + 2 * BSTAGE];
     uint32_t* As = smem;                     // [plane][pixel][ROW]
@@ -132,9 +139,10 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
     // (PMC before: 5.2x the input read from the fabric; phases as blockIdx.y put them a whole grid row apart)
     const bool phase_pre = p.reserved0 == 1;
     const int bid = blockIdx.x;
-    const bool xcd_map = phase_pre && (gridDim.x & 31) == 0;
-    const int ph_pre = !phase_pre ? 0 : (xcd_map ? (bid >> 3) & 3 : bid & 3);
-    const int tile = !phase_pre ? bid : (xcd_map ? ((bid >> 5) << 3) | (bid & 7) : bid >> 2);
+    // (PAIR: blockIdx.x = 2 x tiles, one workgroup per row parity; ph_pre is then the px = 0 phase of the pair)
+    const bool xcd_map = phase_pre && (gridDim.x & (PAIR ? 15 : 31)) == 0;
+    const int ph_pre = !phase_pre ? 0 : PAIR ? 2 * (xcd_map ? (bid >> 3) & 1 : bid & 1) : (xcd_map ? (bid >> 3) & 3 : bid & 3);
+    const int tile = !phase_pre ? bid : PAIR ? (xcd_map ? ((bid >> 4) << 3) | (bid & 7) : bid >> 1) : (xcd_map ? ((bid >> 5) << 3) | (bid & 7) : bid >> 2);
     const int n = g_shift ? (tile << g_shift) : tile / tiles_hw;  // first image of the tile; 3-D: depth plane (sample * D + d)
     const int KD = p.KD;                                           // 1, or 3 (then g_shift == 0)
     const int smp = KD == 3 ? n / p.D : n;                         // sample of the tile's first image: statistics / sigma groups
@@ -254,9 +262,10 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
         b_tail[i] = row + (c_last + ch < p.Cin ? c_last + ch : 0);  // absolute channel: the tail's scalar base has no chunk offset
     }
     const bool has_tail = (p.Cin & (CK - 1)) != 0;
-    auto dma_b = [&](int chunk, int tap, int stage) {  // tap: 0 .. 9 KD - 1
+    const size_t phase_rows = (size_t)p.Cout * (size_t)taps * p.Cin;  // elements between the weight rows of two consecutive phases (PAIR)
+    auto dma_b = [&](int chunk, int tap, int stage, int pxo = 0) {  // tap: 0 .. 9 KD - 1; pxo (PAIR): 1 = the px = 1 phase's tap sums
         const bool tail = has_tail && chunk == nchunks - 1;
-        const uint16_t* base = p.w_split + ((size_t)tap * p.Cin + (tail ? 0 : chunk * CK));
+        const uint16_t* base = p.w_split + ((size_t)tap * p.Cin + (tail ? 0 : chunk * CK)) + (PAIR ? (size_t)pxo * phase_rows : 0);
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
             if (PRIV)  // 16 rows x 64 bytes of this wave's own slice: [plane][TN * 32 rows][ROW]
@@ -266,13 +275,15 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
         }
     };
 
-    accv_t acc[TM][TN];
+    accv_t accs[NACC][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < RPB; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < RPB; ++r) accs[a][i][j][r] = 0.f;
 
     // halo pixel of this lane under each filter row / column: pix = rowpix[dy] + colpix[dx] (the taps are unrolled below)
     int rowpix[TM][3], colpix[TM][3];
@@ -292,7 +303,8 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
     constexpr int BPLANE = PRIV ? TN * 32 : BN;  // rows between the hi and the lo plane of a stage
     // half: the chunk holds <= 16 real channels (Cin = 48, 144: the last chunk) - its second 16-channel step is all zeros, skipped
     const bool tail16 = (p.Cin & (CK - 1)) != 0 && (p.Cin & (CK - 1)) <= 16;
-    auto mma = [&](int dyi, int dxi, int stage, bool half) {
+    auto mma_sel = [&](int dyi, int dxi, int stage, bool half, auto acc_sel) {  // acc_sel: which accumulator set (PAIR: the column parity)
+        accv_t (&acc)[TM][TN] = accs[decltype(acc_sel)::value];
         const uint32_t* Ab[TM];
         int asw[TM];
 #pragma unroll
@@ -327,6 +339,7 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
             __builtin_amdgcn_s_setprio(0);
         }
     };
+    auto mma = [&](int dyi, int dxi, int stage, bool half) { mma_sel(dyi, dxi, stage, half, std::integral_constant<int, 0>{}); };
 
     dma_b(0, 0, 0);
     stage_a(0, 0);
@@ -366,7 +379,35 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
             }
         }
     }
-    if (phase) {
+    if (phase && PAIR) {
+        if constexpr (PAIR) {
+#pragma unroll 1
+            for (int chunk = 0; chunk < nchunks; ++chunk) {  // eight taps per chunk (px = 0: taps 0 .. 3, px = 1: taps 0 .. 3), one halo
+                const bool more = chunk + 1 < nchunks;
+                const bool half = tail16 && !more;
+                auto step = [&](auto vc) {
+                    constexpr int v = decltype(vc)::value, pxo = v >> 2, tap = v & 3, st = v & 1;
+                    if (v < 7) dma_b(chunk, (v + 1) & 3, st ^ 1, (v + 1) >> 2);
+                    else if (more) dma_b(chunk + 1, 0, st ^ 1, 0);
+                    mma_sel(tap >> 1, (tap & 1) + pxo, st, half, std::integral_constant<int, pxo>{});
+                    if (v == 7 && more) {
+                        __syncthreads();
+                        stage_a(chunk + 1, 0);
+                    }
+                    dma_drain();
+                    __syncthreads();
+                };
+                step(std::integral_constant<int, 0>{});
+                step(std::integral_constant<int, 1>{});
+                step(std::integral_constant<int, 2>{});
+                step(std::integral_constant<int, 3>{});
+                step(std::integral_constant<int, 4>{});
+                step(std::integral_constant<int, 5>{});
+                step(std::integral_constant<int, 6>{});
+                step(std::integral_constant<int, 7>{});
+            }
+        }
+    } else if (phase) {
 #pragma unroll 1
         for (int chunk = 0; chunk < nchunks; ++chunk) {  // four taps per chunk: the stage parity restarts with every chunk
             const bool more = chunk + 1 < nchunks;
@@ -407,304 +448,314 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
         }
     }
 
-    // ---- epilogue (conv3x3_win_kernel's) ----
-    if (dbg & 1) {  // (the accumulators must stay live: a store that never happens for finite sums)
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) t += acc[i][j][0];
-        if (t == 123456.789f) p.y[0] = t;
-        return;
-    }
-    const float sc = p.scale ? p.scale[smp / p.scale_group] : 1.f;
-    const int emode = p.epi_mode;
-    const int pshift = phase ? 1 : 0, oH = p.H << pshift, oW = p.W << pshift;  // the output map (phase mode: twice the input's)
-    // ---- 16-byte epilogue (p.reserved1 & 4: Cout % 4 == 0 and every tensor it touches is 16-byte aligned; set by the library) ----
-    // The accumulator blocks hold one COLUMN per lane (16 rows of a 32 x 32 block in 16 registers): a lane-per-column epilogue issues
-    // one 4-byte store (and one 4-byte load per fused operand) per row and block - 96 stores per lane on a 256 x 96 tile, which is
-    // what the epilogue's time went into (measured by switching it off, tools/r3_probe.sh: 12 ... 38 % of a launch).  Here every 4 x 4
-    // patch (4 consecutive rows in 4 registers x the 4 lanes of a quad) is transposed across the quad with DPP moves, after which a
-    // lane holds 4 consecutive CHANNELS of one pixel: a quarter of the memory instructions, each 16 bytes wide.  Same arithmetic per
-    // element, in the same order, as the lane-per-column path below (kept for Cout % 4 != 0 / unaligned views): bit-identical outputs.
-    if (p.reserved1 & 4) {
-        const int j4 = lane & 3;                                  // row of the 4 x 4 patch this lane ends up with
-        const int q4 = (lane & (MB - 1)) >> 2;                    // its column quad inside a block
-        const int rsel = M16 ? lane >> 4 : lane >> 5;             // which rows of the block this lane group holds
-        constexpr int NG = RPB / 4;                               // 4-row register groups per block
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
-        // output pixel (row of the [pixels][Cout] matrix) of this lane in each of its TM x NG row groups; the residual's when it is
-        // at half resolution
-        int mpix[TM][NG], rpix[TM][NG];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int q = M16 ? wm * TM * 16 + i * 16 + 4 * rsel + j4 : wm * TM * 32 + i * 32 + j4 + 8 * g + 4 * rsel;
+    // the epilogue of ONE accumulator set (PAIR: called once per column parity; ph / px shadow the workgroup's own)
+    auto epilogue = [&](accv_t (&acc)[TM][TN], const int ph, const int px) {
+        // ---- epilogue (conv3x3_win_kernel's) ----
+        if (dbg & 1) {  // (the accumulators must stay live: a store that never happens for finite sums)
+            float t = 0.f;
+    #pragma unroll
+            for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                for (int j = 0; j < TN; ++j) t += acc[i][j][0];
+            if (t == 123456.789f) p.y[0] = t;
+            return;
+        }
+        const float sc = p.scale ? p.scale[smp / p.scale_group] : 1.f;
+        const int emode = p.epi_mode;
+        const int pshift = phase ? 1 : 0, oH = p.H << pshift, oW = p.W << pshift;  // the output map (phase mode: twice the input's)
+        // ---- 16-byte epilogue (p.reserved1 & 4: Cout % 4 == 0 and every tensor it touches is 16-byte aligned; set by the library) ----
+        // The accumulator blocks hold one COLUMN per lane (16 rows of a 32 x 32 block in 16 registers): a lane-per-column epilogue issues
+        // one 4-byte store (and one 4-byte load per fused operand) per row and block - 96 stores per lane on a 256 x 96 tile, which is
+        // what the epilogue's time went into (measured by switching it off, tools/r3_probe.sh: 12 ... 38 % of a launch).  Here every 4 x 4
+        // patch (4 consecutive rows in 4 registers x the 4 lanes of a quad) is transposed across the quad with DPP moves, after which a
+        // lane holds 4 consecutive CHANNELS of one pixel: a quarter of the memory instructions, each 16 bytes wide.  Same arithmetic per
+        // element, in the same order, as the lane-per-column path below (kept for Cout % 4 != 0 / unaligned views): bit-identical outputs.
+        if (p.reserved1 & 4) {
+            const int j4 = lane & 3;                                  // row of the 4 x 4 patch this lane ends up with
+            const int q4 = (lane & (MB - 1)) >> 2;                    // its column quad inside a block
+            const int rsel = M16 ? lane >> 4 : lane >> 5;             // which rows of the block this lane group holds
+            constexpr int NG = RPB / 4;                               // 4-row register groups per block
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+            // output pixel (row of the [pixels][Cout] matrix) of this lane in each of its TM x NG row groups; the residual's when it is
+            // at half resolution
+            int mpix[TM][NG], rpix[TM][NG];
+    #pragma unroll
+            for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int q = M16 ? wm * TM * 16 + i * 16 + 4 * rsel + j4 : wm * TM * 32 + i * 32 + j4 + 8 * g + 4 * rsel;
+                    const int ni = n + (q >> sub_shift);
+                    const int hh = ((h0 + ((q >> tw_shift) & (TH - 1))) << pshift) + py, ww = ((w0 + (q & (TW - 1))) << pshift) + px;
+                    mpix[i][g] = (ni * oH + hh) * oW + ww;
+                    rpix[i][g] = p.residual_up ? (ni * (oH >> 1) + (hh >> 1)) * (oW >> 1) + (ww >> 1) : mpix[i][g];
+                }
+            const bool want_stats_v = p.stats_out != nullptr && emode == DGMR_EPI_PLAIN;
+            float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
+            if (want_stats_v) __syncthreads();  // (wave-uniform) every wave is done with the operand images before `red` overwrites them
+    #pragma unroll
+            for (int j = 0; j < TN; ++j) {  // one column block at a time: its per-column operands and sums stay in a few registers
+                const int col4 = n0 + wn * TN * MB + j * MB + 4 * q4;
+                const bool cok = col4 < p.Cout;  // (Cout % 4 == 0: the whole quad of columns is in or out)
+                if (emode == DGMR_EPI_GRU_GATES2) {
+                    // read and update gate of a ConvGRU step in one launch: columns [0, C) are the read gate's (pre_out, y = sigmoid * h),
+                    // [C, 2C) the update gate's (y2 = pre-activation); every tensor has C channels per pixel (C % 4 == 0: no quad straddles)
+                    const int C = p.gru_split;
+                    const bool is2 = col4 >= C;
+                    const int c0 = cok ? (is2 ? col4 - C : col4) : 0;
+                    const float* bp = is2 ? p.bias2 : p.bias;
+                    const float* ap = is2 ? p.addend2 : p.addend;
+                    const f32x4 b4 = bp ? *reinterpret_cast<const f32x4*>(bp + c0) : zero4;
+                    const float scj = is2 ? (p.scale2 ? p.scale2[smp / p.scale_group] : 1.f) : sc;
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+    #pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            const size_t off = (size_t)mpix[i][g] * C + c0;
+                            f32x4 v = quad_transpose(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], lane);
+                            if (ap) v += *reinterpret_cast<const f32x4*>(ap + off);
+    #pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], scj, b4[c]);
+                            if (!cok) continue;
+                            if (is2) {
+                                *reinterpret_cast<f32x4*>(p.y2 + off) = v;
+                            } else {
+                                const f32x4 hv = *reinterpret_cast<const f32x4*>(p.gru_h + off);
+                                f32x4 o;
+    #pragma unroll
+                                for (int c = 0; c < 4; ++c) o[c] = sigmoid_(v[c]) * hv[c];
+                                if (p.pre_out) *reinterpret_cast<f32x4*>(p.pre_out + off) = v;
+                                *reinterpret_cast<f32x4*>(p.y + off) = o;
+                            }
+                        }
+                    }
+                    continue;
+                }
+                const int cc = cok ? col4 : 0;
+                const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cc) : zero4;
+                f32x4 ma4 = one4, mb4 = zero4;
+                if (p.mask_a) {
+                    const size_t g = (size_t)(smp / p.mask_group) * p.Cout + cc;
+                    ma4 = *reinterpret_cast<const f32x4*>(p.mask_a + g);
+                    mb4 = *reinterpret_cast<const f32x4*>(p.mask_b + g);
+                }
+                f32x4 s0 = zero4, s1 = zero4;
+    #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+    #pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const size_t off = (size_t)mpix[i][g] * p.Cout + cc;
+                        f32x4 v = quad_transpose(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], lane);
+                        if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + off);
+    #pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], sc, b4[c]);
+                        if (emode == DGMR_EPI_PLAIN) {
+                            f32x4 rs = zero4, ms = zero4;
+                            if (p.residual) rs = *reinterpret_cast<const f32x4*>(p.residual + (size_t)rpix[i][g] * p.Cout + cc);
+                            if (p.mask_src) ms = *reinterpret_cast<const f32x4*>(p.mask_src + off);
+                            f32x4 o = v;
+    #pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (p.act_relu) o[c] = fmaxf(o[c], 0.f);
+                                if (p.residual) o[c] += rs[c];
+                                if (p.mask_src) o[c] = fmaf(ms[c], ma4[c], mb4[c]) > 0.f ? o[c] : 0.f;
+                            }
+                            if (cok) *reinterpret_cast<f32x4*>(p.y + off) = o;
+                            if (want_stats_v) {
+    #pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    s0[c] += o[c];
+                                    s1[c] = fmaf(o[c], p.mask_src ? ms[c] : o[c], s1[c]);
+                                }
+                            }
+                        } else {  // ConvGRU step: pre_out = v; gate: y = sigmoid(v) * h; blend: y = s*h + (1-s)*relu(v), s = sigmoid(pu)
+                            const f32x4 hv = *reinterpret_cast<const f32x4*>(p.gru_h + off);
+                            f32x4 pv = zero4, o;
+                            if (emode == DGMR_EPI_GRU_BLEND) pv = *reinterpret_cast<const f32x4*>(p.gru_pu + off);
+    #pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (emode == DGMR_EPI_GRU_BLEND) {
+                                    const float sg = sigmoid_(pv[c]);
+                                    o[c] = sg * hv[c] + (1.f - sg) * fmaxf(v[c], 0.f);
+                                } else {
+                                    o[c] = sigmoid_(v[c]) * hv[c];
+                                }
+                            }
+                            if (cok) {
+                                if (p.pre_out) *reinterpret_cast<f32x4*>(p.pre_out + off) = v;
+                                *reinterpret_cast<f32x4*>(p.y + off) = o;
+                            }
+                        }
+                    }
+                }
+                if (want_stats_v) {  // per-column sums: fold the 4 rows of the quad and the row groups of the wave (the WM waves: below)
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float a = s0[c], b = s1[c];
+                        a += quad_xor1(a);
+                        b += quad_xor1(b);
+                        a += quad_xor2(a);
+                        b += quad_xor2(b);
+                        a += __shfl_xor(a, 32, 64);
+                        b += __shfl_xor(b, 32, 64);
+                        if (M16) {
+                            a += __shfl_xor(a, 16, 64);
+                            b += __shfl_xor(b, 16, 64);
+                        }
+                        if ((lane & (M16 ? 0x33 : 0x23)) == 0) {
+                            const int cl = wn * TN * MB + j * MB + 4 * q4 + c;
+                            red[(wm * BN + cl) * 2 + 0] = a;
+                            red[(wm * BN + cl) * 2 + 1] = b;
+                        }
+                    }
+                }
+            }
+            if (want_stats_v) {
+                __syncthreads();
+                for (int idx = tid; idx < BN * 2; idx += 256) {
+                    const int cl = idx >> 1, which = idx & 1;
+                    float v = 0.f;
+    #pragma unroll
+                    for (int qq = 0; qq < WM; ++qq) v += red[(qq * BN + cl) * 2 + which];
+                    const size_t srow = phase ? (size_t)tile * 4 + ph : (size_t)tile;  // (a tile's four phases: consecutive rows)
+                    if (n0 + cl < p.Cout) p.stats_out[(srow * 2 + which) * p.Cout + n0 + cl] = v;
+                }
+            }
+            // tail probe (dgmr_debug_flags 64 / 128: sleep ~3.4 / ~6.8 us after the last store was ISSUED): a wave cannot retire before its
+            // stores are acknowledged; if a launch does not get slower with the sleep, that wait is at least as long
+            if (dbg & 64) __builtin_amdgcn_s_sleep(127);
+            if (dbg & 128) {
+                __builtin_amdgcn_s_sleep(127);
+                __builtin_amdgcn_s_sleep(127);
+            }
+            return;
+        }
+        float bj[TN];
+        int colj[TN];
+    #pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            colj[j] = n0 + wn * TN * MB + j * MB + (lane & (MB - 1));
+            bj[j] = (p.bias && colj[j] < p.Cout) ? p.bias[colj[j]] : 0.f;
+        }
+        float maj[TN], mbj[TN];  // affine of the BatchNorm whose relu is being back-propagated through (data gradient), per column
+    #pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const bool on = p.mask_a && colj[j] < p.Cout;
+            const size_t g = (size_t)(smp / p.mask_group) * p.Cout + (on ? colj[j] : 0);
+            maj[j] = on ? p.mask_a[g] : 1.f;
+            mbj[j] = on ? p.mask_b[g] : 0.f;
+        }
+        // Every variant is straight-line per output row: the loads of a row (addend, ConvGRU state, residual, mask source) are issued
+        // together, unconditionally, on clamped addresses.  (The element-wise generic epilogue with its per-element divisions and
+        // dependent loads made a ConvGRU step conv spend as long in its epilogue as in its 18 taps.)
+        const int cmax = p.Cout - 1;
+        // BatchNorm statistics of the OUTPUT for the next layer, taken here (stats_out): per column sum y and sum y^2 (data gradient
+        // through relu(BatchNorm(x)), i.e. with mask_src: sum y and sum y * x, the two sums of BatchNorm's backward) over this lane's
+        // 16 TM rows, folded over the two lane halves, the WM waves (LDS) and written as ONE row of partials per workgroup tile
+        float st0[TN], st1[TN];
+    #pragma unroll
+        for (int j = 0; j < TN; ++j) st0[j] = st1[j] = 0.f;
+        const bool want_stats = p.stats_out != nullptr && emode == DGMR_EPI_PLAIN;
+    #pragma unroll
+        for (int i = 0; i < TM; ++i) {
+    #pragma unroll
+            for (int r = 0; r < RPB; ++r) {
+                // accumulator register r of this lane: block row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) [32 x 32] / 4 (lane >> 4) + r [16 x 16]
+                const int q = M16 ? wm * TM * 16 + i * 16 + 4 * (lane >> 4) + r
+                                  : wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int ni = n + (q >> sub_shift);
                 const int hh = ((h0 + ((q >> tw_shift) & (TH - 1))) << pshift) + py, ww = ((w0 + (q & (TW - 1))) << pshift) + px;
-                mpix[i][g] = (ni * oH + hh) * oW + ww;
-                rpix[i][g] = p.residual_up ? (ni * (oH >> 1) + (hh >> 1)) * (oW >> 1) + (ww >> 1) : mpix[i][g];
-            }
-        const bool want_stats_v = p.stats_out != nullptr && emode == DGMR_EPI_PLAIN;
-        float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
-        if (want_stats_v) __syncthreads();  // (wave-uniform) every wave is done with the operand images before `red` overwrites them
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {  // one column block at a time: its per-column operands and sums stay in a few registers
-            const int col4 = n0 + wn * TN * MB + j * MB + 4 * q4;
-            const bool cok = col4 < p.Cout;  // (Cout % 4 == 0: the whole quad of columns is in or out)
-            if (emode == DGMR_EPI_GRU_GATES2) {
-                // read and update gate of a ConvGRU step in one launch: columns [0, C) are the read gate's (pre_out, y = sigmoid * h),
-                // [C, 2C) the update gate's (y2 = pre-activation); every tensor has C channels per pixel (C % 4 == 0: no quad straddles)
-                const int C = p.gru_split;
-                const bool is2 = col4 >= C;
-                const int c0 = cok ? (is2 ? col4 - C : col4) : 0;
-                const float* bp = is2 ? p.bias2 : p.bias;
-                const float* ap = is2 ? p.addend2 : p.addend;
-                const f32x4 b4 = bp ? *reinterpret_cast<const f32x4*>(bp + c0) : zero4;
-                const float scj = is2 ? (p.scale2 ? p.scale2[smp / p.scale_group] : 1.f) : sc;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const size_t off = (size_t)mpix[i][g] * C + c0;
-                        f32x4 v = quad_transpose(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], lane);
-                        if (ap) v += *reinterpret_cast<const f32x4*>(ap + off);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], scj, b4[c]);
-                        if (!cok) continue;
-                        if (is2) {
-                            *reinterpret_cast<f32x4*>(p.y2 + off) = v;
+                const size_t mrow = (size_t)((ni * oH + hh) * oW + ww) * p.Cout;
+                const size_t rrow = p.residual_up ? (((size_t)ni * (oH >> 1) + (hh >> 1)) * (oW >> 1) + (ww >> 1)) * p.Cout : mrow;
+                float v[TN];
+    #pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
+                if (p.addend) {
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) v[j] += p.addend[mrow + min(colj[j], cmax)];
+                }
+    #pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] = fmaf(v[j], sc, bj[j]);
+                if (emode == DGMR_EPI_PLAIN) {
+                    float rs[TN], ms[TN];
+                    if (p.residual) {
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j) rs[j] = p.residual[rrow + min(colj[j], cmax)];
+                    }
+                    if (p.mask_src) {
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j) ms[j] = p.mask_src[mrow + min(colj[j], cmax)];
+                    }
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float o = v[j];
+                        if (p.act_relu) o = fmaxf(o, 0.f);
+                        if (p.residual) o += rs[j];
+                        if (p.mask_src) o = fmaf(ms[j], maj[j], mbj[j]) > 0.f ? o : 0.f;
+                        if (colj[j] < p.Cout) p.y[mrow + colj[j]] = o;
+                        if (want_stats) {
+                            st0[j] += o;
+                            st1[j] = fmaf(o, p.mask_src ? ms[j] : o, st1[j]);
+                        }
+                    }
+                } else {  // ConvGRU step: pre_out = v; gate: y = sigmoid(v) * h; blend: y = s*h + (1-s)*relu(v), s = sigmoid(pu)
+                    float hv[TN], pv[TN];
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) hv[j] = p.gru_h[mrow + min(colj[j], cmax)];
+                    if (emode == DGMR_EPI_GRU_BLEND) {
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j) pv[j] = p.gru_pu[mrow + min(colj[j], cmax)];
+                    }
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float o;
+                        if (emode == DGMR_EPI_GRU_BLEND) {
+                            const float sg = sigmoid_(pv[j]);
+                            o = sg * hv[j] + (1.f - sg) * fmaxf(v[j], 0.f);
                         } else {
-                            const f32x4 hv = *reinterpret_cast<const f32x4*>(p.gru_h + off);
-                            f32x4 o;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) o[c] = sigmoid_(v[c]) * hv[c];
-                            if (p.pre_out) *reinterpret_cast<f32x4*>(p.pre_out + off) = v;
-                            *reinterpret_cast<f32x4*>(p.y + off) = o;
+                            o = sigmoid_(v[j]) * hv[j];
                         }
-                    }
-                }
-                continue;
-            }
-            const int cc = cok ? col4 : 0;
-            const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cc) : zero4;
-            f32x4 ma4 = one4, mb4 = zero4;
-            if (p.mask_a) {
-                const size_t g = (size_t)(smp / p.mask_group) * p.Cout + cc;
-                ma4 = *reinterpret_cast<const f32x4*>(p.mask_a + g);
-                mb4 = *reinterpret_cast<const f32x4*>(p.mask_b + g);
-            }
-            f32x4 s0 = zero4, s1 = zero4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const size_t off = (size_t)mpix[i][g] * p.Cout + cc;
-                    f32x4 v = quad_transpose(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], lane);
-                    if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + off);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], sc, b4[c]);
-                    if (emode == DGMR_EPI_PLAIN) {
-                        f32x4 rs = zero4, ms = zero4;
-                        if (p.residual) rs = *reinterpret_cast<const f32x4*>(p.residual + (size_t)rpix[i][g] * p.Cout + cc);
-                        if (p.mask_src) ms = *reinterpret_cast<const f32x4*>(p.mask_src + off);
-                        f32x4 o = v;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (p.act_relu) o[c] = fmaxf(o[c], 0.f);
-                            if (p.residual) o[c] += rs[c];
-                            if (p.mask_src) o[c] = fmaf(ms[c], ma4[c], mb4[c]) > 0.f ? o[c] : 0.f;
+                        if (colj[j] < p.Cout) {
+                            if (p.pre_out) p.pre_out[mrow + colj[j]] = v[j];
+                            p.y[mrow + colj[j]] = o;
                         }
-                        if (cok) *reinterpret_cast<f32x4*>(p.y + off) = o;
-                        if (want_stats_v) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                s0[c] += o[c];
-                                s1[c] = fmaf(o[c], p.mask_src ? ms[c] : o[c], s1[c]);
-                            }
-                        }
-                    } else {  // ConvGRU step: pre_out = v; gate: y = sigmoid(v) * h; blend: y = s*h + (1-s)*relu(v), s = sigmoid(pu)
-                        const f32x4 hv = *reinterpret_cast<const f32x4*>(p.gru_h + off);
-                        f32x4 pv = zero4, o;
-                        if (emode == DGMR_EPI_GRU_BLEND) pv = *reinterpret_cast<const f32x4*>(p.gru_pu + off);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (emode == DGMR_EPI_GRU_BLEND) {
-                                const float sg = sigmoid_(pv[c]);
-                                o[c] = sg * hv[c] + (1.f - sg) * fmaxf(v[c], 0.f);
-                            } else {
-                                o[c] = sigmoid_(v[c]) * hv[c];
-                            }
-                        }
-                        if (cok) {
-                            if (p.pre_out) *reinterpret_cast<f32x4*>(p.pre_out + off) = v;
-                            *reinterpret_cast<f32x4*>(p.y + off) = o;
-                        }
-                    }
-                }
-            }
-            if (want_stats_v) {  // per-column sums: fold the 4 rows of the quad and the row groups of the wave (the WM waves: below)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float a = s0[c], b = s1[c];
-                    a += quad_xor1(a);
-                    b += quad_xor1(b);
-                    a += quad_xor2(a);
-                    b += quad_xor2(b);
-                    a += __shfl_xor(a, 32, 64);
-                    b += __shfl_xor(b, 32, 64);
-                    if (M16) {
-                        a += __shfl_xor(a, 16, 64);
-                        b += __shfl_xor(b, 16, 64);
-                    }
-                    if ((lane & (M16 ? 0x33 : 0x23)) == 0) {
-                        const int cl = wn * TN * MB + j * MB + 4 * q4 + c;
-                        red[(wm * BN + cl) * 2 + 0] = a;
-                        red[(wm * BN + cl) * 2 + 1] = b;
                     }
                 }
             }
         }
-        if (want_stats_v) {
+        if (want_stats) {  // (wave-uniform)
+            if (PRIV) __syncthreads();  // no barrier since the last halo: other waves may still be reading the LDS
+            float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
+    #pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                st0[j] += __shfl_xor(st0[j], 32, 64);
+                st1[j] += __shfl_xor(st1[j], 32, 64);
+                if (M16) {  // four lane groups hold the same column
+                    st0[j] += __shfl_xor(st0[j], 16, 64);
+                    st1[j] += __shfl_xor(st1[j], 16, 64);
+                }
+                if (lane < MB) {
+                    const int cl = wn * TN * MB + j * MB + lane;
+                    red[(wm * BN + cl) * 2 + 0] = st0[j];
+                    red[(wm * BN + cl) * 2 + 1] = st1[j];
+                }
+            }
             __syncthreads();
             for (int idx = tid; idx < BN * 2; idx += 256) {
                 const int cl = idx >> 1, which = idx & 1;
                 float v = 0.f;
-#pragma unroll
-                for (int qq = 0; qq < WM; ++qq) v += red[(qq * BN + cl) * 2 + which];
+    #pragma unroll
+                for (int q = 0; q < WM; ++q) v += red[(q * BN + cl) * 2 + which];
                 const size_t srow = phase ? (size_t)tile * 4 + ph : (size_t)tile;  // (a tile's four phases: consecutive rows)
                 if (n0 + cl < p.Cout) p.stats_out[(srow * 2 + which) * p.Cout + n0 + cl] = v;
             }
         }
-        // tail probe (dgmr_debug_flags 64 / 128: sleep ~3.4 / ~6.8 us after the last store was ISSUED): a wave cannot retire before its
-        // stores are acknowledged; if a launch does not get slower with the sleep, that wait is at least as long
-        if (dbg & 64) __builtin_amdgcn_s_sleep(127);
-        if (dbg & 128) {
-            __builtin_amdgcn_s_sleep(127);
-            __builtin_amdgcn_s_sleep(127);
-        }
-        return;
-    }
-    float bj[TN];
-    int colj[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        colj[j] = n0 + wn * TN * MB + j * MB + (lane & (MB - 1));
-        bj[j] = (p.bias && colj[j] < p.Cout) ? p.bias[colj[j]] : 0.f;
-    }
-    float maj[TN], mbj[TN];  // affine of the BatchNorm whose relu is being back-propagated through (data gradient), per column
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const bool on = p.mask_a && colj[j] < p.Cout;
-        const size_t g = (size_t)(smp / p.mask_group) * p.Cout + (on ? colj[j] : 0);
-        maj[j] = on ? p.mask_a[g] : 1.f;
-        mbj[j] = on ? p.mask_b[g] : 0.f;
-    }
-    // Every variant is straight-line per output row: the loads of a row (addend, ConvGRU state, residual, mask source) are issued
-    // together, unconditionally, on clamped addresses.  (The element-wise generic epilogue with its per-element divisions and
-    // dependent loads made a ConvGRU step conv spend as long in its epilogue as in its 18 taps.)
-    const int cmax = p.Cout - 1;
-    // BatchNorm statistics of the OUTPUT for the next layer, taken here (stats_out): per column sum y and sum y^2 (data gradient
-    // through relu(BatchNorm(x)), i.e. with mask_src: sum y and sum y * x, the two sums of BatchNorm's backward) over this lane's
-    // 16 TM rows, folded over the two lane halves, the WM waves (LDS) and written as ONE row of partials per workgroup tile
-    float st0[TN], st1[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) st0[j] = st1[j] = 0.f;
-    const bool want_stats = p.stats_out != nullptr && emode == DGMR_EPI_PLAIN;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < RPB; ++r) {
-            // accumulator register r of this lane: block row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) [32 x 32] / 4 (lane >> 4) + r [16 x 16]
-            const int q = M16 ? wm * TM * 16 + i * 16 + 4 * (lane >> 4) + r
-                              : wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int ni = n + (q >> sub_shift);
-            const int hh = ((h0 + ((q >> tw_shift) & (TH - 1))) << pshift) + py, ww = ((w0 + (q & (TW - 1))) << pshift) + px;
-            const size_t mrow = (size_t)((ni * oH + hh) * oW + ww) * p.Cout;
-            const size_t rrow = p.residual_up ? (((size_t)ni * (oH >> 1) + (hh >> 1)) * (oW >> 1) + (ww >> 1)) * p.Cout : mrow;
-            float v[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
-            if (p.addend) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) v[j] += p.addend[mrow + min(colj[j], cmax)];
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) v[j] = fmaf(v[j], sc, bj[j]);
-            if (emode == DGMR_EPI_PLAIN) {
-                float rs[TN], ms[TN];
-                if (p.residual) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) rs[j] = p.residual[rrow + min(colj[j], cmax)];
-                }
-                if (p.mask_src) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) ms[j] = p.mask_src[mrow + min(colj[j], cmax)];
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float o = v[j];
-                    if (p.act_relu) o = fmaxf(o, 0.f);
-                    if (p.residual) o += rs[j];
-                    if (p.mask_src) o = fmaf(ms[j], maj[j], mbj[j]) > 0.f ? o : 0.f;
-                    if (colj[j] < p.Cout) p.y[mrow + colj[j]] = o;
-                    if (want_stats) {
-                        st0[j] += o;
-                        st1[j] = fmaf(o, p.mask_src ? ms[j] : o, st1[j]);
-                    }
-                }
-            } else {  // ConvGRU step: pre_out = v; gate: y = sigmoid(v) * h; blend: y = s*h + (1-s)*relu(v), s = sigmoid(pu)
-                float hv[TN], pv[TN];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) hv[j] = p.gru_h[mrow + min(colj[j], cmax)];
-                if (emode == DGMR_EPI_GRU_BLEND) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) pv[j] = p.gru_pu[mrow + min(colj[j], cmax)];
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float o;
-                    if (emode == DGMR_EPI_GRU_BLEND) {
-                        const float sg = sigmoid_(pv[j]);
-                        o = sg * hv[j] + (1.f - sg) * fmaxf(v[j], 0.f);
-                    } else {
-                        o = sigmoid_(v[j]) * hv[j];
-                    }
-                    if (colj[j] < p.Cout) {
-                        if (p.pre_out) p.pre_out[mrow + colj[j]] = v[j];
-                        p.y[mrow + colj[j]] = o;
-                    }
-                }
-            }
-        }
-    }
-    if (want_stats) {  // (wave-uniform)
-        if (PRIV) __syncthreads();  // no barrier since the last halo: other waves may still be reading the LDS
-        float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            st0[j] += __shfl_xor(st0[j], 32, 64);
-            st1[j] += __shfl_xor(st1[j], 32, 64);
-            if (M16) {  // four lane groups hold the same column
-                st0[j] += __shfl_xor(st0[j], 16, 64);
-                st1[j] += __shfl_xor(st1[j], 16, 64);
-            }
-            if (lane < MB) {
-                const int cl = wn * TN * MB + j * MB + lane;
-                red[(wm * BN + cl) * 2 + 0] = st0[j];
-                red[(wm * BN + cl) * 2 + 1] = st1[j];
-            }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < BN * 2; idx += 256) {
-            const int cl = idx >> 1, which = idx & 1;
-            float v = 0.f;
-#pragma unroll
-            for (int q = 0; q < WM; ++q) v += red[(q * BN + cl) * 2 + which];
-            const size_t srow = phase ? (size_t)tile * 4 + ph : (size_t)tile;  // (a tile's four phases: consecutive rows)
-            if (n0 + cl < p.Cout) p.stats_out[(srow * 2 + which) * p.Cout + n0 + cl] = v;
-        }
+    };
+    if constexpr (PAIR) {
+        epilogue(accs[0], ph, 0);
+        __syncthreads();  // (the statistics rows of the first parity have been read out of `red`)
+        epilogue(accs[1], ph + 1, 1);
+    } else {
+        epilogue(accs[0], ph, px);
     }
 }
 

@@ -12,9 +12,15 @@ namespace dgmr_tu {
 int DGMR_TU_CAT(launch_window_ns, DGMR_NS)(const dgmr_conv_args& p, const WinPlan& wp, bool phases, int tune_window, hipStream_t s) {
     constexpr int NS = DGMR_NS;
     const int tw_shift = wp.tw_shift, g_shift = wp.g_shift, tiles_w = wp.tiles_w, tiles_hw = wp.tiles_hw, bnw = wp.bnw;
-    const dim3 grid((unsigned)wp.grid_x * (phases ? 4u : 1u), (unsigned)((p.Cout + bnw - 1) / bnw));
+    const dim3 grid((unsigned)wp.grid_x * (phases ? (wp.pair ? 2u : 4u) : 1u), (unsigned)((p.Cout + bnw - 1) / bnw));
 #define DGMR_GLDS(BN_, WM_, WN_, ...) \
     hipLaunchKernelGGL((conv3x3_glds_kernel<BN_, WM_, WN_, NS, __VA_ARGS__>), grid, dim3(256), 0, s, p, tw_shift, tiles_w, tiles_hw, g_shift)
+#if DGMR_NS != 6
+    if (phases && wp.pair) {  // both column parities of a row parity per workgroup (128-pixel tiles, 96 columns: window_plan)
+        DGMR_GLDS(96, 4, 1, 128, false, false, true);
+        return 0;
+    }
+#endif
     if (wp.big) {  // 256-pixel tiles (never with 128 columns: window_plan)
         if (bnw == 16) DGMR_GLDS(16, 4, 1, 256, false, true);
         else if (bnw == 96) DGMR_GLDS(96, 4, 1, 256);

@@ -465,6 +465,57 @@ def test_thin_output_tile_matches_the_other_window_tiles(tuned, n, d, h, w, cin,
     assert (ys[0] - ys[2]).abs().max().item() <= 5e-6 * sc
 
 
+# Round 5: phase launches with ONE workgroup per ROW parity that computes both column parities from one staged halo (conv_win_glds.h
+# PAIR; dgmr_debug_flags 256 / DGMR_PHASE_PAIR=1) against the default four-workgroups-per-tile scheme: the same MFMA sequence per output element - bit-identical
+# outputs and fused statistics, with BatchNorm-on-load, residual at half resolution, 32- and 16-wide input maps, 96 ... 768 columns.
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("n,h,w,cin,cout,bn,res_up", [(8, 64, 64, 96, 96, True, False), (16, 32, 32, 192, 192, True, True), (40, 128, 128, 96, 96, True, True),
+                                                      (12, 32, 32, 384, 384, False, False), (6, 64, 64, 48, 288, True, False)])
+def test_phase_pair_kernel_is_bit_identical_to_one_workgroup_per_parity(n, h, w, cin, cout, bn, res_up, prec):
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import ops
+    from skillful_nowcasting_amd._lib import call
+
+    torch.manual_seed(4)
+    x = torch.randn(n * (h // 2) * (w // 2) * cin, device=DEV)
+    wt = torch.randn(cout * 9 * cin, device=DEV) * 0.05
+    bias = torch.randn(cout, device=DEV)
+    scale = torch.rand(n, device=DEV) + 0.5
+    a = torch.rand(n * cin, device=DEV) + 0.5
+    b = torch.randn(n * cin, device=DEV) * 0.1
+    r = torch.randn(n * (h // 2) * (w // 2) * cout, device=DEV) if res_up else None
+    S.set_precision(prec)
+    outs = []
+    try:
+        wsp = torch.empty(2 * wt.numel(), device=DEV, dtype=torch.int16)
+        call("dgmr_split_weights", wt.data_ptr(), wsp.data_ptr(), cout * 9, cin, 0, 0, 2, 0, ops._stream())
+        sums = torch.empty(16 * cout * cin, device=DEV)
+        call("dgmr_upsample_phase_weights", wt.data_ptr(), sums.data_ptr(), cout, cin, ops._stream())
+        wph = torch.empty(2 * sums.numel(), device=DEV, dtype=torch.int16)
+        call("dgmr_split_weights", sums.data_ptr(), wph.data_ptr(), 16 * cout, cin, 0, 0, 2, 0, ops._stream())
+        for flags in (0, 256):
+            call("dgmr_debug_flags", flags)
+            y = torch.full((n * h * w * cout,), float("nan"), device=DEV)
+            part = ops._launch_conv(x, wt.data_ptr(), bias, scale, y, n, 1, h, w, cin, cout, 1, 3, 3, upsample=True,
+                                    pre_a=a if bn else None, pre_b=b if bn else None, pre_group=1, scale_group=1, residual=r,
+                                    residual_up=res_up, w_split=wsp, w_phase=wph, want_stats=True)
+            torch.cuda.synchronize()
+            assert part is not None and part is not NotImplemented
+            outs.append((y, part.clone()))
+    finally:
+        call("dgmr_debug_flags", 0)
+        S.set_precision("f32")
+    (y0, p0), (y1, p1) = outs
+    assert not torch.isnan(y1).any()
+    assert torch.equal(y0, y1), f"outputs differ: {(y0 - y1).abs().max().item():.3e}"
+    # statistics rows: [tiles x 4 phases][2][Cout]; the two schemes tile the map alike (128-pixel tiles) only where the four-workgroup scheme
+    # does not pick its 256-pixel tile - compare the per-sample sums, which both must reproduce
+    g = n
+    s0 = p0.double().view(g, -1, 2, cout).sum(1)
+    s1 = p1.double().view(g, -1, 2, cout).sum(1)
+    assert torch.allclose(s0, s1, rtol=1e-6, atol=1e-6 * float(s0.abs().max()))
+
+
 # conv + AvgPool (+ shortcut) as one operator (ops.ConvSpec.pool_out: DBlock's tail) against the conv followed by the pooling kernel.
 # n, d, h, w (the conv's map), cin, cout, shortcut
 POOL_OUT_CASES = [

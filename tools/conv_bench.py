@@ -112,7 +112,7 @@ def main():
         if a.startswith("--dbg="):  # kernel-phase timing switches: 1 no epilogue, 2 one halo only, 3 both (dgmr_debug_flags)
             call("dgmr_debug_flags", int(a.split("=")[1]))
     print("precision:", ops.get_precision(), flush=True)
-    only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    only = [a for a in sys.argv[1:] if not a.startswith("--")] + [a.split("=", 1)[1].replace("+", " ") for a in sys.argv[1:] if a.startswith("--shape=")]
     
     for name, n, d, h, w, cin, cout, ks, up, bn in SHAPES:
         if only and not any(o in name for o in only):

@@ -27,7 +27,7 @@ i=0
 for CTRS in "$SETA" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   CONV_BENCH_SKIP_OLD=1 CONV_BENCH_ITERS=3 timeout 400 rocprofv3 --kernel-trace --pmc $CTRS -f csv -d "$OUT/m$i" -o pmc -- \
-      python "$ROOT/tools/conv_bench.py" --prec=bf16x3 --bwd --groups=96 --phases-only "${SHAPES[@]}" > "$OUT/modes_pass$i.log" 2>&1
+      python "$ROOT/tools/conv_bench.py" --prec=bf16x3 --bwd --groups=96 --phases-only ${CONV_BENCH_EXTRA:-} "${SHAPES[@]}" > "$OUT/modes_pass$i.log" 2>&1
   echo "modes pass $i rc=$?"
   F=$(find "$OUT/m$i" -name '*counter_collection.csv' | head -1); K=$(find "$OUT/m$i" -name '*kernel_trace.csv' | head -1)
   [ -n "$F" ] && python "$ROOT/tools/pmc_agg.py" "$F" "$OUT/modes_pmc_pass$i.csv" $K conv wgrad
