@@ -327,6 +327,10 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL's version banner (NCCL_DEBUG unset or VERSION) goes to STDOUT through C stdio and can land behind the JSON line: the
+        # version is reported in the line itself (process_group.rccl_version); warnings and errors stay on
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+            os.environ["NCCL_DEBUG"] = "WARN"
         if world == 1:  # --force-dist without a launcher: a one-rank RCCL group on this GPU
             import socket
 
@@ -569,11 +573,19 @@ def main():
                 json.dump(out, f, indent=1)
         except OSError as e:  # (a read-only tree must not cost the bench line)
             detail_path = f"not written: {e}"
-        sys.stdout.flush()
-        print(compact_line(out, detail_path), flush=True)
+        final_line = compact_line(out, detail_path)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE line goes out LAST: RCCL prints a version banner through C stdio, which is flushed when it likes - seen behind the
+        # JSON line in a --force-dist run; flush C stdio first, then print
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(final_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -38,7 +38,7 @@ def family(name):
         return "3x3 window forward / data gradient"
     if any(k in name for k in ("conv_wgrad_ws_kernel", "conv_wgrad_win_kernel")):
         return "3x3 window weight gradient"
-    if "wgrad" in name and "reduce" not in name and "finalize" not in name and "sums" not in name:
+    if "wgrad" in name and not any(k in name for k in ("reduce", "finalize", "sums", "finish")):
         return "im2col weight gradient (1x1, small maps)"
     if any(k in name for k in ("conv_bf16_kernel", "conv_igemm_kernel")):
         return "implicit-GEMM conv (strided, small recurrent steps, 1x1)"
@@ -64,7 +64,8 @@ def derive(r):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     step = load(os.path.join(src, "step_pmc_by_kernel.csv"))
-    out = {"definition": "mfma_busy = sum SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x sum GRBM_GUI_ACTIVE / 8 XCDs) over the launches of a row: "
+    out = {"steps_under_counters": "2 (bench.py --warmup 1 --steps 1: rows and shares cover both; they do the same work)",
+           "definition": "mfma_busy = sum SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x sum GRBM_GUI_ACTIVE / 8 XCDs) over the launches of a row: "
                          "the share of SIMD cycles in which the matrix pipe was busy, weighted by launch duration (rocprofv3 --pmc over one "
                          "whole training step of bench.py, paper config, per-GPU batch 16, `mixed`; dispatches run serialised under the "
                          "counter pass, so co-running weight-gradient launches do not dilute each other)"}
