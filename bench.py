@@ -327,10 +327,9 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL's version banner (NCCL_DEBUG unset or VERSION) goes to STDOUT through C stdio and can land behind the JSON line: the
-        # version is reported in the line itself (process_group.rccl_version); warnings and errors stay on
-        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
-            os.environ["NCCL_DEBUG"] = "WARN"
+        # RCCL writes its version banner and its warnings to STDOUT by default: send them to stderr, stdout is for the ONE JSON line
+        # (which is also printed last, after the process group is gone and C stdio has been flushed)
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         if world == 1:  # --force-dist without a launcher: a one-rank RCCL group on this GPU
             import socket
 

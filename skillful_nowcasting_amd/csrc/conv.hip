@@ -1089,6 +1089,9 @@ extern "C" int dgmr_conv_wgrad_plan(dgmr_wgrad_args* a) {
     // the chip better when the launch runs alone - 3 chunks x 18 groups: 216 of 256 CUs with 4 slabs per group, 756 of 768 with 14,
     // +8 % in isolation - but in the training step the weight gradients share the chip with the other streams' kernels and the
     // larger partial sums cost what the fill gains: 999 vs 1000 - 1004 ms per step)
+    // (a weight-gradient workgroup - 84 KB of LDS, 8 waves x 222 registers - leaves no room on its CU for a 256-pixel-tile conv workgroup
+    //  of the main stream: beside each other the two streams share the chip by whole CUs.  With 108 call groups x 3 input chunks a launch
+    //  is 324 workgroups whatever this cap says - round 5 tried 128 ... 512 here: no difference, 880.5 ... 885.2 ms on one box)
     if (wgrad_ws()) per = std::max<int64_t>(1, std::min<int64_t>(256 / ((int64_t)per_slab * groups), tiles_per_group / 2));
     a->nsplit = (int)std::min<int64_t>(per * groups, 4096) * (phases ? 4 : 1);
     a->bias_rows = std::max(a->nsplit, colsum_rows_for(M));  // rows of dgmr_wgrad_args.bias_partial (deterministic bias gradient)
