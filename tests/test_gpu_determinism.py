@@ -107,3 +107,23 @@ def test_nonfinite_count_and_detect_anomaly():
         model.discriminator.spatial_discriminator.d1.conv_1x1.bias[0] = float("nan")
     with pytest.raises(RuntimeError, match="detect_anomaly: non-finite"):
         model.training_step((x, y), 1)
+
+
+def test_deferred_weight_gradients_change_nothing():
+    """DGMR_WGRAD_DEFER (opt-in scheduling experiment: the generator pass's weight gradients are held back until the level's ConvGRU
+    backward chain, _streams.defer_wgrads): the same kernels on the same operands, only issued later - bit-identical parameters,
+    buffers and Adam moments after three steps."""
+    import skillful_nowcasting_amd as S
+    from skillful_nowcasting_amd import _streams
+
+    ref, lref = _run(S, "mixed", 3)
+    old = _streams._DEFER_ON
+    _streams._DEFER_ON = True
+    try:
+        got, lgot = _run(S, "mixed", 3)
+        assert not _streams._DEFERRED, "weight gradients left in the deferral queue after the step"
+    finally:
+        _streams._DEFER_ON = old
+    assert lref == lgot, (lref, lgot)
+    bad = _differing(ref, got)
+    assert not bad, f"{len(bad)} tensors differ with deferred weight gradients, e.g. {bad[:5]}"
