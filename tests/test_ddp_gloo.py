@@ -176,3 +176,57 @@ def test_gradsync_two_ranks_gloo():
         p.join(60)
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def _worker_single(port, q):
+    """One rank, force_exchange: every collective still runs (over one rank they are the identity) - the path tests/test_gpu_rccl.py
+    drives through RCCL on the GPU, here over gloo on CPU tensors."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        torch.set_num_threads(1)
+        import skillful_nowcasting_amd as S
+        from skillful_nowcasting_amd import ddp
+
+        torch.manual_seed(100)
+        model = S.DGMR(**KW)
+        plain = ddp.GradSync(model)  # world 1 without force_exchange: nothing is exchanged
+        assert plain.world == 1 and not plain.exchange
+        sync = model.attach_data_parallel(chunk_mb=1, overlap=True, force_exchange=True)
+        assert sync.world == 1 and sync.exchange
+        sync.check_exchange = True
+        for which, net in (("d", model.discriminator), ("g", model.generator)):
+            params = [p for p in net.parameters() if p.requires_grad]
+            for rep in range(2):  # first pass records the touch order (every bucket late), the second launches during the "backward"
+                sync.flat_for(which).zero_()
+                sync.begin(which)
+                from skillful_nowcasting_amd import ops
+
+                expect = []
+                for i, p in enumerate(params):
+                    g = ops.grad_buffer(p)
+                    g.add_(float(i + 1) * 0.5 + rep)
+                    expect.append(g.detach().clone())
+                sync.sync(which)
+                for p, e in zip(params, expect):
+                    assert torch.equal(p.grad, e), "a one-rank exchange changed a gradient"
+        st = sync.stats
+        assert st["late_buckets"] > 0 and st["overlapped_buckets"] > 0 and st["deviations"] == 0, st
+        sync.broadcast_buffers()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put("ok")
+    except Exception:
+        q.put(traceback.format_exc())
+
+
+def test_gradsync_one_rank_force_exchange_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_single, args=(_free_port(), q))
+    p.start()
+    msg = q.get(timeout=300)
+    p.join(60)
+    assert msg == "ok", msg
