@@ -560,7 +560,7 @@ def main():
             out["roofline"] = roofline
         if also:
             out["also"] = also
-        if args.cpu_baseline != "off":
+        if args.cpu_baseline != "off" and world == 1:  # (the contract: on rank 0 at N = 1 only - the other ranks would sit in the final barrier)
             out["cpu_baseline"] = cpu_baseline_reference(kw, hw, T) or cpu_baseline(kw, hw, T)
             if args.workload in REFERENCE_MEASURED:
                 out["cpu_baseline"]["reference_measured"] = REFERENCE_MEASURED[args.workload]
