@@ -65,3 +65,31 @@ def test_line_drops_optional_blocks_rather_than_overflow():
     assert len(line) <= bench.LINE_LIMIT
     d = json.loads(line)
     assert d["roofline"]["frac"] and d["cpu_baseline"]["value"] and d["value"]
+
+
+def test_line_bound_holds_for_arbitrary_records():
+    """Property test (hypothesis): whatever the per-kernel tables, notes and process-group records look like, the line stays within the
+    limit, stays one line of valid JSON and keeps the headline, the roofline fraction and the CPU baseline."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    text = st.text(alphabet=st.characters(min_codepoint=32, max_codepoint=126), max_size=4000)
+
+    @settings(max_examples=60, deadline=None)
+    @given(n_rows=st.integers(0, 600), n_classes=st.integers(1, 80), note=text, sample=text, workload=st.text(alphabet="abcdefgh =,", max_size=400),
+           ranks=st.integers(0, 64), ms=st.floats(1e-3, 1e6, allow_nan=False))
+    def check(n_rows, n_classes, note, sample, workload, ranks, ms):
+        full = _synthetic(n_rows, n_classes)
+        full["ms_per_step"] = ms
+        full["roofline"]["note"] = note
+        full["cpu_baseline"]["sample"] = sample
+        full["config"]["workload"] = "DGMR.training_step " + workload
+        full["process_group"]["ranks_seen"] = [{"rank": i, "device": "d" * 80} for i in range(ranks)]
+        line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+        assert "\n" not in line and len(line) <= bench.LINE_LIMIT
+        d = json.loads(line)
+        assert d["metric"] and d["value"] and d["ms_per_step"] > 0 and d["n_gpus"] == 1
+        assert d["roofline"]["frac"] and d["roofline"]["bound"] == "mfma"
+        assert d["cpu_baseline"]["value"] and d["cpu_baseline"]["kind"] == "reference"
+
+    check()
