@@ -134,7 +134,7 @@ def test_two_ranks_on_one_gpu_real_steps():
     # rank's generator-pass gradients still differ between identical runs in about every other pair of runs: a few dozen elements of
     # the gradient the sampler's output layer hands to up_g4, although that layer's recorded inputs are identical and it is
     # bit-reproducible in isolation under the same contention (tools/det_probe_ddp.py, tools/head_race_probe.py; no read of unwritten
-    # memory and no stray write: tools/poison_probe.py, tools/guard_probe.py).  Open; DESIGN.md section 6.  Bit identity is therefore
+    # memory and no stray write: tools/poison_probe.py, tools/guard_probe.py).  Open; DESIGN.md section 2.  Bit identity is therefore
     # reported here, not asserted; the bounds below are the ones that held through rounds 1 - 4.
     print(f"bit-identical: two late-exchange runs {torch.equal(late, late_b)}, overlapped vs late {torch.equal(overlapped, late)}")
     err0, cos0, frac0 = _compare(late_b, late, init)
