@@ -331,7 +331,9 @@ int dgmr_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const
 int dgmr_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const double* sums, const float* dx_add, float* dx, float* dgamma, float* dbeta, int G, int64_t R,
                       int C, int train, void* stream);
-/* out[c] (+)= sum_r x[r][c]  (conv / linear bias gradient).  tmp: 2*C doubles of scratch. */
+/* out[c] (+)= sum_r x[r][c]  (conv / linear bias gradient).  tmp: 2*C doubles of scratch (deterministic mode:
+ * dgmr_reduce_doubles(1, R, C)), cleared by the call itself; not touched at all when R <= 4096 && C >= 4096 && C % 4 == 0
+ * (few rows, many columns: one thread per column quad) - any non-NULL pointer will do there. */
 int dgmr_colsum(const float* x, float* out, double* tmp, int64_t R, int C, int accumulate, void* stream);
 /* y = x*a[g][c]+b[g][c]  (BatchNorm1d apply; no relu) */
 int dgmr_affine(const float* x, const float* a, const float* b, float* y, int G, int64_t R, int C, int relu, void* stream);

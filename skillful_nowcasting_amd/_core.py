@@ -53,17 +53,28 @@ def deterministic() -> bool:
     return _DETERMINISTIC
 
 
-def sums_buffer(groups: int, rows: int, c: int, device, row_blocks: bool = True) -> torch.Tensor:
+def sums_buffer(groups: int, rows: int, c: int, device, row_blocks: bool = True, zero: bool = True) -> torch.Tensor:
     """`sums` / `tmp` of a per-channel reduction over [groups][rows][c]: groups * 2 * c doubles, zeroed; in deterministic mode followed
-    by the library's per-workgroup rows (dgmr_reduce_doubles; row_blocks=False: dgmr_bn_partial_reduce needs none)."""
+    by the library's per-workgroup rows (dgmr_reduce_doubles; row_blocks=False: dgmr_bn_partial_reduce needs none).
+    zero=False: scratch of dgmr_colsum, which clears what it uses itself."""
     n = groups * 2 * c
     if not (_DETERMINISTIC and row_blocks):
-        return torch.zeros(n, device=device, dtype=torch.float64)
+        return torch.zeros(n, device=device, dtype=torch.float64) if zero else torch.empty(n, device=device, dtype=torch.float64)
     from ._lib import load
 
     buf = torch.empty(int(load().dgmr_reduce_doubles(groups, rows, c)), device=device, dtype=torch.float64)
-    buf[:n].zero_()
+    if zero:
+        buf[:n].zero_()
     return buf
+
+
+def colsum_tmp(rows: int, c: int, device) -> torch.Tensor:
+    """`tmp` of dgmr_colsum over [rows][c].  Few rows x many columns go through a column-parallel kernel that never touches tmp (ops.hip:
+    R <= 4096, C >= 4096, C % 4 == 0 - the backward of a batch repeat / a group sum): two doubles stand in there instead of the
+    deterministic mode's per-workgroup rows (tens of MB per call)."""
+    if rows <= 4096 and c >= 4096 and c % 4 == 0:
+        return torch.empty(2, device=device, dtype=torch.float64)
+    return sums_buffer(1, rows, c, device, zero=False)
 
 
 def dot_buffer(groups: int, device) -> torch.Tensor:

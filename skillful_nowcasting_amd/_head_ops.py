@@ -11,7 +11,7 @@ import torch
 from torch.autograd import Function
 
 from ._lib import ConvArgs, WgradArgs, call
-from ._core import (BNState, SNCall, _copy, _dims, _p, _stream, bn_prepare, dot_buffer, empty_cl, grad_buffer, require_hip, sums_buffer,
+from ._core import (BNState, SNCall, _copy, _dims, _p, _stream, bn_prepare, dot_buffer, empty_cl, grad_buffer, require_hip, sums_buffer, colsum_tmp,
                     to_cl)
 
 
@@ -192,7 +192,7 @@ class MeanFn(Function):
         x = x.contiguous()
         n = x.numel()
         out = torch.empty((), device=x.device, dtype=torch.float32)
-        tmp = sums_buffer(1, n, 1, x.device)
+        tmp = colsum_tmp(n, 1, x.device)
         call("dgmr_colsum", _p(x), _p(out), _p(tmp), n, 1, 0, _stream())
         call("dgmr_axpby", _p(out), None, _p(out), sign / n, 0.0, 1, _stream())
         ctx.n, ctx.sign, ctx.shape = n, sign, x.shape

@@ -12,7 +12,7 @@ import torch
 from torch.autograd import Function
 
 from ._lib import ConvArgs, WgradArgs, call
-from ._core import _copy, _dims, _p, _stream, empty_cl, require_hip, sums_buffer, to_cl
+from ._core import _copy, _dims, _p, _stream, colsum_tmp, empty_cl, require_hip, sums_buffer, to_cl
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -185,7 +185,7 @@ class RepeatBatchFn(Function):
         dout = to_cl(dout)
         n = dout.numel() // ctx.repeat
         dx = empty_cl((dout.shape[0] // ctx.repeat,) + tuple(dout.shape[1:]), dout)
-        tmp = sums_buffer(1, ctx.repeat, n, dout.device)
+        tmp = colsum_tmp(ctx.repeat, n, dout.device)
         call("dgmr_colsum", _p(dout), _p(dx), _p(tmp), ctx.repeat, n, 0, _stream())
         return dx, None
 
@@ -335,7 +335,7 @@ class SumGroupsFn(Function):
         x = x.contiguous()
         n = x.shape[0] // groups
         out = torch.empty(n, 1, device=x.device, dtype=torch.float32)
-        tmp = sums_buffer(1, groups, n, x.device)
+        tmp = colsum_tmp(groups, n, x.device)
         call("dgmr_colsum", _p(x), _p(out), _p(tmp), groups, n, 0, _stream())
         ctx.groups, ctx.n = groups, n
         return out

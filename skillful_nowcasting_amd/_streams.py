@@ -99,10 +99,13 @@ class defer_wgrads:
     def __enter__(self):
         _DEFER_OPEN[0] += 1
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, exc, tb):
         _DEFER_OPEN[0] -= 1
         if not _DEFER_OPEN[0]:
-            flush_deferred()
+            if exc_type is not None:
+                _DEFERRED.clear()  # the backward pass died: its held-back weight gradients are not wanted (and their operands may be stale)
+            else:
+                flush_deferred()
 
 
 def flush_deferred():

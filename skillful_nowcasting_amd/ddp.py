@@ -296,7 +296,7 @@ class GradSync:
         if self.check_exchange:
             self._verify_exchange(fg)
         self._scale(fg.flat, 1.0 / self.world)
-        if ps.recorded is None and self._touches:
+        if ps.recorded is None and self.overlap and self._touches:  # (a mismatch switches overlap off: checked once, not every step)
             self._record(fg, ps)
 
     def _record(self, fg: FlatGrads, ps: _Pass):
@@ -312,7 +312,11 @@ class GradSync:
         # values; the pass state is committed only on success - a caller that catches the error and goes on keeps exchanging
         # un-overlapped, back to front, which pairs by bucket index on every rank
         if self.exchange:
-            h = 0
+            # (seeded with the one process-level switch that moves the touch order - DGMR_WGRAD_DEFER fires the gradient-buffer touches at
+            #  flush time: ranks that disagree on it must not overlap)
+            from . import _streams
+
+            h = 7 if _streams._DEFER_ON else 0
             for b in order:
                 h = (h * 1000003 + b + 1) % 2147483629
             t = torch.tensor([h, -h], dtype=torch.int64, device=fg.flat.device if fg.flat.is_cuda else "cpu")

@@ -266,11 +266,16 @@ class DGMR(
         # backward does not read D's parameters, so it runs beside the tail of D's weight gradients (second stream, ops.py) and the
         # step comes after it.  Same operations, same RNG order, same results as "backward; step; forward".
         d_step_pending = False
+        d_loss_pending = []
 
         def finish_d_step():
             ops.join_side_streams()
             if self.grad_sync is not None:
                 self.grad_sync.sync("d")
+            if self.detect_anomaly:
+                # AFTER the exchange: every rank scans the same, fully reduced gradients (a scan between begin() and sync() would read
+                # buckets the communication stream is still writing, and a rank that raised alone would leave the others in sync())
+                self._check_finite("the discriminator pass", d_loss_pending, self.discriminator)
             d_opt.step()
 
         for _ in range(2):
@@ -298,9 +303,7 @@ class DGMR(
                 if self.grad_sync is not None:
                     self.grad_sync.abort()  # (no stale touch hook for whatever runs backward next)
                 raise
-            if self.detect_anomaly:
-                ops.join_side_streams()
-                self._check_finite("the discriminator pass", [discriminator_loss], self.discriminator)
+            d_loss_pending[:] = [discriminator_loss]
             d_step_pending = True
         ######################
         # Optimize Generator #
@@ -323,11 +326,11 @@ class DGMR(
                 if self.grad_sync is not None:
                     self.grad_sync.abort()
                 raise
+            if self.grad_sync is not None:
+                self.grad_sync.sync("g")
             if self.detect_anomaly:
                 ops.join_side_streams()
                 self._check_finite("the generator pass", [generator_loss, grid_cell_reg], self.generator)
-            if self.grad_sync is not None:
-                self.grad_sync.sync("g")
             g_opt.step()
             SNScope.weights_changed(self.generator)
         finally:  # an exception (OOM, a refused launch) must not leave the discriminator frozen for a caller that retries

@@ -27,7 +27,7 @@ from ._lib import ConvArgs, WgradArgs, call
 from . import _core, _streams
 from ._core import (BNState, CallLayout, SNCall, SPLITK_WS_BYTES, _copy, _dims, _p, _scratch, _splitk_ws, _stream, bn_prepare,  # noqa: F401
                     bias_rows, bump_weights_epoch, call_slots, deterministic, dot_buffer, empty_cl, grad_buffer, require_hip,
-                    require_weight_layout, set_deterministic, set_grad_touch_hook, sums_buffer, to_cl, weights_epoch)
+                    require_weight_layout, set_deterministic, set_grad_touch_hook, sums_buffer, colsum_tmp, to_cl, weights_epoch)
 from ._head_ops import (AttentionFn, AxpbyFn, BatchNorm1dFn, GridCellFn, HingeDiscFn, MeanFn, ReluSumHWFn, SNLinear1Fn, adam_update,  # noqa: F401
                         attention, axpby, relu_sum_hw)
 from ._layout_ops import (CatChannelsFn, D2SFramesFn, FramesS2DFn, FramesToBatchFn, PoolAddFn, RepeatBatchFn, StackBatchFn,  # noqa: F401
@@ -508,7 +508,7 @@ class ConvFn(Function):
         # ---- bias: column sums of dy ride along in the weight-gradient kernel; standalone only when W is frozen ----
         want_bias = bias is not None and bias.requires_grad
         if want_bias and not w.requires_grad:
-            tmp = sums_buffer(1, m, cout, dev)
+            tmp = colsum_tmp(m, cout, dev)
             call("dgmr_colsum", _p(dy), _p(grad_buffer(bias)), _p(tmp), m, cout, 1, st)
         # ---- weight (and scale) ----
         groups = spec.groups
@@ -960,7 +960,7 @@ class ConvGRUFn(Function):
                 want_bias = bias is not None and bias.requires_grad
                 if not w.requires_grad:
                     if want_bias:
-                        tmpd = sums_buffer(1, m, ch, dev)
+                        tmpd = colsum_tmp(m, ch, dev)
                         call("dgmr_colsum", _p(dp), _p(grad_buffer(bias)), _p(tmpd), m, ch, 1, st)
                     continue
                 g = torch.empty(ch * taps * ct, device=dev, dtype=torch.float32)
