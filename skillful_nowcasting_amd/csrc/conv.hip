@@ -1175,7 +1175,7 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
             else if (rows_in_kernel) q.bias_grad = a->bias_partial, q.bias_stride = a->Cout;
             else if (bias_rows_mode) q.bias_grad = nullptr;
             DGMR_BY_NS(launch_wgrad_window, q, grid, tw_shift, tiles_w, tiles_hw, tiles_per_split, spg, tiles_per_group,
-                       wgrad_ws() ? (1 | ((g_debug_flags & 16) >> 3) | (g_tune_wgrad_window != 2 && g_precision != 3 ? 4 : 0) | (kd << 8)) : 0, s);
+                       wgrad_ws() ? (1 | ((g_debug_flags & 16) >> 3) | (g_tune_wgrad_window != 2 && g_precision != 3 ? 4 : 0) | (g_tune_wgrad_window == 5 ? 32 : 0) | (kd << 8)) : 0, s);
             DGMR_CHECK_LAUNCH();
         }
         if (rows_in_kernel) bias_rows_finish(a->nsplit);
@@ -1353,7 +1353,7 @@ extern "C" int dgmr_get_precision(void) { return g_precision; }
 
 extern "C" int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window) {
     DGMR_CHECK_ARG(variant >= -1 && variant <= V_F128x32 && ksplit >= -1 && window >= -1 && window <= 7 && wgrad_window >= -1 &&
-                       wgrad_window <= 4,
+                       wgrad_window <= 5,
                    "dgmr_conv_tune: variant %d ksplit %d window %d wgrad_window %d", variant, ksplit, window, wgrad_window);
     g_tune_variant = variant;
     g_tune_ksplit = ksplit;

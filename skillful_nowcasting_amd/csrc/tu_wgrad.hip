@@ -33,6 +33,21 @@ int DGMR_TU_CAT(launch_wgrad_window_ns, DGMR_NS)(const dgmr_wgrad_args& p, dim3 
         hipLaunchKernelGGL((conv_wgrad_ws_kernel<BI_, NS, TWS_, 3>), dim3(grid.x * grid.y * grid.z), dim3(448), 0, s, p, tiles_w,    \
                            tiles_hw, tiles_per_split, splits_per_group, tiles_per_group, ws & 0xff, (ws >> 8) & 0xff);           \
     } while (0)
+        // <= 48 output channels, four matrix waves, bf16 / bf16x3, no phases: the pixel-split 48-column tile (ws bit 32 keeps the
+        // 64-column one: dgmr_conv_tune wgrad_window = 5, the A/B reference)
+        bool done = false;
+        if constexpr (NS != 6) {
+            if (p.Cout <= 48 && (ws & 4) && !(ws & 8) && !(ws & 32)) {
+                if (tw_shift == 5)
+                    hipLaunchKernelGGL((conv_wgrad_ws_kernel<48, NS, 5, 4, false, true>), dim3(grid.x * grid.y * grid.z), dim3(512), 0, s, p, tiles_w,
+                                       tiles_hw, tiles_per_split, splits_per_group, tiles_per_group, ws & 0x1f, (ws >> 8) & 0xff);
+                else
+                    hipLaunchKernelGGL((conv_wgrad_ws_kernel<48, NS, 4, 4, false, true>), dim3(grid.x * grid.y * grid.z), dim3(512), 0, s, p, tiles_w,
+                                       tiles_hw, tiles_per_split, splits_per_group, tiles_per_group, ws & 0x1f, (ws >> 8) & 0xff);
+                done = true;
+            }
+        }
+        if (done) return 0;
         if (b96) {
             if (tw_shift == 5) DGMR_WGS(96, 5);
             else DGMR_WGS(96, 4);

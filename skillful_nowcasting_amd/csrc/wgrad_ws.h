@@ -75,7 +75,14 @@ __device__ __forceinline__ void ws_interleave() {
 //         3 x 3-tap gradient on the upsampled one: 16 instead of 36 multiply steps per input pixel, as forward and data gradient
 //         already run.  Every launch writes a complete 9-tap slab (each G into the taps it feeds); the four parities of a slab are
 //         consecutive rows of `partial` (slab_mul = 4), which the reduction sums like any other slabs.
-template <int BI, int NS, int TWS, int MW = 3, bool PHASE = false>
+// PSPLIT (MW = 4, BI = 48; round 6): 48 output channels are three 16-channel blocks, which do not split over two wave halves - the
+//         64-column tile ran the 48-channel layers (up_g4.last_conv_3x3 at 128 x 128, the fourth ConvGRU, the context stack's second
+//         block, the temporal discriminator's 3-D blocks) with a quarter of its MFMAs on padding (PMC, round 5: 27.6 % pipe busy, the
+//         third-largest kernel of the step).  Here the four matrix waves split the PIXELS instead: wave (ci half, pixel half) owns 16
+//         input channels x all 48 output channels x 9 taps = 27 accumulators (the BI = 96 count) and multiplies ONE of the tile's
+//         two 32-pixel steps - 81 instead of 108 MFMAs per wave and tile, none on padding.  The two pixel halves of a slab meet once,
+//         after the last tile, through LDS (fixed order: half 0 + half 1).
+template <int BI, int NS, int TWS, int MW = 3, bool PHASE = false, bool PSPLIT = false>
 __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr_wgrad_args p, const int tiles_w, const int tiles_hw,
                                                            const int tiles_per_split, const int splits_per_group,
                                                            const int tiles_per_group, const int dbg, const int kd, const int ph = 0,
@@ -97,11 +104,15 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
     constexpr int XP = (XITEMS + NL - 1) / NL, YP = YITEMS / NL;
     // a loader thread's dY items i, i + BSN, ... have the same channel quad (items advance by NL % YQ quads): 3 (BI 96) / 1 (BI 64)
     constexpr int BSN = NL % YQ == 0 ? 1 : YQ / ws_gcd(NL % YQ, YQ);
-    static_assert(BI == 64 || BI == 96, "BI");
+    static_assert(BI == 64 || BI == 96 || (BI == 48 && PSPLIT), "BI");
+    static_assert(!PSPLIT || (MW == 4 && !PHASE && BI == 48 && NP <= 2), "pixel-split tile");
+    constexpr int NACC4 = 9 * 3 * 4;                   // accumulator registers of a PSPLIT matrix wave
+    constexpr int RED_DW = ((NL % (BI / 4) == 0 ? 1 : (BI / 4) / ws_gcd(NL % (BI / 4), BI / 4)) * NL * 4);  // dwords of the bias sums (`red`)
+    constexpr int EXCH_DW = PSPLIT ? 2 * NACC4 * 64 : 0;  // the pixel halves' exchange: [ci half][register][lane]
     static_assert(TWS == 5 || TWS == 4, "tile width");
     static_assert(YITEMS % NL == 0 && YP % BSN == 0, "dY items per loader thread");
 
-    __shared__ __attribute__((aligned(16))) uint32_t smem[2 * BUF];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[(2 * BUF > RED_DW + EXCH_DW) ? 2 * BUF : RED_DW + EXCH_DW];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the role branch and the loops below are uniform control flow)
@@ -278,13 +289,14 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
         if (want_bias) {
 #pragma unroll
             for (int i = 0; i < BSN; ++i) *reinterpret_cast<f32x4*>(red + (i * NL + lt) * 4) = bsum[i];
-            __syncthreads();
         }
+        if (want_bias || PSPLIT) __syncthreads();  // (PSPLIT: the matrix waves' pixel halves meet at this barrier too)
     } else {
         // ============================================= matrix waves =============================================
         if constexpr (MW == 4) {
-            constexpr int CBH = BI / 32;  // 16-channel output blocks of this wave's half
-            const int cih = wid & 1, coh = wid >> 1;
+            constexpr int CBH = PSPLIT ? 3 : BI / 32;  // 16-channel output blocks of this wave (PSPLIT: all three; else its half's)
+            const int cih = wid & 1, coh = PSPLIT ? 0 : wid >> 1;
+            const int psh = PSPLIT ? wid >> 1 : 0;  // PSPLIT: which 32-pixel step of every tile this wave multiplies
             constexpr int NT = PHASE ? 4 : 9;  // taps a wave accumulates
             f32x4 acc[NT][CBH];
 #pragma unroll
@@ -321,7 +333,25 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
                         for (int c = 0; c < CBH; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[c], x[t], acc[t][c], 0, 0, 0);
                 };
                 constexpr int M = NT * CBH, RX = 2 * NT, RY = CBH * 2, RX0 = PHASE ? 4 : 6;
-                if constexpr (NP == 2) {  // (product order and fragment rotation as in the three-wave variant below)
+                if constexpr (PSPLIT) {
+                    // one 32-pixel step per wave: hi.lo + lo.hi + hi.hi with the second product's fragments read in the first one's shadow
+                    if constexpr (NP == 2) {
+                        bf16x8_t y0[CBH], y1[CBH], x0[NT], x1[NT];
+                        fetch_y(psh, 0, y0), fetch_x(psh, 1, x1);
+                        __builtin_amdgcn_sched_group_barrier(0x100, RY + RX0, 0);
+                        fetch_y(psh, 1, y1), fetch_x(psh, 0, x0);
+                        mm(y0, x1);  // hi(dY) . lo(x)
+                        ws_interleave<RX - RX0 + RX + RY, M, 0>();
+                        mm(y1, x0);  // lo(dY) . hi(x)
+                        __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
+                        mm(y0, x0);  // hi . hi
+                        __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
+                    } else {
+                        bf16x8_t xf[NT], yf[CBH];
+                        fetch_y(psh, 0, yf), fetch_x(psh, 0, xf);
+                        mm(yf, xf);
+                    }
+                } else if constexpr (NP == 2) {  // (product order and fragment rotation as in the three-wave variant below)
                     bf16x8_t y0[2][CBH], x0[NT], x1[NT], y1[CBH];
                     fetch_y(0, 0, y0[0]), fetch_x(0, 1, x1);
                     __builtin_amdgcn_sched_group_barrier(0x100, RY + RX0, 0);  // dY and the first filter row of x: the first MFMAs can start
@@ -356,11 +386,33 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
                 if (t + 1 < nt && !(dbg & 2)) compute(1);
                 __syncthreads();
             }
+            if constexpr (PSPLIT) {
+                // the slab's two pixel halves: half 1 hands its accumulators over through LDS (the tile images are free now; behind `red`),
+                // half 0 adds them - a fixed order - and writes the slab
+                float* ex = reinterpret_cast<float*>(smem) + RED_DW + cih * (NACC4 * 64) + lane;
+                if (psh == 1) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int c = 0; c < CBH; ++c)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) ex[((t * CBH + c) * 4 + r) * 64] = acc[t][c][r];
+                }
+                __syncthreads();  // (the loaders' bias sums are published by the same barrier)
+                if (psh == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int c = 0; c < CBH; ++c)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[t][c][r] += ex[((t * CBH + c) * 4 + r) * 64];
+                }
+            }
             // ---- partial[slab][co][tap*Cin + ci]: lane = input channel (16 per wave), 4 output channels per lane and block ----
             const int Ktot = 9 * p.KD * p.Cin, tap0 = (p.KD == 3 ? kd : 0) * 9;
             float* out = p.partial + ((size_t)slab * slab_mul + (PHASE ? ph : 0)) * p.Cout * Ktot;
             const int ci = chunk * CK + cih * 16 + (lane & 15);
-            if (ci < p.Cin) {
+            if (ci < p.Cin && psh == 0) {
 #pragma unroll
                 for (int c = 0; c < CBH; ++c)
 #pragma unroll
@@ -489,7 +541,7 @@ __global__ __launch_bounds__(MW * 64 + 256) void conv_wgrad_ws_kernel(const dgmr
         }
         if (want_bias) {  // (deterministic within the workgroup; across workgroups one float atomic per channel - or, with
                           //  dgmr_wgrad_args.bias_partial, a row of its own per slab that dgmr_conv_wgrad adds up in order)
-            __syncthreads();  // the loaders have written their sums: slot i of thread lt covers channel quad (lt + i NL) mod YQ
+            if (!PSPLIT) __syncthreads();  // the loaders have written their sums: slot i of thread lt covers channel quad (lt + i NL) mod YQ
             if (tid < BI && co0 + tid < p.Cout) {
                 const int q = tid >> 2, comp = tid & 3;
                 float total = 0.f;

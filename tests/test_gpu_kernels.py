@@ -193,6 +193,9 @@ WGRAD_CASES = [
     (5, 32, 32, 64, 96, False, True, 1),     # 80 tiles over 40 slabs ... an odd number of tiles per slab where the plan says so
     (1, 64, 32, 24, 200, True, False, 1),    # ragged input chunk (24 of 32 channels), 200 = 3 x 64 + 8 output channels
     (3, 16, 32, 96, 288, False, True, 3),    # 288 = 3 x 96 output-channel tiles
+    (3, 32, 32, 96, 48, False, True, 3),     # 48 output channels: the pixel-split tile (wgrad_ws.h PSPLIT), three input-channel chunks
+    (4, 16, 16, 48, 48, False, False, 2),    # ... on 16-wide maps, ragged second chunk (48 = 32 + 16 input channels)
+    (5, 64, 32, 24, 40, False, True, 1),     # ... 40 of 48 columns, 24 of 32 input channels, an odd number of tiles per slab
 ]
 # 3 x 3 x 3 convs (n, depth, h, w, cin, cout, call groups): the temporal discriminator's first blocks - one window launch per depth tap
 WGRAD_CASES_3D = [(2, 6, 32, 32, 48, 96, 2), (1, 5, 16, 32, 8, 48, 1), (3, 2, 32, 64, 96, 96, 3)]

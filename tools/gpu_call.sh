@@ -43,7 +43,8 @@ for STEP in "$@"; do
       LAST_MS=$(python -c "import json; print(1.02*json.loads([l for l in open('$OUT/prof_run_$n.log') if l.startswith('{')][-1])['ms_per_step'])" 2>/dev/null || echo 0)
       echo "steady-state window: $LAST_MS ms"
       [ -n "$KT" ] && python tools/trace_by_grid.py "$KT" "$OUT/prof_keep_$n/kernel_by_grid.csv" $LAST_MS "$OUT/prof_keep_$n/kernel_stats_last_step.csv" \
-        && python tools/trace_gaps.py "$KT" "$OUT/prof_keep_$n/kernel_gaps.txt" 20 $LAST_MS
+        && python tools/trace_gaps.py "$KT" "$OUT/prof_keep_$n/kernel_gaps.txt" 20 $LAST_MS \
+        && python tools/trace_streams.py "$KT" "$OUT/prof_keep_$n/kernel_streams.txt" $LAST_MS > /dev/null
       rm -rf "$OUT/prof$n"; head -25 "$OUT/prof_keep_$n/kernel_stats_last_step.csv" | cut -c1-160 ;;
     pmc)
       SKIP_STEP=${ARG:-0} bash tools/r5_pmc.sh "$TAG/pmc" ;;
