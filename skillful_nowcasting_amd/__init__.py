@@ -4,11 +4,22 @@ Mirrors ``dgmr/__init__.py:3-6`` of openclimatefix/skillful_nowcasting: same pub
 signatures, attribute names and ``state_dict`` keys; the arithmetic runs as hand-written HIP kernels for
 gfx950 in ``lib/libdgmr_hip.so`` (C ABI: ``include/dgmr_hip.h``).
 """
-from .common import ContextConditioningStack, LatentConditioningStack
-from .dgmr import DGMR
-from .discriminators import Discriminator, SpatialDiscriminator, TemporalDiscriminator
-from .generators import Generator, Sampler
-from .ops import deterministic, get_precision, set_deterministic, set_precision
+import os as _os
+
+# The step runs its data-gradient chain, its weight gradients, the spectral-norm plans and (data parallel) the gradient exchange on
+# separate HIP streams.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order:
+# with RCCL's own streams in the process the weight-gradient stream landed on the SAME hardware queue as the main chain and the
+# two serialised - the whole of the "+6 % with a process group" of round 5 (rocprofv3: every weight-gradient kernel on the main
+# queue; 931.6 ms with 4 queues, 882.4 with 8, 870.8 without a process group; profiles/r06_force_dist_hw_queues.log).  Eight queues
+# unless the user says otherwise; read by the runtime when HIP initialises, so it must be in the environment before the first
+# device call of the process (import this package - or export the variable - before touching torch.cuda).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from .common import ContextConditioningStack, LatentConditioningStack  # noqa: E402
+from .dgmr import DGMR  # noqa: E402
+from .discriminators import Discriminator, SpatialDiscriminator, TemporalDiscriminator  # noqa: E402
+from .generators import Generator, Sampler  # noqa: E402
+from .ops import deterministic, get_precision, set_deterministic, set_precision  # noqa: E402
 
 
 

@@ -1042,6 +1042,12 @@ static inline int colsum_rows_for(int64_t M) { return (int)std::max<int64_t>(1, 
 // which of the two window kernels: the wave-specialised one (wgrad_ws.h; dgmr_conv_tune wgrad_window 2: three matrix waves, 3 = automatic:
 // four matrix waves in bf16 / bf16x3, three in bf16x6) or the one-role kernel of round 2 (wgrad_win.h; 1)
 static bool wgrad_ws() { return g_tune_wgrad_window != 1; }
+// DGMR_WGRAD_PSPLIT=0: the 48-channel layers' weight gradients on the 64-column tile as in rounds 3 - 5 (A/B switch for the pixel-split
+// 48-column tile of wgrad_ws.h; dgmr_conv_tune wgrad_window = 5 does the same inside a process, without the phase launches)
+static const bool g_wgrad_psplit = []() {
+    const char* e = getenv("DGMR_WGRAD_PSPLIT");
+    return !(e && e[0] == '0');
+}();
 // (3 x 3 x 3 convs, without upsampling: the wave-specialised kernel only, one launch per depth tap)
 static bool wgrad_uses_window(const dgmr_wgrad_args* a) {
     const bool k2d = a->KD == 1 && a->D == 1, k3d = a->KD == 3 && a->D >= 1 && !a->upsample && wgrad_ws();
@@ -1175,7 +1181,7 @@ extern "C" int dgmr_conv_wgrad(const dgmr_wgrad_args* a, void* stream) {
             else if (rows_in_kernel) q.bias_grad = a->bias_partial, q.bias_stride = a->Cout;
             else if (bias_rows_mode) q.bias_grad = nullptr;
             DGMR_BY_NS(launch_wgrad_window, q, grid, tw_shift, tiles_w, tiles_hw, tiles_per_split, spg, tiles_per_group,
-                       wgrad_ws() ? (1 | ((g_debug_flags & 16) >> 3) | (g_tune_wgrad_window != 2 && g_precision != 3 ? 4 : 0) | (g_tune_wgrad_window == 5 ? 32 : 0) | (kd << 8)) : 0, s);
+                       wgrad_ws() ? (1 | ((g_debug_flags & 16) >> 3) | (g_tune_wgrad_window != 2 && g_precision != 3 ? 4 : 0) | ((g_tune_wgrad_window == 5 || !g_wgrad_psplit) ? 32 : 0) | (kd << 8)) : 0, s);
             DGMR_CHECK_LAUNCH();
         }
         if (rows_in_kernel) bias_rows_finish(a->nsplit);

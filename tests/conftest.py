@@ -1,7 +1,9 @@
 import os
 import sys
 
-import pytest
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (as skillful_nowcasting_amd/__init__.py does; here because collection touches torch.cuda first)
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
