@@ -21,8 +21,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # (before anything initialises HIP: see skillful_nowcasting_amd/__init__.py - streams beyond the runtime's default of four hardware
-#  queues share one, which serialised the weight-gradient stream with the main chain whenever a process group existed)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+#  queues share one, which serialised the weight-gradient stream with the main chain whenever a process group existed; one process per
+#  GPU only - never where several processes share a device)
+if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or "--force-dist" in sys.argv:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak

@@ -10,10 +10,13 @@ import os as _os
 # separate HIP streams.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order:
 # with RCCL's own streams in the process the weight-gradient stream landed on the SAME hardware queue as the main chain and the
 # two serialised - the whole of the "+6 % with a process group" of round 5 (rocprofv3: every weight-gradient kernel on the main
-# queue; 931.6 ms with 4 queues, 882.4 with 8, 870.8 without a process group; profiles/r06_force_dist_hw_queues.log).  Eight queues
-# unless the user says otherwise; read by the runtime when HIP initialises, so it must be in the environment before the first
-# device call of the process (import this package - or export the variable - before touching torch.cuda).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# queue; 931.6 ms with 4 queues, 882.4 with 8, 870.8 without a process group; profiles/r06_force_dist_hw_queues.log).  So: eight
+# queues for a rank of a multi-process job (one process per GPU - torchrun sets WORLD_SIZE), unless the user has set the variable.
+# NOT for everybody: two processes with eight queues each on ONE GPU oversubscribe its queue slots and crawl (tests/test_gpu_ddp.py:
+# 9 minutes instead of 20 s).  The runtime reads the variable when HIP initialises: import this package - or export the variable -
+# before the first device call of the process.
+if int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .common import ContextConditioningStack, LatentConditioningStack  # noqa: E402
 from .dgmr import DGMR  # noqa: E402

@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdgmr_hip.so")
+# DGMR_LIB=<path>: load another build of the library (A/B runs of a compiler flag or an experimental kernel; the tests use the default)
+LIB_PATH = os.environ.get("DGMR_LIB") or os.path.join(_HERE, "lib", "libdgmr_hip.so")
 ABI_VERSION = 11
 
 P = c_void_p  # every device pointer and the stream travel as void*

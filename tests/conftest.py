@@ -1,9 +1,7 @@
 import os
 import sys
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (as skillful_nowcasting_amd/__init__.py does; here because collection touches torch.cuda first)
-
-import pytest  # noqa: E402
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

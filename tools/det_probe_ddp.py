@@ -16,7 +16,7 @@ STEPS = int(os.environ.get("PROBE_STEPS", "1"))
 
 def worker(rank, world, port, out, q):
     try:
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), GPU_MAX_HW_QUEUES="4")  # (two ranks on ONE device)
         import torch.distributed as dist
 
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -136,10 +136,12 @@ def compare(out):
                 e = (ta.double() - tb.double()).abs().max().item() / max(tb.double().abs().max().item(), 1e-300)
                 if shown == 0:
                     print(f"rank {rank} identical before it:", [n_.replace("discriminator.", "D.") for n_, _ in ga[max(0, idx_ - 4):idx_]], "next:", [n_ for n_, _ in ga[idx_:idx_ + 3]])
-                    pix = sorted({(int(i[0]), int(i[2]), int(i[3])) for i in nz})
-                    print(f"rank {rank} differing pixels (n, h, w): {pix[:16]}; channels per pixel:", [int(((nz[:, 0] == a_) & (nz[:, 2] == b_) & (nz[:, 3] == c_)).sum()) for a_, b_, c_ in pix[:16]])
                     d = (ta.double() - tb.double()).abs()
                     nz = (d > 0).nonzero()
+                    if nz.shape[1] == 4:
+                        pix = sorted({(int(i[0]), int(i[2]), int(i[3])) for i in nz})
+                        print(f"rank {rank} differing pixels (n, h, w): {pix[:16]}; channels per pixel:", [int(((nz[:, 0] == a_) & (nz[:, 2] == b_) & (nz[:, 3] == c_)).sum()) for a_, b_, c_ in pix[:16]])
+                        print(f"rank {rank} differing channels:", sorted({int(i[1]) for i in nz})[:48])
                     print(f"rank {rank} first differing tensor: {nz.shape[0]} of {d.numel()} elements differ; index ranges per dim:",
                           [(int(nz[:, k].min()), int(nz[:, k].max())) for k in range(nz.shape[1])], "strides", ta.stride())
                     big = (d > 0.01 * tb.abs().max()).nonzero()
