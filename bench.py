@@ -256,7 +256,7 @@ def compact_line(full, detail_path=None, limit=LINE_LIMIT):
     line still exceed `limit` bytes."""
     out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median",
                                     "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "hbm") if k in full}
-    for k in ("replicas_in_sync",):
+    for k in ("replicas_in_sync", "wgrad_tail_balance"):
         if k in full:
             out[k] = full[k]
     pg = full.get("process_group")
@@ -597,6 +597,14 @@ def main():
                        "semantics": "fast (state-only forwards skipped)" if args.fast else
                                     "strict: every observable effect of the reference step (losses, both Adam updates, u/v, BN and RNG state)"},
         }
+        try:  # tail balancing of the weight-gradient stream (_streams.py): per recurring backward pass, the share of its weight-gradient
+            # cost that runs on the main stream and the last measured waits of the main stream at the join (ms; > 0: it waited)
+            from skillful_nowcasting_amd import _streams as _st
+
+            out["wgrad_tail_balance"] = [{"pass_calls": len(pr.costs), "inline_share": round(sh, 4), "join_wait_ms": hist}
+                                         for (k_, (sh, hist)), pr in zip(_st.tail_stats().items(), _st._tail_profiles.values())]
+        except Exception:  # noqa: BLE001
+            pass
         if replicas_in_sync is not None:
             out["replicas_in_sync"] = replicas_in_sync  # parameter checksums agree bit for bit across the ranks after the timed steps
         if pg_info is not None:

@@ -569,7 +569,8 @@ class ConvFn(Function):
                         call("dgmr_sn_wgrad_finalize", _p(g), _p(gw), None, None, None, None, cout, cin, taps, 1, 1, st)
 
             if _WGRAD_STREAM and ctx.needs_input_grad[0]:
-                _on_side_stream(dev, weight_grad, (x, dy, scale, bn_a, bn_b, sn_u, sn_v), lane=0 if spec.upsample else None)
+                _on_side_stream(dev, weight_grad, (x, dy, scale, bn_a, bn_b, sn_u, sn_v), lane=0 if spec.upsample else None,
+                                cost=float(m) * k * cout * (4.0 / 9.0 if spec.upsample else 1.0))
             else:
                 weight_grad()
         # ---- input ----
@@ -989,7 +990,7 @@ class ConvGRUFn(Function):
             keep = [buf, rh, dpr, dpu, dpc, x_all, isr, ur, vr, isu, uu, vu, isc, uc, vc]
             if x_shared:
                 keep += [x_rep] + dsum
-            _on_side_stream(dev, weight_grads, keep)
+            _on_side_stream(dev, weight_grads, keep, cost=float(tb * hh * ww) * kh * kw * (cx + ch) * 3 * ch)
         else:
             weight_grads()
         # ---- x-part data gradient, batched over the T steps (each step with its own 1/sigma) ----

@@ -230,7 +230,8 @@ def test_wave_specialised_wgrad_keeps_its_prefetch_in_flight(lib, tmp_path):
             if ns != 6:
                 assert not any("scratch_" in l for l in body), f"{asm[start]}: scratch traffic in the weight-gradient kernel"
             checked.add((bi, ns, tws, mw))
-    assert len(checked) == 20, sorted(checked)  # BI {64, 96} x tile {32x2, 16x4} x (bf16, bf16x3: 3 and 4 matrix waves; bf16x6: 3)
+    # BI {64, 96} x tile {32x2, 16x4} x (bf16, bf16x3: 3 and 4 matrix waves; bf16x6: 3) + the pixel-split 48-column tile (round 6) x tile x (bf16, bf16x3)
+    assert len(checked) == 24, sorted(checked)
 
 
 def test_missing_library_fails_loudly(monkeypatch):

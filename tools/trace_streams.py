@@ -128,6 +128,18 @@ def main():
         a = f"{c[0]:5d} {c[1]/1e6:8.2f} ms {c[1]/max(c[0],1)/1e3:9.1f} us" if c[0] else " " * 33
         b = f"{c[2]:5d} {c[3]/1e6:8.2f} ms {c[3]/max(c[2],1)/1e3:9.1f} us" if c[2] else ""
         out.append(f"    {k:78s} alone {a} | beside {b}")
+    # the main queue idle while another queue works: exposed tails of the side streams (joins before an optimiser step) and waits on them
+    mk = sorted(byq[main_q])
+    tails = []
+    for (s0, e0, n0), (s1, e1, n1) in zip(mk, mk[1:]):
+        if s1 > e0:
+            ov = overlap(e0, s1)
+            if ov > 0:
+                tails.append((ov, (s1 - e0), e0 - t0, short(n0), short(n1)))
+    tot_t = sum(t[0] for t in tails)
+    out.append(f"\nmain queue {main_q} idle while another queue is busy: {tot_t/1e6:.1f} ms in {len(tails)} gaps; the largest (other-queue busy ms | gap ms | at ms | main kernel before -> after):")
+    for ov, gap, at, n0, n1 in sorted(tails, reverse=True)[:14]:
+        out.append(f"    {ov/1e6:7.2f} | {gap/1e6:7.2f} | {at/1e6:7.1f} | {n0[:50]} -> {n1[:50]}")
     fam = defaultdict(int)
     for s, e, n in byq[main_q]:
         sn = short(n)
@@ -137,7 +149,7 @@ def main():
         fam[f_] += e - s
     out.append(f"\nmain queue {main_q} by family: " + "; ".join(f"{k} {v/1e6:.1f} ms" for k, v in sorted(fam.items(), key=lambda kv: -kv[1])))
     open(dst, "w").write("\n".join(out) + "\n")
-    print("\n".join(out[:60]))
+    print("\n".join(out[:60] + out[-40:]))
 
 
 if __name__ == "__main__":
