@@ -515,7 +515,8 @@ int dgmr_profile_collect_detail(char* buf, int cap);
  * allows / 2 the wave-specialised one (wgrad_ws.h: loader waves + matrix waves, ds_read_b64_tr_b16 fragments) with three matrix
  * waves (32x32x16 MFMAs, one filter row each) / 3 (= automatic) with four (16x16x32 MFMAs, one per SIMD; bf16x6: three) / 4 like 3,
  * and upsampling convs by output-pixel parity on the low-resolution map (wgrad_ws.h PHASE) even under DGMR_WGRAD_PHASES=0 (by default
- * that is the library's own choice where the four-wave kernel applies). */
+ * that is the library's own choice where the four-wave kernel applies) / 5 (round 6) like 3, but layers with <= 48 output channels on
+ * the 64-column tile of rounds 3 - 5 instead of the pixel-split 48-column one (wgrad_ws.h PSPLIT; the A/B reference) and no phase launches. */
 int dgmr_conv_tune(int variant, int ksplit, int window, int wgrad_window);
 /* Kernel-phase timing switches for tools/conv_bench.py (process-wide, 0 at load and in every product launch): bit 0 = the LDS-window
  * conv kernels return before their epilogue, bit 1 = they stage only their first input halo.  Outputs are then garbage by design;

@@ -64,7 +64,8 @@ def derive(r):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     step = load(os.path.join(src, "step_pmc_by_kernel.csv"))
-    out = {"steps_under_counters": "2 (bench.py --warmup 1 --steps 1: rows and shares cover both; they do the same work)",
+    out = {"commit": os.environ.get("DGMR_COMMIT", ""),  # (the tree the counters were taken on: the GPU box has no .git - pass it in)
+           "steps_under_counters": "2 (bench.py --warmup 1 --steps 1: rows and shares cover both; they do the same work)",
            "definition": "mfma_busy = sum SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x sum GRBM_GUI_ACTIVE / 8 XCDs) over the launches of a row: "
                          "the share of SIMD cycles in which the matrix pipe was busy, weighted by launch duration (rocprofv3 --pmc over one "
                          "whole training step of bench.py, paper config, per-GPU batch 16, `mixed`; dispatches run serialised under the "
