@@ -111,7 +111,10 @@ class GradSync:
         self._deviated = False
         self._locals: Dict[int, torch.Tensor] = {}
         self._comm_stream = None
-        self.stats = {"overlapped_buckets": 0, "late_buckets": 0, "deviations": 0}
+        # late_buckets: launched at sync() instead of during the backward pass; of those, late_buckets_recording_step belong to the first
+        # pass of a network (nothing recorded yet: every bucket is late) - what remains afterwards is one bucket per pass, the one the pass
+        # writes last, plus whatever a deviation from the recorded order left over
+        self.stats = {"overlapped_buckets": 0, "late_buckets": 0, "late_buckets_recording_step": 0, "deviations": 0}
         self._flatten_buffers(model)
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -289,6 +292,8 @@ class GradSync:
         for b in canonical:
             if b not in self._launched:
                 self._launch(fg, b, overlapped=False)
+                if ps.recorded is None:
+                    self.stats["late_buckets_recording_step"] += 1
         for b, work in self._launched.items():
             work.wait()  # (RCCL: the current stream waits for the collective; gloo: the host does)
         if fg.flat.is_cuda and self._comm_stream is not None:
