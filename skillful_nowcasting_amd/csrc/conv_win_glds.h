@@ -475,6 +475,9 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
             const int q4 = (lane & (MB - 1)) >> 2;                    // its column quad inside a block
             const int rsel = M16 ? lane >> 4 : lane >> 5;             // which rows of the block this lane group holds
             constexpr int NG = RPB / 4;                               // 4-row register groups per block
+            // ConvGRU epilogues: fetch a row group's operands ahead of its patches (128-pixel tiles: what the recurrent steps run; the
+            // 256-pixel tile with 96 columns has no registers for it and no ConvGRU launch of the step uses it)
+            constexpr bool GRU_AHEAD = BM == 128;
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
             // output pixel (row of the [pixels][Cout] matrix) of this lane in each of its TM x NG row groups; the residual's when it is
             // at half resolution
@@ -508,21 +511,32 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
                     const float scj = is2 ? (p.scale2 ? p.scale2[smp / p.scale_group] : 1.f) : sc;
     #pragma unroll
                     for (int i = 0; i < TM; ++i) {
+                        // (operands of the row group's four patches first, then the patches: see the plain path below)
+                        f32x4 ad[NG], hvs[NG];
+                        if constexpr (GRU_AHEAD) {
+    #pragma unroll
+                            for (int g = 0; g < NG; ++g) ad[g] = ap ? *reinterpret_cast<const f32x4*>(ap + ((size_t)mpix[i][g] * C + c0)) : zero4;
+    #pragma unroll
+                            for (int g = 0; g < NG; ++g) hvs[g] = is2 ? zero4 : *reinterpret_cast<const f32x4*>(p.gru_h + ((size_t)mpix[i][g] * C + c0));
+                        }
     #pragma unroll
                         for (int g = 0; g < NG; ++g) {
                             const size_t off = (size_t)mpix[i][g] * C + c0;
+                            if constexpr (!GRU_AHEAD) {
+                                ad[g] = ap ? *reinterpret_cast<const f32x4*>(ap + off) : zero4;
+                                hvs[g] = is2 ? zero4 : *reinterpret_cast<const f32x4*>(p.gru_h + off);
+                            }
                             f32x4 v = quad_transpose(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], lane);
-                            if (ap) v += *reinterpret_cast<const f32x4*>(ap + off);
+                            if (ap) v += ad[g];
     #pragma unroll
                             for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], scj, b4[c]);
                             if (!cok) continue;
                             if (is2) {
                                 *reinterpret_cast<f32x4*>(p.y2 + off) = v;
                             } else {
-                                const f32x4 hv = *reinterpret_cast<const f32x4*>(p.gru_h + off);
                                 f32x4 o;
     #pragma unroll
-                                for (int c = 0; c < 4; ++c) o[c] = sigmoid_(v[c]) * hv[c];
+                                for (int c = 0; c < 4; ++c) o[c] = sigmoid_(v[c]) * hvs[g][c];
                                 if (p.pre_out) *reinterpret_cast<f32x4*>(p.pre_out + off) = v;
                                 *reinterpret_cast<f32x4*>(p.y + off) = o;
                             }
@@ -539,38 +553,98 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
                     mb4 = *reinterpret_cast<const f32x4*>(p.mask_b + g);
                 }
                 f32x4 s0 = zero4, s1 = zero4;
+                // (round 6) The fused operands of a row group are fetched UP FRONT, four patches at a time, and the patches are then finished
+                // and stored with no memory wait in between.  The loop of rounds 3 - 5 loaded each patch's residual / mask source inside the
+                // patch and the compiler's one `s_waitcnt vmcnt(0)` per patch - placed at the join of the operand branches, so it ran even
+                // when a launch had no operand at all - also waited for the PREVIOUS patch's store to be acknowledged: 24 store round trips
+                // per wave and tile, one after the other; that serial chain, not the transposes, was the "12 - 38 % of a launch" the epilogue
+                // cost (tools/isa_outline.py; profiles/r06_epilogue_hoisted_loads_ab.log).  Same arithmetic per element, in the same
+                // order: bit-identical outputs.
+                if (emode == DGMR_EPI_PLAIN && !p.addend && !p.residual && !p.mask_src) {
+                    // no fused operand (the first convs of the G-blocks, every launch of a no-grad forward that has no shortcut to add): a
+                    // path WITHOUT any load, hence without any wait - the 24 stores of a wave stream out back to back
     #pragma unroll
-                for (int i = 0; i < TM; ++i) {
+                    for (int i = 0; i < TM; ++i) {
     #pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const size_t off = (size_t)mpix[i][g] * p.Cout + cc;
-                        f32x4 v = quad_transpose(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], lane);
-                        if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + off);
-    #pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], sc, b4[c]);
-                        if (emode == DGMR_EPI_PLAIN) {
-                            f32x4 rs = zero4, ms = zero4;
-                            if (p.residual) rs = *reinterpret_cast<const f32x4*>(p.residual + (size_t)rpix[i][g] * p.Cout + cc);
-                            if (p.mask_src) ms = *reinterpret_cast<const f32x4*>(p.mask_src + off);
-                            f32x4 o = v;
+                        for (int g = 0; g < NG; ++g) {
+                            const size_t off = (size_t)mpix[i][g] * p.Cout + cc;
+                            f32x4 o = quad_transpose(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], lane);
     #pragma unroll
                             for (int c = 0; c < 4; ++c) {
+                                o[c] = fmaf(o[c], sc, b4[c]);
                                 if (p.act_relu) o[c] = fmaxf(o[c], 0.f);
-                                if (p.residual) o[c] += rs[c];
-                                if (p.mask_src) o[c] = fmaf(ms[c], ma4[c], mb4[c]) > 0.f ? o[c] : 0.f;
                             }
                             if (cok) *reinterpret_cast<f32x4*>(p.y + off) = o;
                             if (want_stats_v) {
     #pragma unroll
                                 for (int c = 0; c < 4; ++c) {
                                     s0[c] += o[c];
-                                    s1[c] = fmaf(o[c], p.mask_src ? ms[c] : o[c], s1[c]);
+                                    s1[c] = fmaf(o[c], o[c], s1[c]);
                                 }
                             }
-                        } else {  // ConvGRU step: pre_out = v; gate: y = sigmoid(v) * h; blend: y = s*h + (1-s)*relu(v), s = sigmoid(pu)
-                            const f32x4 hv = *reinterpret_cast<const f32x4*>(p.gru_h + off);
-                            f32x4 pv = zero4, o;
-                            if (emode == DGMR_EPI_GRU_BLEND) pv = *reinterpret_cast<const f32x4*>(p.gru_pu + off);
+                        }
+                    }
+                } else if (emode == DGMR_EPI_PLAIN) {
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        f32x4 ad[NG], rs[NG], ms[NG];
+    #pragma unroll
+                        for (int g = 0; g < NG; ++g) ad[g] = p.addend ? *reinterpret_cast<const f32x4*>(p.addend + ((size_t)mpix[i][g] * p.Cout + cc)) : zero4;
+    #pragma unroll
+                        for (int g = 0; g < NG; ++g) rs[g] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + (size_t)rpix[i][g] * p.Cout + cc) : zero4;
+    #pragma unroll
+                        for (int g = 0; g < NG; ++g) ms[g] = p.mask_src ? *reinterpret_cast<const f32x4*>(p.mask_src + ((size_t)mpix[i][g] * p.Cout + cc)) : zero4;
+    #pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            const size_t off = (size_t)mpix[i][g] * p.Cout + cc;
+                            f32x4 v = quad_transpose(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], lane);
+                            if (p.addend) v += ad[g];
+    #pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], sc, b4[c]);
+                            f32x4 o = v;
+    #pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (p.act_relu) o[c] = fmaxf(o[c], 0.f);
+                                if (p.residual) o[c] += rs[g][c];
+                                if (p.mask_src) o[c] = fmaf(ms[g][c], ma4[c], mb4[c]) > 0.f ? o[c] : 0.f;
+                            }
+                            if (cok) *reinterpret_cast<f32x4*>(p.y + off) = o;
+                            if (want_stats_v) {
+    #pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    s0[c] += o[c];
+                                    s1[c] = fmaf(o[c], p.mask_src ? ms[g][c] : o[c], s1[c]);
+                                }
+                            }
+                        }
+                    }
+                } else {
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        // ConvGRU step: pre_out = v; gate: y = sigmoid(v) * h; blend: y = s*h + (1-s)*relu(v), s = sigmoid(pu)
+                        f32x4 ad[NG], hvs[NG], pvs[NG];
+                        if constexpr (GRU_AHEAD) {
+    #pragma unroll
+                            for (int g = 0; g < NG; ++g) ad[g] = p.addend ? *reinterpret_cast<const f32x4*>(p.addend + ((size_t)mpix[i][g] * p.Cout + cc)) : zero4;
+    #pragma unroll
+                            for (int g = 0; g < NG; ++g) hvs[g] = *reinterpret_cast<const f32x4*>(p.gru_h + ((size_t)mpix[i][g] * p.Cout + cc));
+    #pragma unroll
+                            for (int g = 0; g < NG; ++g) pvs[g] = emode == DGMR_EPI_GRU_BLEND ? *reinterpret_cast<const f32x4*>(p.gru_pu + ((size_t)mpix[i][g] * p.Cout + cc)) : zero4;
+                        }
+    #pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            const size_t off = (size_t)mpix[i][g] * p.Cout + cc;
+                            if constexpr (!GRU_AHEAD) {
+                                ad[g] = p.addend ? *reinterpret_cast<const f32x4*>(p.addend + off) : zero4;
+                                hvs[g] = *reinterpret_cast<const f32x4*>(p.gru_h + off);
+                                pvs[g] = emode == DGMR_EPI_GRU_BLEND ? *reinterpret_cast<const f32x4*>(p.gru_pu + off) : zero4;
+                            }
+                            f32x4 v = quad_transpose(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], lane);
+                            if (p.addend) v += ad[g];
+    #pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], sc, b4[c]);
+                            const f32x4 hv = hvs[g], pv = pvs[g];
+                            f32x4 o;
     #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 if (emode == DGMR_EPI_GRU_BLEND) {
