@@ -125,14 +125,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const dgmr_conv_args p,
             const int ks = kk * 2 + kg;
             bf16x8_t af[NP][TM], bf[NP][TN];
             const int ob = (ks ^ bsw) << 2;
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
+            for (int t = 0; t < NP; ++t) {  // (in the order the products consume them: schedule_split_products, conv_bf16.h)
+                const int qa = NP - 1 - t, qb = t;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    af[q][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab[i] + q * BM * ROW + ((ks ^ asw[i]) << 2)));
+                    af[qa][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab[i] + qa * BM * ROW + ((ks ^ asw[i]) << 2)));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bf[q][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (q * BN + j * 32) * ROW + ob));
+                    bf[qb][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (qb * BN + j * 32) * ROW + ob));
             }
             for_each_product<NP>([&](auto qa, auto qb) {
 #pragma unroll
@@ -140,6 +142,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const dgmr_conv_args p,
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = mfma_blk<false>(af[qa][i], bf[qb][j], acc[i][j]);
             });
+            schedule_split_products<NP, TM, TN>();
+            __builtin_amdgcn_s_setprio(0);
         }
     };
 

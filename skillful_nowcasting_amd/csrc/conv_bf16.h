@@ -67,6 +67,35 @@ __device__ __forceinline__ void for_each_product(F&& f) {
     product_step<NP - 1, NP - 1>(f);
 }
 
+// Instruction order asked of the scheduler for one 16-channel step of a split contraction (round 6).  The fragments are READ in the order
+// the products consume them - for_each_product starts with A's last plane x B's first, so read (A[NP-1], B[0]), (A[NP-2], B[1]), ... -
+// and the reads of pair t + 1 are spread between the MFMAs of product t: LDS reads return in order, so the first MFMAs issue as soon as
+// the first TM + TN fragments have landed.  Left alone the compiler clusters all reads of a step and waits for every one of them
+// (`s_waitcnt lgkmcnt(0)`) before the first MFMA - the LDS latency of a step fully exposed, twice per tap of the window kernel
+// (803.6 vs 816.4 ms per training step from that kernel alone).  The s_setprio pair must enclose reads AND MFMAs: it bounds a
+// scheduling region.  The builtin wants literal counts, hence the templates.
+template <int READS, int M, int I>
+__device__ __forceinline__ void mfma_read_interleave() {
+    if constexpr (I < M) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        constexpr int N = (READS * (I + 1)) / M - (READS * I) / M;
+        if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(0x100, N, 0);
+        mfma_read_interleave<READS, M, I + 1>();
+    }
+}
+template <int NP, int TM, int TN, int T = 1>
+__device__ __forceinline__ void schedule_split_products() {
+    if constexpr (NP >= 2) {
+        if constexpr (T == 1) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        if constexpr (T < NP) {
+            mfma_read_interleave<TM + TN, TM * TN, 0>();
+            schedule_split_products<NP, TM, TN, T + 1>();
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, (NP * (NP + 1) / 2 - (NP - 1)) * TM * TN, 0);
+        }
+    }
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int NS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_conv_args p, const int M, const int Ktot,
                                                                   const int kt_per_split) {
@@ -226,23 +255,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_bf16_kernel(const dgmr_c
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8_t af[NP][TM], bf[NP][TN];
+            __builtin_amdgcn_s_setprio(1);  // the co-resident workgroup is usually in its load / store phase: matrix pipe first
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
+            for (int t = 0; t < NP; ++t) {  // (in the order the products consume them: schedule_split_products)
+                const int qa = NP - 1 - t, qb = t;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    af[q][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab + (q * BM + i * 32) * LDW + kk * 8));
+                    af[qa][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ab + (qa * BM + i * 32) * LDW + kk * 8));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bf[q][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (q * BN + j * 32) * LDW + kk * 8));
+                    bf[qb][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (qb * BN + j * 32) * LDW + kk * 8));
             }
             // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); small terms first
-            __builtin_amdgcn_s_setprio(1);  // the co-resident workgroup is usually in its load / store phase: matrix pipe first
             for_each_product<NP>([&](auto qa, auto qb) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa][i], bf[qb][j], acc[i][j], 0, 0, 0);
             });
+            schedule_split_products<NP, TM, TN>();
             __builtin_amdgcn_s_setprio(0);
         }
     };
@@ -437,23 +468,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const dgmr_wgra
 #pragma unroll
         for (int kk = 0; kk < BR / 16; ++kk) {
             bf16x8_t yf[NP][TM], xf[NP][TN];
+            __builtin_amdgcn_s_setprio(1);  // the co-resident workgroup is usually in its load / store phase: matrix pipe first
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
+            for (int t = 0; t < NP; ++t) {  // (in the order the products consume them: schedule_split_products)
+                const int qa = NP - 1 - t, qb = t;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    yf[q][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Yb + (q * BI + i * 32) * LDW + kk * 8));
+                    yf[qa][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Yb + (qa * BI + i * 32) * LDW + kk * 8));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    xf[q][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Xb + (q * BJ + j * 32) * LDW + kk * 8));
+                    xf[qb][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Xb + (qb * BJ + j * 32) * LDW + kk * 8));
             }
             // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent issue); small terms first
-            __builtin_amdgcn_s_setprio(1);  // the co-resident workgroup is usually in its load / store phase: matrix pipe first
             for_each_product<NP>([&](auto qa, auto qb) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[qa][i], xf[qb][j], acc[i][j], 0, 0, 0);
             });
+            schedule_split_products<NP, TM, TN>();
             __builtin_amdgcn_s_setprio(0);
         }
         if (it + 1 < nr) store(cur ^ 1);

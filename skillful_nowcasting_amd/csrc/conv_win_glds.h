@@ -48,17 +48,6 @@ __device__ __forceinline__ ACC mfma_blk(const bf16x8_t& a, const bf16x8_t& b, co
 #endif
 }
 
-// scheduling template "one MFMA, its share of READS LDS reads" x M (the builtin wants literal counts; as ws_interleave of wgrad_ws.h)
-template <int READS, int M, int I>
-__device__ __forceinline__ void win_interleave() {
-    if constexpr (I < M) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        constexpr int N = (READS * (I + 1)) / M - (READS * I) / M;
-        if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(0x100, N, 0);
-        win_interleave<READS, M, I + 1>();
-    }
-}
-
 // value of lane ^ 1 / lane ^ 2 (inside a quad of lanes: DPP quad_perm [1,0,3,2] / [2,3,0,1] - a VALU move, no LDS traffic)
 __device__ __forceinline__ float quad_xor1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
@@ -331,10 +320,10 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
             const int ks = M16 ? kg : kk * 2 + kg;  // logical 16-byte k-slot of this lane's fragment
             bf16x8_t af[NP][TM], bf[NP][TN];
             const int ob = (ks ^ bsw) << 2;
-            if constexpr (NP == 2) __builtin_amdgcn_s_setprio(1);  // (in front of the reads: s_setprio bounds a scheduling region)
+            __builtin_amdgcn_s_setprio(1);  // (in front of the reads: s_setprio bounds a scheduling region)
             // fragments in the order the products consume them (for_each_product: lowest planes' product first = A's LAST plane with B's
             // first): LDS reads return in order, so the first MFMAs can issue while the later fragments are still on their way - read in
-            // plane order they all had to land first (`s_waitcnt lgkmcnt(0)` in front of every 16-channel step)
+            // plane order they all had to land first (`s_waitcnt lgkmcnt(0)` in front of every 16-channel step; conv_bf16.h)
 #pragma unroll
             for (int t = 0; t < NP; ++t) {
                 const int qa = NP - 1 - t, qb = t;
@@ -345,22 +334,13 @@ __global__ __launch_bounds__(256, (BN == 128 || BM == 256 || PRIV || NS == 6 || 
                 for (int j = 0; j < TN; ++j)
                     bf[qb][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Bb + (qb * BPLANE + j * MB) * ROW + ob));
             }
-            if constexpr (NP != 2) __builtin_amdgcn_s_setprio(1);
             for_each_product<NP>([&](auto qa, auto qb) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = mfma_blk<M16>(af[qa][i], bf[qb][j], acc[i][j]);
             });
-            if constexpr (NP == 2) {
-                // instruction order asked of the scheduler: the first product's fragments (TM + TN reads), then that product's MFMAs
-                // with the other TM + TN reads spread between them, then the two products those feed.  Left alone the compiler
-                // clusters all ten reads and waits for every one of them (`s_waitcnt lgkmcnt(0)`) before the first MFMA of each
-                // 16-channel step: the LDS latency of a step was exposed twice per tap.
-                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-                win_interleave<TM + TN, TM * TN, 0>();
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
-            }
+            schedule_split_products<NP, TM, TN>();  // (conv_bf16.h: the reads of the next plane pair between the MFMAs of a product)
             __builtin_amdgcn_s_setprio(0);
         }
     };
