@@ -5,6 +5,7 @@ No arithmetic lives here that is not a call into libdgmr_hip.so; there is no CPU
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
@@ -127,6 +128,24 @@ def _scratch(numel: int, device, key: str) -> torch.Tensor:
         buf = torch.empty(numel, device=device, dtype=torch.float32)
         _SCRATCH[k] = buf
     return buf[:numel]
+
+
+_ASYNC_UPLOAD = os.environ.get("DGMR_ASYNC_UPLOAD", "1") != "0"  # A/B switch: 0 = the blocking `.to(device)` of rounds 1 - 6
+
+
+def upload(t: torch.Tensor, device, dtype=None) -> torch.Tensor:
+    """A small host tensor (a latent draw, drawn frame indices - both come from the CPU generator, as in the reference) on `device`
+    WITHOUT blocking the host.  `t.to(device)` from pageable memory is a synchronous copy, ordered behind everything queued on the
+    stream: the host waits for the GPU to drain - eleven times per training step - and the GPU then idles until the host has issued
+    new work (the 0.4 - 6 ms gaps after `__amd_rocclr_copyBuffer` in `profiles/r06_final2_B16_kernel_gaps.txt`, host time per step =
+    device time per step).  Staged through pinned memory the copy is asynchronous; torch's caching host allocator keeps the pinned
+    block alive until the copy has executed (it records an event for `non_blocking` copies out of pinned memory)."""
+    src = t if dtype is None or t.dtype == dtype else t.to(dtype)
+    if not _ASYNC_UPLOAD or torch.device(device).type != "cuda":
+        return src.to(device)
+    pinned = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+    pinned.copy_(src)
+    return pinned.to(device, non_blocking=True)
 
 
 def require_hip(t: torch.Tensor, what: str = "input"):

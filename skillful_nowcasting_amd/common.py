@@ -200,7 +200,7 @@ class LatentConditioningStack(torch.nn.Module, PyTorchModelHubMixin):
         """One latent draw [1, shape[0], h, w] on x's device.  z comes from the CPU generator exactly as in the reference
         (common.py:481-483): fixed seeds give the same latent on both sides.  Only 8*h*w floats cross PCIe."""
         z = self.distribution.sample(self.shape)
-        return torch.permute(z, (3, 0, 1, 2)).type_as(x)
+        return ops.upload(torch.permute(z, (3, 0, 1, 2)), x.device, x.dtype)  # (asynchronous; same values as `.type_as(x)`)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.forward_latent(self.draw(x))

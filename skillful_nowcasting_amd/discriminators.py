@@ -119,7 +119,7 @@ class SpatialDiscriminator(torch.nn.Module, PyTorchModelHubMixin):
         ops.require_hip(x, "discriminator frames")
         # frame indices come from the CPU generator exactly as in the reference (discriminators.py:199): one draw per call
         idxs = torch.stack([torch.randint(low=0, high=x.size()[1], size=(self.num_timesteps,)) for _ in range(calls)])
-        idxs_dev = idxs.to(device=x.device, dtype=torch.int32)
+        idxs_dev = ops.upload(idxs, x.device, torch.int32)  # (asynchronous: the host does not wait for the queue to drain)
         frames = self.num_timesteps
         lay = _frame_layout(calls, frames)
         groups = frames * calls

@@ -27,7 +27,7 @@ from ._lib import ConvArgs, WgradArgs, call
 from . import _core, _streams
 from ._core import (BNState, CallLayout, SNCall, SPLITK_WS_BYTES, _copy, _dims, _p, _scratch, _splitk_ws, _stream, bn_prepare,  # noqa: F401
                     bias_rows, bump_weights_epoch, call_slots, deterministic, dot_buffer, empty_cl, grad_buffer, require_hip,
-                    require_weight_layout, set_deterministic, set_grad_touch_hook, sums_buffer, colsum_tmp, to_cl, weights_epoch)
+                    require_weight_layout, set_deterministic, set_grad_touch_hook, sums_buffer, colsum_tmp, to_cl, upload, weights_epoch)
 from ._head_ops import (AttentionFn, AxpbyFn, BatchNorm1dFn, GridCellFn, HingeDiscFn, MeanFn, ReluSumHWFn, SNLinear1Fn, adam_update,  # noqa: F401
                         attention, axpby, relu_sum_hw)
 from ._layout_ops import (CatChannelsFn, D2SFramesFn, FramesS2DFn, FramesToBatchFn, PoolAddFn, RepeatBatchFn, StackBatchFn,  # noqa: F401

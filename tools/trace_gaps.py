@@ -24,9 +24,11 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     min_gap = float(sys.argv[3]) if len(sys.argv) > 3 else 20.0
     ev = []
+    queues = []
     with open(src) as f:
         for r in csv.DictReader(f):
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Kernel_Name") or r.get("Name")))
+            queues.append((ev[-1][0], ev[-1][1], ev[-1][2], r.get("Queue_Id") or r.get("Stream_Id") or "?"))
     ev.sort()
     last_ms = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
     if last_ms > 0:
@@ -81,6 +83,18 @@ def main():
         if g / 1e3 < min_gap:
             break
         out.append(f"  {g/1e3:9.1f} | {(s-t0)/1e6:9.1f} | {short(p or '')} -> {short(n)}")
+    # what ran around the five largest gaps: queue | start ms | duration us | kernel (the 8 launches on either side, every queue)
+    queues.sort()
+    starts = [q[0] for q in queues]
+    import bisect
+
+    for g, p, n, s in sorted(gaps, key=lambda x: -x[0])[:5]:
+        if g / 1e3 < 200:
+            break
+        i = bisect.bisect_left(starts, s)
+        out.append(f"around the {g/1e3:.0f} us gap at {(s-t0)/1e6:.1f} ms:")
+        for qs, qe, qn, qq in queues[max(0, i - 8):i + 8]:
+            out.append(f"    q{qq:>3s} | {(qs-t0)/1e6:9.3f} | {(qe-qs)/1e3:9.1f} | {short(qn)}")
     open(dst, "w").write("\n".join(out) + "\n")
     print("\n".join(out[:16]))
 
