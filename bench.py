@@ -309,7 +309,10 @@ def time_steps(model, batch, first_idx, n, barrier):
     t0 = time.perf_counter()
     evs[0].record()
     host = []
+    step_sync = os.environ.get("DGMR_BENCH_STEP_SYNC") == "1"  # A/B switch: drain the device before every step (how much of a result is the host's lead)
     for i in range(n):
+        if step_sync:
+            torch.cuda.synchronize()
         h0 = time.perf_counter()
         model.training_step(batch, first_idx + i)
         evs[i + 1].record()

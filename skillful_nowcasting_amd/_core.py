@@ -133,6 +133,11 @@ def _scratch(numel: int, device, key: str) -> torch.Tensor:
 _ASYNC_UPLOAD = os.environ.get("DGMR_ASYNC_UPLOAD", "1") != "0"  # A/B switch: 0 = the blocking `.to(device)` of rounds 1 - 6
 
 
+def _process_group_active() -> bool:
+    d = torch.distributed
+    return d.is_available() and d.is_initialized()
+
+
 def upload(t: torch.Tensor, device, dtype=None) -> torch.Tensor:
     """A small host tensor (a latent draw, drawn frame indices - both come from the CPU generator, as in the reference) on `device`
     WITHOUT blocking the host.  `t.to(device)` from pageable memory is a synchronous copy, ordered behind everything queued on the
@@ -141,7 +146,12 @@ def upload(t: torch.Tensor, device, dtype=None) -> torch.Tensor:
     device time per step).  Staged through pinned memory the copy is asynchronous; torch's caching host allocator keeps the pinned
     block alive until the copy has executed (it records an event for `non_blocking` copies out of pinned memory)."""
     src = t if dtype is None or t.dtype == dtype else t.to(dtype)
-    if not _ASYNC_UPLOAD or torch.device(device).type != "cuda":
+    if not _ASYNC_UPLOAD or torch.device(device).type != "cuda" or _process_group_active():
+        # Under a process group the blocking copies STAY (measured, `profiles/r06_async_upload_and_host_lead.log`): with the host
+        # running ahead, the one-rank RCCL configuration went from 820 - 825 to 896 - 899 ms per step; draining the device once per
+        # step gave half of that back (861 - 863).  There the host's lead lets the weight-gradient stream's backlog compete with the
+        # data-gradient chain much earlier (it finishes 134 ms before BOTH discriminator joins instead of 114 / 22), and HIP has no
+        # stream priority below normal (priority_range() = (0, -1)) to hold it back with: the eleven copies are the throttle.
         return src.to(device)
     pinned = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
     pinned.copy_(src)

@@ -20,6 +20,10 @@ with open(src) as f:
         name = r.get("Kernel_Name") or r.get("Name")
         grid = "x".join(str(r.get(k, "")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")) if "Grid_Size_X" in r else r.get("Grid_Size", "")
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, grid))
+_skip = float(__import__('os').environ.get('TRACE_SKIP_TAIL_MS', '0'))  # drop the trace's last ms (bench.py's post-loop diagnostics under a process group)
+if _skip > 0:
+    _hi = max(e for _, e, _, _ in ev) - int(_skip * 1e6)
+    ev = [x for x in ev if x[0] < _hi]
 if last_ms > 0:
     cut = max(e for _, e, _, _ in ev) - int(last_ms * 1e6)
     ev = [x for x in ev if x[0] >= cut]

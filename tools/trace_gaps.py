@@ -31,6 +31,11 @@ def main():
             queues.append((ev[-1][0], ev[-1][1], ev[-1][2], r.get("Queue_Id") or r.get("Stream_Id") or "?"))
     ev.sort()
     last_ms = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+    skip = float(__import__('os').environ.get('TRACE_SKIP_TAIL_MS', '0'))  # drop the trace's last ms (post-loop diagnostics)
+    if skip > 0:
+        hi = max(e for _, e, _ in ev) - int(skip * 1e6)
+        ev = [x for x in ev if x[0] < hi]
+        queues = [q for q in queues if q[0] < hi]
     if last_ms > 0:
         cut = max(e for _, e, _ in ev) - int(last_ms * 1e6)
         ev = [x for x in ev if x[0] >= cut]

@@ -28,6 +28,10 @@ def main():
         for r in csv.DictReader(f):
             q = r.get("Queue_Id") or r.get("Stream_Id") or "0"
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Kernel_Name") or r.get("Name"), q))
+    skip = float(__import__('os').environ.get('TRACE_SKIP_TAIL_MS', '0'))  # drop the trace's last ms (post-loop diagnostics)
+    if skip > 0:
+        hi = max(e for _, e, _, _ in ev) - int(skip * 1e6)
+        ev = [x for x in ev if x[0] < hi]
     if last_ms > 0:
         cut = max(e for _, e, _, _ in ev) - int(last_ms * 1e6)
         ev = [x for x in ev if x[0] >= cut]
