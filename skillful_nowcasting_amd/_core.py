@@ -27,6 +27,32 @@ def weights_epoch() -> int:
     return _WEIGHTS_EPOCH
 
 
+# Round 6: an optimiser step marks ITS parameters, not every weight of the process.  The caches of derived weight images (bf16 planes,
+# flipped / phase / pooled tap sums, W W^T) were keyed on one global counter: a discriminator step also invalidated every image of the
+# generator's unchanged weights and vice versa - of the three rebuilds per training step two (generator) and one (discriminator) were
+# redundant, ~400 small launches on the forward passes' critical path.  Keyed by the address of the parameter's storage; a tensor that
+# is not a stepped parameter (a view at an offset, a temporary) falls back to the count of ALL optimiser steps - the old behaviour.
+# Out-of-band writes (load_state_dict, the parameter broadcast, tests) keep using bump_weights_epoch(), which invalidates everything.
+_PARAM_STEP = {}   # parameter data_ptr -> number of optimiser steps that wrote it
+_ANY_STEP = [0]    # optimiser steps of any optimiser
+_PER_PARAM = os.environ.get("DGMR_PARAM_EPOCH", "1") != "0"  # A/B switch: 0 = every optimiser step invalidates every image
+
+
+def note_optimizer_step(params):
+    """The optimiser has just written `params` in place (raw pointers: torch's version counters do not move)."""
+    _ANY_STEP[0] += 1
+    for p in params:
+        k = p.data_ptr()
+        _PARAM_STEP[k] = _PARAM_STEP.get(k, 0) + 1
+
+
+def weight_tag(w: torch.Tensor):
+    """What a cached image of weight `w` is valid for: torch's version counter, the global out-of-band epoch, the optimiser steps that
+    wrote this parameter (or, for a tensor that is not a stepped parameter, all optimiser steps), address and shape."""
+    e = _PARAM_STEP.get(w.data_ptr()) if _PER_PARAM else None
+    return (w._version, _WEIGHTS_EPOCH, e if e is not None else -1 - _ANY_STEP[0], w.data_ptr(), tuple(w.shape))
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -357,7 +357,7 @@ class _SpectralNormBase(nn.Module):
         """W W^T (in a persistent buffer), recomputed only when the optimiser (or a load_state_dict) has changed W."""
         w = self.weight_orig
         buf = self._gram_buffer()
-        tag = (w._version, ops.weights_epoch(), w.data_ptr())
+        tag = ops._core.weight_tag(w)
         if self._gram_tag != tag:
             ops.weight_gram(w, out=buf)
             self._gram_tag = tag

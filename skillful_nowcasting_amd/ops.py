@@ -187,7 +187,7 @@ def _flipped_weight(w: torch.Tensor, coff: int = 0, cin: Optional[int] = None) -
     if cin is None:
         cin = cin_total
     key = (id(w), coff, cin)
-    tag = (w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    tag = _core.weight_tag(w)
     hit = _flip_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:  # the weakref guards against id() reuse after a parameter is freed
         return hit[1]
@@ -220,7 +220,7 @@ def _split_planes(w: torch.Tensor, flipped: bool, coff: int = 0, cin: Optional[i
         return None
     planes = _PLANES[_PRECISION_CODE]
     key = (id(w), flipped, coff, cin, planes)
-    tag = (w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    tag = _core.weight_tag(w)
     hit = _split_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
@@ -244,7 +244,7 @@ def _split_planes_cat(ws: Sequence[torch.Tensor], coff: int, cin: int) -> Option
         return None
     planes = _PLANES[_PRECISION_CODE]
     key = (tuple(id(w) for w in ws), "cat", coff, cin, planes)
-    tag = tuple((w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape)) for w in ws)
+    tag = tuple(_core.weight_tag(w) for w in ws)
     hit = _split_cache.get(key)
     if hit is not None and hit[0] == tag and all(r() is w for r, w in zip(hit[2], ws)):
         return hit[1]
@@ -272,7 +272,7 @@ def _phase_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
     cout, cin = w.shape[0], w.shape[1]
     planes = _PLANES[_PRECISION_CODE]
     key = (id(w), "phase", planes)
-    tag = (w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    tag = _core.weight_tag(w)
     hit = _phase_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
@@ -292,7 +292,7 @@ def _pool2_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
     cout, cin = w.shape[0], w.shape[1]
     planes = _PLANES[_PRECISION_CODE]
     key = (id(w), "pool2", planes)
-    tag = (w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    tag = _core.weight_tag(w)
     hit = _phase_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]
@@ -314,7 +314,7 @@ def _pool2_fwd_planes(w: torch.Tensor) -> Optional[torch.Tensor]:
     kd = 3 if w.dim() == 5 else 1
     planes = _PLANES[_PRECISION_CODE]
     key = (id(w), "pool2f", planes)
-    tag = (w._version, _core._WEIGHTS_EPOCH, w.data_ptr(), tuple(w.shape))
+    tag = _core.weight_tag(w)
     hit = _phase_cache.get(key)
     if hit is not None and hit[0] == tag and hit[2]() is w:
         return hit[1]

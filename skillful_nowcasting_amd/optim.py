@@ -31,12 +31,14 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        written = []
         for group in self.param_groups:
             b1, b2 = group["betas"]
             todo = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
+                written.append(p)
                 ops.require_hip(p, "parameter")
                 st = self.state[p]
                 if len(st) == 0:
@@ -53,7 +55,7 @@ class FusedAdam(torch.optim.Optimizer):
                     ops.adam_update(p, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], b1, b2, group["eps"])
             if todo:
                 self._step_multi(todo, group["lr"], b1, b2, group["eps"])
-        ops.bump_weights_epoch()
+        ops._core.note_optimizer_step(written)  # (the images of THESE weights are stale; everything else keeps its caches)
         return loss
 
     def _step_multi(self, todo, lr, b1, b2, eps):
