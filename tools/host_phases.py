@@ -56,8 +56,7 @@ from skillful_nowcasting_amd import nn as snn  # noqa: E402
 
 wrap(snn.SNPlan, "run", "  SNPlan.run")
 wrap(snn.SNScope, "_prefetch", "  SNScope._prefetch")
-wrap(model.generator.conditioning_stack, "forward", "  conditioning stack (host)") if hasattr(model.generator, "conditioning_stack") else None
-wrap(model.generator.sampler, "forward", "  sampler (host)") if hasattr(model.generator, "sampler") else None
+wrap(model.generator.conditioning_stack, "forward", "  conditioning stack (the first launches of a forward: where the host waits for queue space)")
 g_opt, d_opt = model.optimizers()
 wrap(g_opt, "step", "g_opt.step")
 wrap(d_opt, "step", "d_opt.step")
