@@ -62,3 +62,23 @@ def test_upload_on_cpu_is_a_plain_conversion():
     z = torch.randn(8, 8, 8, 1).permute(3, 0, 1, 2)
     assert torch.equal(_core.upload(z, "cpu", torch.float32), z)
     assert _core._process_group_active() is False
+
+
+def test_uploads_stay_blocking_under_a_process_group():
+    """_core.upload keeps the synchronous copy whenever torch.distributed is initialised (profiles/r06_async_upload_and_host_lead.log, part 3)."""
+    import os
+
+    import torch.distributed as dist
+
+    if dist.is_initialized():  # (another test of this process owns a group: the predicate is all there is to check)
+        assert _core._process_group_active()
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert _core._process_group_active()
+        assert torch.equal(_core.upload(torch.arange(4), "cpu", torch.int32), torch.arange(4, dtype=torch.int32))
+    finally:
+        dist.destroy_process_group()
+    assert not _core._process_group_active()
